@@ -1,0 +1,244 @@
+/*
+ * theia_hip.h -- C ABI of libtheia_hip.so: the MI355X (gfx950) transient
+ * photon-tracing backend behind theia's SceneForwardTracer / VolumeForwardTracer.
+ *
+ * The reference (tkerscher/theia) has no FFI; the seam this library sits
+ * behind is the `hephaistos` PipelineStage protocol. Each
+ * entry point below names the reference interface it replaces (paths relative
+ * to /root/reference). Conventions: C linkage, opaque handles, `int` status
+ * (0 ok, <0 error; thx_last_error() gives the text), caller owns host memory,
+ * the library owns device memory, calls on one context are serialised by the
+ * caller, launches are asynchronous on a HIP stream, reads synchronise.
+ *
+ * Parameter blocks are the reference's UBO layouts verbatim (scalar layout,
+ * tightly packed, docs/pipeline/extend.md:163-164).
+ */
+#ifndef THEIA_HIP_H
+#define THEIA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define THX_OK 0
+#define THX_ERR_INVALID (-1)     /* bad argument */
+#define THX_ERR_HIP (-2)         /* HIP runtime error */
+#define THX_ERR_NO_DEVICE (-3)   /* no usable gfx950 device */
+#define THX_ERR_UNSUPPORTED (-4) /* component outside the supported closed set */
+
+typedef struct thx_ctx thx_ctx;
+typedef struct thx_scene thx_scene;
+typedef struct thx_tracer thx_tracer;
+
+#pragma pack(push, 4)
+
+/* src/theia/trace.py:354-360 (Tracer.DispatchParams) */
+typedef struct {
+    uint32_t batchSize;
+    uint32_t groupCountX, groupCountY, groupCountZ; /* kept for layout parity; unused */
+} thx_dispatch_params;
+
+/* src/theia/random.py:253-254; shader/random.philox.glsl:8-11 */
+typedef struct {
+    uint32_t key[2];
+    uint32_t offset[4];
+} thx_philox_params;
+
+/* src/theia/light.py:1132-1139; shader/lightsource.spherical.glsl:7-14 */
+typedef struct {
+    float position[3];
+    float contribFwd;
+    float contribBwd;
+    float t_min, t_max;
+} thx_light_params;
+
+/* src/theia/light.py:272-273 (const) / :308-312 (uniform) */
+typedef struct {
+    float p0; /* const: lambda | uniform: lam_min */
+    float p1; /*               | uniform: lam_max */
+    float p2; /*               | uniform: contrib */
+} thx_wavelength_params;
+
+/* src/theia/target.py:105-112; shader/target.sphere.glsl:8-16 */
+typedef struct {
+    float position[3];
+    float radius;
+    float invPos[3];
+    float invRad;
+    float hemisphereProb;
+} thx_target_params;
+
+/* src/theia/target.py:496-501; shader/target_guide.sphere.glsl:7-10 */
+typedef struct {
+    float position[3];
+    float radius;
+    float prob;
+} thx_guide_params;
+
+/* shader/ray.propagate.glsl:18-26 */
+typedef struct {
+    float scatterCoefficient;
+    float lowerBBoxCorner[3];
+    float upperBBoxCorner[3];
+    float maxTime;
+    float maxDist;
+} thx_propagate_params;
+
+/* src/theia/trace.py:589-598; shader/tracer.volume.forward.glsl:18-23 */
+typedef struct {
+    uint32_t medium[2]; /* device address (lo, hi) */
+    int32_t objectId;
+    thx_propagate_params propagation;
+} thx_volume_trace_params;
+
+/* src/theia/trace.py:1136-1145; shader/tracer.scene.forward.glsl:36-41 */
+typedef struct {
+    int32_t targetId;
+    uint32_t sceneMedium[2];
+    thx_propagate_params propagation;
+} thx_scene_trace_params;
+
+/* src/theia/response.py:1256-1257; shader/response.histogram.glsl:11-14 */
+typedef struct {
+    float t0;
+    float binSize;
+} thx_response_params;
+
+/* everything one batch needs (one `stage.update(i)` round of the reference's
+ * pipeline, docs/pipeline/pipeline.md:32-38) */
+typedef struct {
+    thx_dispatch_params dispatch;
+    uint32_t photon_offset; /* index/RNG stream of the first photon (multi-GPU sharding) */
+    thx_philox_params philox;
+    thx_light_params light;
+    thx_wavelength_params wavelength;
+    thx_response_params response;
+    thx_volume_trace_params volume; /* kind == THX_TRACER_VOLUME_FORWARD */
+    thx_target_params target;
+    thx_scene_trace_params scene;   /* kind == THX_TRACER_SCENE_FORWARD */
+    thx_guide_params guide;
+} thx_run_params;
+
+#pragma pack(pop)
+
+enum { THX_TRACER_VOLUME_FORWARD = 0, THX_TRACER_SCENE_FORWARD = 1 };
+
+/* compile-time macros of the reference's shaders (trace.py:660-666, 1226-1235) */
+enum {
+    THX_FLAG_POLARIZED             = 1u << 0,
+    THX_FLAG_DISABLE_DIRECT        = 1u << 1,
+    THX_FLAG_DISABLE_MIS           = 1u << 2,
+    THX_FLAG_DISABLE_TRANSMISSION  = 1u << 3,
+    THX_FLAG_DISABLE_VOLUME_BORDER = 1u << 4,
+    THX_FLAG_HIT_USE_TRANSMITTED   = 1u << 5,
+    THX_FLAG_WAVELENGTH_UNIFORM    = 1u << 6, /* UniformWavelengthSource, else Const */
+    THX_FLAG_STATISTICS            = 1u << 8, /* EventStatisticCallback + traversal counters */
+    THX_FLAG_TRACK                 = 1u << 9  /* per-event state dump (parity probe) */
+};
+
+/* number of u64 counters returned by thx_tracer_read_stats: 12 event counters
+ * in the order of shader/callback.stat.glsl:7-20, then queries, nodes,
+ * triangles, instances, hits, lut_reads, responses, steps */
+#define THX_N_STATS 20
+/* words per event in the track buffer: code, pos.xyz, dir.xyz, time, lin, log, wavelength, dim */
+#define THX_TRACK_WORDS 12
+
+typedef struct {
+    uint32_t kind;        /* THX_TRACER_* */
+    uint32_t flags;       /* THX_FLAG_* */
+    uint32_t path_length; /* PATH_LENGTH macro */
+    uint32_t block_size;  /* reference BLOCK_SIZE; accepted for API parity */
+    uint32_t n_bins;      /* N_BINS macro */
+    uint32_t capacity;    /* max batch size */
+    uint32_t reserved[6];
+} thx_tracer_desc;
+
+/* vertices [n][6] f32 = position + normal (shader/scene.types.glsl:6-9),
+ * indices [m][3] u32 (:12-14) -- what hp.Mesh holds (scene.py:425-431) */
+typedef struct {
+    const float* vertices;
+    uint32_t n_vertices;
+    const uint32_t* indices;
+    uint32_t n_triangles;
+} thx_mesh_desc;
+
+/* hp.GeometryInstance + Scene.GLSLGeometry (scene.py:589-596, 628-645):
+ * object->world 3x4 row-major, customIndex = detectorId, material device address */
+typedef struct {
+    uint32_t mesh;
+    float transform[12];
+    int32_t customIndex;
+    uint64_t material;
+} thx_instance_desc;
+
+typedef struct {
+    uint32_t n_nodes, n_triangles, n_instances, max_depth;
+    uint64_t bytes_nodes, bytes_triangles, bytes_instances, bytes_total;
+} thx_scene_info;
+
+/* ---- context / device (replaces hp.getCurrentDevice, hp.selectDevice) ---- */
+const char* thx_last_error(void);
+int thx_device_count(int* out);
+int thx_ctx_create(int device, thx_ctx** out);
+int thx_ctx_destroy(thx_ctx* ctx);
+int thx_ctx_device_name(thx_ctx* ctx, char* buf, size_t n);
+int thx_ctx_device_info(thx_ctx* ctx, uint32_t* n_cus, uint32_t* lds_per_cu, uint64_t* hbm_bytes);
+int thx_ctx_sync(thx_ctx* ctx);
+
+/* ---- raw device memory (replaces hp.Tensor/hp.Buffer + hp.updateTensor for the
+ * MaterialStore blob; addresses stay plain integers, material.py:1005-1018) ---- */
+int thx_mem_alloc(thx_ctx* ctx, size_t nbytes, uint64_t* dev_addr);
+int thx_mem_free(thx_ctx* ctx, uint64_t dev_addr);
+int thx_mem_upload(thx_ctx* ctx, uint64_t dev_addr, const void* src, size_t nbytes);
+int thx_mem_download(thx_ctx* ctx, void* dst, uint64_t dev_addr, size_t nbytes);
+
+/* ---- scene (replaces hp.GeometryStore + hp.AccelerationStructure + the
+ * Geometries tensor, scene.py:550, 637-668): builds BLAS/TLAS (own BVH2) ---- */
+int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshes,
+                     const thx_instance_desc* instances, uint32_t n_instances, thx_scene** out);
+int thx_scene_destroy(thx_scene* scene);
+int thx_scene_get_info(const thx_scene* scene, thx_scene_info* out);
+/* closest-hit probe: n rays (origin[3], dir[3], tmax) -> out[n][5] =
+ * {hit, instance, primitive, t, bary.x, bary.y}[..] as floats (6 per ray) */
+int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out6);
+
+/* ---- tracer (replaces hp.Program(compileShader("tracer.*.forward.glsl")) +
+ * Tracer.run/_dispatch, trace.py:478-481, 758-766, 1326-1336) ---- */
+int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scene_or_null,
+                      thx_tracer** out);
+int thx_tracer_destroy(thx_tracer* tracer);
+/* launches one batch for pipeline config `cfg` (0/1) on `stream`
+ * (hipStream_t; NULL = the context's stream) */
+int thx_tracer_run(thx_tracer* tracer, uint32_t cfg, const thx_run_params* params, void* stream);
+/* HistogramReducer.run (response.py:1188-1197; shader/estimator.reduce.glsl):
+ * out[b] = norm * KahanSum_h slab[h][b]; d_out == 0 -> internal buffer of cfg */
+int thx_tracer_reduce(thx_tracer* tracer, uint32_t cfg, float norm, uint64_t d_out, void* stream);
+/* hp.retrieveTensor + response.result(i) (response.py:1184-1186, 1357-1365) */
+int thx_tracer_read_hist(thx_tracer* tracer, uint32_t cfg, float* out, uint32_t n_bins);
+int thx_tracer_hist_device_ptr(thx_tracer* tracer, uint32_t cfg, uint64_t* out);
+/* EventStatisticCallback (trace.py:77-187) */
+int thx_tracer_read_stats(thx_tracer* tracer, uint64_t* out, uint32_t n);
+int thx_tracer_reset_stats(thx_tracer* tracer);
+/* parity probe: per-event dump of the last run, [batch][path_length+3][THX_TRACK_WORDS] */
+int thx_tracer_read_track(thx_tracer* tracer, float* out, size_t n_floats);
+/* launch geometry chosen by the library: workgroups, threads per workgroup,
+ * dynamic LDS bytes, registers are reported by rocprof */
+int thx_tracer_launch_info(thx_tracer* tracer, uint32_t batch, uint32_t* grid, uint32_t* block,
+                           uint32_t* lds_bytes);
+/* timing of the most recent thx_tracer_run on cfg, measured with HIP events on
+ * the launch stream (ms); synchronises */
+int thx_tracer_last_kernel_ms(thx_tracer* tracer, uint32_t cfg, float* ms);
+
+/* ---- RNG probe (replaces RNGBufferSink, random.py:44-226): out[stream][sample]
+ * = raw uint32 behind random(base_stream+stream, first_dim+sample) ---- */
+int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream,
+                 uint32_t n_streams, uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
+                 float* out_f32);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

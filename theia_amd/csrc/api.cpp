@@ -1,0 +1,489 @@
+// C ABI of libtheia_hip.so (include/theia_hip.h): contexts, device memory,
+// scene upload, tracer launch/reduce/readback. No torch types, no CPU fallback:
+// every entry point fails with THX_ERR_NO_DEVICE / THX_ERR_HIP when there is no
+// usable GPU.
+#include <hip/hip_runtime.h>
+
+#include <algorithm>
+#include <cmath>
+#include <cstdio>
+#include <cstdlib>
+#include <cstring>
+#include <mutex>
+#include <new>
+#include <stdexcept>
+#include <string>
+#include <vector>
+
+#include "bvh_build.h"
+#include "kernels.h"
+
+using namespace thx;
+
+namespace {
+thread_local std::string g_error;
+
+int fail(int code, const std::string& msg) {
+    g_error = msg;
+    return code;
+}
+int hipFail(hipError_t e, const char* what) {
+    return fail(THX_ERR_HIP, std::string(what) + ": " + hipGetErrorString(e));
+}
+#define THX_HIP(call)                                        \
+    do {                                                     \
+        hipError_t e_ = (call);                              \
+        if (e_ != hipSuccess) return hipFail(e_, #call);     \
+    } while (0)
+} // namespace
+
+struct thx_ctx {
+    int device = 0;
+    hipStream_t stream = nullptr;
+    hipDeviceProp_t prop{};
+    std::mutex lock;
+};
+
+struct thx_scene {
+    thx_ctx* ctx = nullptr;
+    SceneView view{};
+    thx_scene_info info{};
+    std::vector<void*> allocs;
+};
+
+struct thx_tracer {
+    thx_ctx* ctx = nullptr;
+    thx_scene* scene = nullptr;
+    thx_tracer_desc desc{};
+    TraceVariant variant{};
+    bool debug = false;
+    uint32_t block = kTraceBlock;
+    size_t lds = 0;
+    uint32_t gridMax = 1;
+    float* slabs[2] = {nullptr, nullptr};
+    float* out[2] = {nullptr, nullptr};
+    uint32_t lastGrid[2] = {0, 0};
+    unsigned long long* stats = nullptr;
+    float* track = nullptr;
+    uint32_t trackEvents = 0;
+    uint32_t lastBatch = 0;
+    hipEvent_t evStart[2] = {nullptr, nullptr}, evStop[2] = {nullptr, nullptr};
+    bool timed[2] = {false, false};
+};
+
+extern "C" {
+
+const char* thx_last_error(void) { return g_error.c_str(); }
+
+int thx_device_count(int* out) {
+    if (!out) return fail(THX_ERR_INVALID, "null argument");
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess) {
+        *out = 0;
+        return fail(THX_ERR_NO_DEVICE, std::string("hipGetDeviceCount: ") + hipGetErrorString(e));
+    }
+    *out = n;
+    return THX_OK;
+}
+
+int thx_ctx_create(int device, thx_ctx** out) {
+    if (!out) return fail(THX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    int n = 0;
+    hipError_t e = hipGetDeviceCount(&n);
+    if (e != hipSuccess || n == 0)
+        return fail(THX_ERR_NO_DEVICE, "no HIP device available (libtheia_hip has no CPU fallback)");
+    if (device < 0 || device >= n) return fail(THX_ERR_INVALID, "device index out of range");
+    THX_HIP(hipSetDevice(device));
+    thx_ctx* c = new (std::nothrow) thx_ctx();
+    if (!c) return fail(THX_ERR_INVALID, "out of host memory");
+    c->device = device;
+    e = hipGetDeviceProperties(&c->prop, device);
+    if (e != hipSuccess) { delete c; return hipFail(e, "hipGetDeviceProperties"); }
+    e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
+    if (e != hipSuccess) { delete c; return hipFail(e, "hipStreamCreate"); }
+    *out = c;
+    return THX_OK;
+}
+
+int thx_ctx_destroy(thx_ctx* ctx) {
+    if (!ctx) return THX_OK;
+    hipSetDevice(ctx->device);
+    hipStreamSynchronize(ctx->stream);
+    hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return THX_OK;
+}
+
+int thx_ctx_device_name(thx_ctx* ctx, char* buf, size_t n) {
+    if (!ctx || !buf || n == 0) return fail(THX_ERR_INVALID, "null argument");
+    std::snprintf(buf, n, "%s (%s)", ctx->prop.name, ctx->prop.gcnArchName);
+    return THX_OK;
+}
+
+int thx_ctx_device_info(thx_ctx* ctx, uint32_t* n_cus, uint32_t* lds_per_cu, uint64_t* hbm_bytes) {
+    if (!ctx) return fail(THX_ERR_INVALID, "null argument");
+    if (n_cus) *n_cus = (uint32_t)ctx->prop.multiProcessorCount;
+    if (lds_per_cu) *lds_per_cu = (uint32_t)ctx->prop.maxSharedMemoryPerMultiProcessor;
+    if (hbm_bytes) *hbm_bytes = (uint64_t)ctx->prop.totalGlobalMem;
+    return THX_OK;
+}
+
+int thx_ctx_sync(thx_ctx* ctx) {
+    if (!ctx) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(ctx->device));
+    THX_HIP(hipStreamSynchronize(ctx->stream));
+    return THX_OK;
+}
+
+int thx_mem_alloc(thx_ctx* ctx, size_t nbytes, uint64_t* dev_addr) {
+    if (!ctx || !dev_addr) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(ctx->device));
+    void* p = nullptr;
+    THX_HIP(hipMalloc(&p, nbytes ? nbytes : 16));
+    *dev_addr = (uint64_t)(uintptr_t)p;
+    return THX_OK;
+}
+
+int thx_mem_free(thx_ctx* ctx, uint64_t dev_addr) {
+    if (!ctx) return fail(THX_ERR_INVALID, "null argument");
+    if (dev_addr == 0) return THX_OK;
+    THX_HIP(hipSetDevice(ctx->device));
+    THX_HIP(hipFree((void*)(uintptr_t)dev_addr));
+    return THX_OK;
+}
+
+int thx_mem_upload(thx_ctx* ctx, uint64_t dev_addr, const void* src, size_t nbytes) {
+    if (!ctx || (!src && nbytes) || (dev_addr == 0 && nbytes)) return fail(THX_ERR_INVALID, "null argument");
+    if (nbytes == 0) return THX_OK;
+    THX_HIP(hipSetDevice(ctx->device));
+    THX_HIP(hipMemcpy((void*)(uintptr_t)dev_addr, src, nbytes, hipMemcpyHostToDevice));
+    return THX_OK;
+}
+
+int thx_mem_download(thx_ctx* ctx, void* dst, uint64_t dev_addr, size_t nbytes) {
+    if (!ctx || (!dst && nbytes) || (dev_addr == 0 && nbytes)) return fail(THX_ERR_INVALID, "null argument");
+    if (nbytes == 0) return THX_OK;
+    THX_HIP(hipSetDevice(ctx->device));
+    THX_HIP(hipStreamSynchronize(ctx->stream));
+    THX_HIP(hipMemcpy(dst, (const void*)(uintptr_t)dev_addr, nbytes, hipMemcpyDeviceToHost));
+    return THX_OK;
+}
+
+// ------------------------------------------------------------------- scene
+
+static int uploadVec(thx_scene* s, const void* src, size_t nbytes, void** out) {
+    void* p = nullptr;
+    THX_HIP(hipMalloc(&p, nbytes ? nbytes : 16));
+    s->allocs.push_back(p);
+    if (nbytes) THX_HIP(hipMemcpy(p, src, nbytes, hipMemcpyHostToDevice));
+    *out = p;
+    return THX_OK;
+}
+
+int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshes,
+                     const thx_instance_desc* instances, uint32_t n_instances, thx_scene** out) {
+    if (!ctx || !meshes || !instances || !out) return fail(THX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    THX_HIP(hipSetDevice(ctx->device));
+    BuiltScene built;
+    try {
+        built = buildScene(meshes, n_meshes, instances, n_instances, kStackDepth);
+    } catch (const std::exception& e) {
+        return fail(THX_ERR_INVALID, e.what());
+    }
+    thx_scene* s = new (std::nothrow) thx_scene();
+    if (!s) return fail(THX_ERR_INVALID, "out of host memory");
+    s->ctx = ctx;
+    int rc;
+    void* p;
+#define UP(vec, field, T)                                                          \
+    rc = uploadVec(s, (vec).data(), (vec).size() * sizeof((vec)[0]), &p);          \
+    if (rc != THX_OK) { thx_scene_destroy(s); return rc; }                         \
+    s->view.field = reinterpret_cast<const T*>(p);
+    UP(built.nodes, nodes, BvhNode)
+    UP(built.tris, tris, TriRecord)
+    UP(built.instances, instances, InstanceRecord)
+    UP(built.tlasInstance, tlasInstance, uint32_t)
+#undef UP
+    // reference-layout vertex / index buffers (scene.types.glsl:6-14), one pair per mesh
+    std::vector<uint64_t> vaddr(n_meshes), iaddr(n_meshes);
+    for (uint32_t m = 0; m < n_meshes; ++m) {
+        rc = uploadVec(s, meshes[m].vertices, sizeof(float) * 6 * (size_t)meshes[m].n_vertices, &p);
+        if (rc != THX_OK) { thx_scene_destroy(s); return rc; }
+        vaddr[m] = (uint64_t)(uintptr_t)p;
+        rc = uploadVec(s, meshes[m].indices, sizeof(uint32_t) * 3 * (size_t)meshes[m].n_triangles, &p);
+        if (rc != THX_OK) { thx_scene_destroy(s); return rc; }
+        iaddr[m] = (uint64_t)(uintptr_t)p;
+    }
+    // Geometry[] (scene.py:628-645)
+    std::vector<GeometryGLSL> geo(n_instances);
+    for (uint32_t k = 0; k < n_instances; ++k) {
+        geo[k].vertices = vaddr[instances[k].mesh];
+        geo[k].indices = iaddr[instances[k].mesh];
+        geo[k].material = instances[k].material;
+    }
+    rc = uploadVec(s, geo.data(), geo.size() * sizeof(GeometryGLSL), &p);
+    if (rc != THX_OK) { thx_scene_destroy(s); return rc; }
+    s->view.geometries = reinterpret_cast<const GeometryGLSL*>(p);
+    s->view.tlasRoot = built.tlasRoot;
+    s->view.nInstances = n_instances;
+
+    s->info.n_nodes = (uint32_t)built.nodes.size();
+    s->info.n_triangles = (uint32_t)built.tris.size();
+    s->info.n_instances = n_instances;
+    s->info.max_depth = built.maxDepth;
+    s->info.bytes_nodes = built.nodes.size() * sizeof(BvhNode);
+    s->info.bytes_triangles = built.tris.size() * sizeof(TriRecord);
+    s->info.bytes_instances = built.instances.size() * sizeof(InstanceRecord);
+    uint64_t total = s->info.bytes_nodes + s->info.bytes_triangles + s->info.bytes_instances +
+                     built.tlasInstance.size() * 4 + geo.size() * sizeof(GeometryGLSL);
+    for (uint32_t m = 0; m < n_meshes; ++m)
+        total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
+    s->info.bytes_total = total;
+    *out = s;
+    return THX_OK;
+}
+
+int thx_scene_destroy(thx_scene* scene) {
+    if (!scene) return THX_OK;
+    hipSetDevice(scene->ctx->device);
+    hipStreamSynchronize(scene->ctx->stream);
+    for (void* p : scene->allocs) hipFree(p);
+    delete scene;
+    return THX_OK;
+}
+
+int thx_scene_get_info(const thx_scene* scene, thx_scene_info* out) {
+    if (!scene || !out) return fail(THX_ERR_INVALID, "null argument");
+    *out = scene->info;
+    return THX_OK;
+}
+
+int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out6) {
+    if (!scene || !rays7 || !out6) return fail(THX_ERR_INVALID, "null argument");
+    if (n == 0) return THX_OK;
+    thx_ctx* ctx = scene->ctx;
+    THX_HIP(hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    THX_HIP(hipMalloc((void**)&d_in, sizeof(float) * 7 * (size_t)n));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * 6 * (size_t)n);
+    if (e != hipSuccess) { hipFree(d_in); return hipFail(e, "hipMalloc"); }
+    e = hipMemcpy(d_in, rays7, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice);
+    if (e == hipSuccess) e = launchQuery(scene->view, d_in, n, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out6, d_out, sizeof(float) * 6 * (size_t)n, hipMemcpyDeviceToHost);
+    hipFree(d_in);
+    hipFree(d_out);
+    if (e != hipSuccess) return hipFail(e, "thx_scene_query");
+    return THX_OK;
+}
+
+// ------------------------------------------------------------------ tracer
+
+int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scene, thx_tracer** out) {
+    if (!ctx || !desc || !out) return fail(THX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (desc->kind != THX_TRACER_VOLUME_FORWARD && desc->kind != THX_TRACER_SCENE_FORWARD)
+        return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
+    if (desc->kind == THX_TRACER_SCENE_FORWARD && !scene)
+        return fail(THX_ERR_INVALID, "scene tracer needs a scene");
+    if (desc->n_bins == 0 || desc->n_bins > 8192)
+        return fail(THX_ERR_INVALID, "n_bins must be in [1, 8192] (LDS histogram, response.py:1098)");
+    if (desc->capacity == 0) return fail(THX_ERR_INVALID, "capacity must be positive");
+    THX_HIP(hipSetDevice(ctx->device));
+    thx_tracer* t = new (std::nothrow) thx_tracer();
+    if (!t) return fail(THX_ERR_INVALID, "out of host memory");
+    t->ctx = ctx;
+    t->scene = scene;
+    t->desc = *desc;
+    const bool pol = (desc->flags & THX_FLAG_POLARIZED) != 0;
+    const bool mis = (desc->flags & THX_FLAG_DISABLE_MIS) == 0;
+    t->variant = traceVariant(desc->kind, pol, mis);
+    t->debug = (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK)) != 0;
+    t->block = kTraceBlock;
+    t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block);
+    int perCU = t->variant.occupancy(t->debug, t->block, t->lds);
+    if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
+    uint32_t mult = 1;
+    if (const char* env = std::getenv("THX_GRID_MULT")) mult = (uint32_t)std::max(1, std::atoi(env));
+    t->gridMax = (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)perCU * mult;
+    const size_t slabBytes = sizeof(float) * (size_t)t->gridMax * desc->n_bins;
+    hipError_t e = hipSuccess;
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        e = hipMalloc((void**)&t->slabs[i], slabBytes);
+        if (e == hipSuccess) e = hipMemset(t->slabs[i], 0, slabBytes);
+        if (e == hipSuccess) e = hipMalloc((void**)&t->out[i], sizeof(float) * desc->n_bins);
+        if (e == hipSuccess) e = hipMemset(t->out[i], 0, sizeof(float) * desc->n_bins);
+        if (e == hipSuccess) e = hipEventCreate(&t->evStart[i]);
+        if (e == hipSuccess) e = hipEventCreate(&t->evStop[i]);
+    }
+    if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
+    if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
+    if (e == hipSuccess && (desc->flags & THX_FLAG_TRACK)) {
+        t->trackEvents = desc->path_length + 3;
+        size_t nb = sizeof(float) * THX_TRACK_WORDS * (size_t)t->trackEvents * desc->capacity;
+        e = hipMalloc((void**)&t->track, nb);
+        if (e == hipSuccess) e = hipMemset(t->track, 0, nb);
+    }
+    if (e != hipSuccess) { thx_tracer_destroy(t); return hipFail(e, "thx_tracer_create"); }
+    *out = t;
+    return THX_OK;
+}
+
+int thx_tracer_destroy(thx_tracer* t) {
+    if (!t) return THX_OK;
+    hipSetDevice(t->ctx->device);
+    hipStreamSynchronize(t->ctx->stream);
+    for (int i = 0; i < 2; ++i) {
+        if (t->slabs[i]) hipFree(t->slabs[i]);
+        if (t->out[i]) hipFree(t->out[i]);
+        if (t->evStart[i]) hipEventDestroy(t->evStart[i]);
+        if (t->evStop[i]) hipEventDestroy(t->evStop[i]);
+    }
+    if (t->stats) hipFree(t->stats);
+    if (t->track) hipFree(t->track);
+    delete t;
+    return THX_OK;
+}
+
+static void launchGeometry(const thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* ppw) {
+    const uint32_t wavesPerBlock = t->block / 64;
+    uint64_t wavesNeeded = ((uint64_t)batch + 63) / 64;
+    uint64_t blocksNeeded = (wavesNeeded + wavesPerBlock - 1) / wavesPerBlock;
+    uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, blocksNeeded));
+    uint64_t waves = (uint64_t)g * wavesPerBlock;
+    uint32_t p = (uint32_t)(((uint64_t)batch + waves - 1) / waves);
+    *grid = g;
+    *ppw = std::max<uint32_t>(p, 1);
+}
+
+int thx_tracer_launch_info(thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes) {
+    if (!t) return fail(THX_ERR_INVALID, "null argument");
+    uint32_t g, p;
+    launchGeometry(t, batch, &g, &p);
+    if (grid) *grid = g;
+    if (block) *block = t->block;
+    if (lds_bytes) *lds_bytes = (uint32_t)t->lds;
+    return THX_OK;
+}
+
+int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, void* stream) {
+    if (!t || !params) return fail(THX_ERR_INVALID, "null argument");
+    if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
+    const uint32_t batch = params->dispatch.batchSize;
+    if (batch > t->desc.capacity) return fail(THX_ERR_INVALID, "batchSize cannot be larger than capacity");
+    thx_ctx* ctx = t->ctx;
+    THX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+
+    LaunchArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.p = *params;
+    a.flags = t->desc.flags;
+    a.path_length = t->desc.path_length;
+    a.n_bins = t->desc.n_bins;
+    a.track_events = t->trackEvents;
+    a.stack_depth = kStackDepth;
+    a.slabs = t->slabs[cfg];
+    a.stats = t->stats;
+    a.track = t->track;
+    if (t->scene) a.scene = t->scene->view;
+    uint32_t grid, ppw;
+    launchGeometry(t, batch, &grid, &ppw);
+    a.photons_per_wave = ppw;
+    t->lastGrid[cfg] = grid;
+    t->lastBatch = batch;
+    THX_HIP(hipEventRecord(t->evStart[cfg], s));
+    THX_HIP(t->variant.launch(t->debug, a, grid, t->block, t->lds, s));
+    THX_HIP(hipEventRecord(t->evStop[cfg], s));
+    t->timed[cfg] = true;
+    return THX_OK;
+}
+
+int thx_tracer_reduce(thx_tracer* t, uint32_t cfg, float norm, uint64_t d_out, void* stream) {
+    if (!t) return fail(THX_ERR_INVALID, "null argument");
+    if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
+    thx_ctx* ctx = t->ctx;
+    THX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    float* out = d_out ? (float*)(uintptr_t)d_out : t->out[cfg];
+    THX_HIP(launchReduce(t->slabs[cfg], out, t->desc.n_bins, t->lastGrid[cfg], norm, s));
+    return THX_OK;
+}
+
+int thx_tracer_read_hist(thx_tracer* t, uint32_t cfg, float* out, uint32_t n_bins) {
+    if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    if (cfg > 1 || n_bins != t->desc.n_bins) return fail(THX_ERR_INVALID, "bad config index or bin count");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    THX_HIP(hipMemcpy(out, t->out[cfg], sizeof(float) * n_bins, hipMemcpyDeviceToHost));
+    return THX_OK;
+}
+
+int thx_tracer_hist_device_ptr(thx_tracer* t, uint32_t cfg, uint64_t* out) {
+    if (!t || !out || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    *out = (uint64_t)(uintptr_t)t->out[cfg];
+    return THX_OK;
+}
+
+int thx_tracer_read_stats(thx_tracer* t, uint64_t* out, uint32_t n) {
+    if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    if (n > THX_N_STATS) n = THX_N_STATS;
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    THX_HIP(hipMemcpy(out, t->stats, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+    return THX_OK;
+}
+
+int thx_tracer_reset_stats(thx_tracer* t) {
+    if (!t) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    THX_HIP(hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS));
+    return THX_OK;
+}
+
+int thx_tracer_read_track(thx_tracer* t, float* out, size_t n_floats) {
+    if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    if (!t->track) return fail(THX_ERR_INVALID, "tracer was created without THX_FLAG_TRACK");
+    size_t have = (size_t)THX_TRACK_WORDS * t->trackEvents * t->desc.capacity;
+    if (n_floats > have) return fail(THX_ERR_INVALID, "track buffer is smaller than requested");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    THX_HIP(hipMemcpy(out, t->track, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
+    return THX_OK;
+}
+
+int thx_tracer_last_kernel_ms(thx_tracer* t, uint32_t cfg, float* ms) {
+    if (!t || !ms || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    if (!t->timed[cfg]) return fail(THX_ERR_INVALID, "no launch recorded for this config");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipEventSynchronize(t->evStop[cfg]));
+    THX_HIP(hipEventElapsedTime(ms, t->evStart[cfg], t->evStop[cfg]));
+    return THX_OK;
+}
+
+int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream, uint32_t n_streams,
+                 uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32, float* out_f32) {
+    if (!ctx || !p) return fail(THX_ERR_INVALID, "null argument");
+    size_t total = (size_t)n_streams * n_samples;
+    if (total == 0) return THX_OK;
+    THX_HIP(hipSetDevice(ctx->device));
+    uint32_t* d_u = nullptr;
+    float* d_f = nullptr;
+    hipError_t e = hipSuccess;
+    if (out_u32) e = hipMalloc((void**)&d_u, 4 * total);
+    if (e == hipSuccess && out_f32) e = hipMalloc((void**)&d_f, 4 * total);
+    if (e == hipSuccess) e = launchRngFill(*p, base_stream, n_streams, first_dim, n_samples, d_u, d_f, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && out_u32) e = hipMemcpy(out_u32, d_u, 4 * total, hipMemcpyDeviceToHost);
+    if (e == hipSuccess && out_f32) e = hipMemcpy(out_f32, d_f, 4 * total, hipMemcpyDeviceToHost);
+    if (d_u) hipFree(d_u);
+    if (d_f) hipFree(d_f);
+    if (e != hipSuccess) return hipFail(e, "thx_rng_fill");
+    return THX_OK;
+}
+
+} // extern "C"

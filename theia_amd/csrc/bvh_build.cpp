@@ -1,0 +1,286 @@
+// Binned-SAH BVH2 builder (host). Leaves hold <= 4 triangles (BLAS) or exactly
+// one instance (TLAS). Children of an inner node are adjacent so the walk
+// fetches both with one 64-B access. Node boxes are padded by a few ulps so the
+// conservative slab test can never reject a point the watertight triangle test
+// accepts.
+#include "bvh_build.h"
+
+#include <algorithm>
+#include <cmath>
+#include <cstring>
+#include <limits>
+#include <stdexcept>
+
+namespace thx {
+
+namespace {
+
+struct Box {
+    float lo[3], hi[3];
+    void reset() {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::numeric_limits<float>::infinity();
+            hi[k] = -std::numeric_limits<float>::infinity();
+        }
+    }
+    void grow(const float p[3]) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], p[k]);
+            hi[k] = std::max(hi[k], p[k]);
+        }
+    }
+    void grow(const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            lo[k] = std::min(lo[k], b.lo[k]);
+            hi[k] = std::max(hi[k], b.hi[k]);
+        }
+    }
+    float area() const {
+        float dx = hi[0] - lo[0], dy = hi[1] - lo[1], dz = hi[2] - lo[2];
+        if (dx < 0 || dy < 0 || dz < 0) return 0.0f;
+        return dx * dy + dy * dz + dz * dx;
+    }
+};
+
+struct Prim {
+    Box box;
+    float cen[3];
+    uint32_t id;
+};
+
+struct Builder {
+    std::vector<Prim>& prims;
+    std::vector<BvhNode>& nodes;
+    uint32_t leafMax;
+    bool median;
+    uint32_t maxDepth = 0;
+
+    static void store(BvhNode& n, const Box& b) {
+        for (int k = 0; k < 3; ++k) {
+            float pad = 2e-6f * std::max(std::fabs(b.lo[k]), std::fabs(b.hi[k])) + 1e-30f;
+            n.lo[k] = b.lo[k] - pad;
+            n.hi[k] = b.hi[k] + pad;
+        }
+    }
+
+    void build(uint32_t node, uint32_t first, uint32_t count, uint32_t depth) {
+        maxDepth = std::max(maxDepth, depth);
+        Box box, cbox;
+        box.reset();
+        cbox.reset();
+        for (uint32_t i = first; i < first + count; ++i) {
+            box.grow(prims[i].box);
+            cbox.grow(prims[i].cen);
+        }
+        store(nodes[node], box);
+        if (count <= leafMax) {
+            nodes[node].leftFirst = first;
+            nodes[node].count = count;
+            return;
+        }
+        int axis = 0;
+        float ext[3] = {cbox.hi[0] - cbox.lo[0], cbox.hi[1] - cbox.lo[1], cbox.hi[2] - cbox.lo[2]};
+        if (ext[1] > ext[axis]) axis = 1;
+        if (ext[2] > ext[axis]) axis = 2;
+        uint32_t mid = first + count / 2;
+        bool done = false;
+        if (!median && ext[axis] > 0.0f) {
+            // binned SAH over all three axes
+            constexpr int NB = 16;
+            float best = std::numeric_limits<float>::infinity();
+            int bestAxis = -1, bestBin = -1;
+            for (int ax = 0; ax < 3; ++ax) {
+                if (!(ext[ax] > 0.0f)) continue;
+                Box bb[NB];
+                uint32_t bc[NB];
+                for (int b = 0; b < NB; ++b) { bb[b].reset(); bc[b] = 0; }
+                float scale = NB / ext[ax];
+                for (uint32_t i = first; i < first + count; ++i) {
+                    int b = std::min(NB - 1, std::max(0, (int)((prims[i].cen[ax] - cbox.lo[ax]) * scale)));
+                    bb[b].grow(prims[i].box);
+                    bc[b]++;
+                }
+                float rightArea[NB];
+                uint32_t rightCount[NB];
+                Box acc;
+                acc.reset();
+                uint32_t cnt = 0;
+                for (int b = NB - 1; b > 0; --b) {
+                    acc.grow(bb[b]);
+                    cnt += bc[b];
+                    rightArea[b] = acc.area();
+                    rightCount[b] = cnt;
+                }
+                acc.reset();
+                cnt = 0;
+                for (int b = 0; b < NB - 1; ++b) {
+                    acc.grow(bb[b]);
+                    cnt += bc[b];
+                    if (cnt == 0 || rightCount[b + 1] == 0) continue;
+                    float cost = acc.area() * cnt + rightArea[b + 1] * rightCount[b + 1];
+                    if (cost < best) { best = cost; bestAxis = ax; bestBin = b; }
+                }
+            }
+            if (bestAxis >= 0) {
+                float scale = NB / ext[bestAxis];
+                auto it = std::partition(prims.begin() + first, prims.begin() + first + count, [&](const Prim& p) {
+                    int b = std::min(NB - 1, std::max(0, (int)((p.cen[bestAxis] - cbox.lo[bestAxis]) * scale)));
+                    return b <= bestBin;
+                });
+                mid = (uint32_t)(it - prims.begin());
+                done = mid > first && mid < first + count;
+            }
+        }
+        if (!done) {
+            mid = first + count / 2;
+            std::nth_element(prims.begin() + first, prims.begin() + mid, prims.begin() + first + count,
+                             [axis](const Prim& a, const Prim& b) { return a.cen[axis] < b.cen[axis]; });
+        }
+        uint32_t left = (uint32_t)nodes.size();
+        nodes.push_back(BvhNode{});
+        nodes.push_back(BvhNode{});
+        nodes[node].leftFirst = left;
+        nodes[node].count = 0;
+        build(left, first, mid - first, depth + 1);
+        build(left + 1, mid, first + count - mid, depth + 1);
+    }
+};
+
+// builds a subtree rooted at a fresh node appended to `nodes`; returns (root, depth)
+std::pair<uint32_t, uint32_t> buildTree(std::vector<Prim>& prims, std::vector<BvhNode>& nodes,
+                                        uint32_t leafMax, uint32_t depthLimit) {
+    for (int attempt = 0; attempt < 2; ++attempt) {
+        size_t mark = nodes.size();
+        std::vector<Prim> work = prims;
+        nodes.push_back(BvhNode{});
+        Builder b{work, nodes, leafMax, attempt == 1};
+        b.build((uint32_t)mark, 0, (uint32_t)work.size(), 0);
+        if (b.maxDepth <= depthLimit || attempt == 1) {
+            prims.swap(work);
+            return {(uint32_t)mark, b.maxDepth};
+        }
+        nodes.resize(mark); // too deep for the LDS stack: rebuild balanced (median splits)
+    }
+    return {0, 0};
+}
+
+} // namespace
+
+void invertAffine(const float m[12], float out[12]) {
+    double a = m[0], b = m[1], c = m[2], d = m[4], e = m[5], f = m[6], g = m[8], h = m[9], i = m[10];
+    double det = a * (e * i - f * h) - b * (d * i - f * g) + c * (d * h - e * g);
+    double id = 1.0 / det;
+    double r[9] = {(e * i - f * h) * id, (c * h - b * i) * id, (b * f - c * e) * id,
+                   (f * g - d * i) * id, (a * i - c * g) * id, (c * d - a * f) * id,
+                   (d * h - e * g) * id, (b * g - a * h) * id, (a * e - b * d) * id};
+    double tx = m[3], ty = m[7], tz = m[11];
+    for (int k = 0; k < 3; ++k) {
+        out[k * 4 + 0] = (float)r[k * 3 + 0];
+        out[k * 4 + 1] = (float)r[k * 3 + 1];
+        out[k * 4 + 2] = (float)r[k * 3 + 2];
+        out[k * 4 + 3] = (float)(-(r[k * 3 + 0] * tx + r[k * 3 + 1] * ty + r[k * 3 + 2] * tz));
+    }
+}
+
+BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
+                      const thx_instance_desc* instances, uint32_t n_instances,
+                      uint32_t max_stack_depth) {
+    if (n_meshes == 0 || n_instances == 0) throw std::runtime_error("scene cannot be empty");
+    BuiltScene out;
+    // reserve the TLAS at the front: at most 2*n-1 nodes
+    const uint32_t tlasMax = 2 * n_instances;
+    out.nodes.resize(tlasMax);
+
+    const uint32_t blasLimit = max_stack_depth > 14 ? (max_stack_depth - 2) / 2 + 2 : 8;
+    uint32_t deepestBlas = 0;
+    for (uint32_t m = 0; m < n_meshes; ++m) {
+        const thx_mesh_desc& md = meshes[m];
+        if (!md.vertices || !md.indices || md.n_triangles == 0 || md.n_vertices == 0)
+            throw std::runtime_error("mesh without vertices/triangles");
+        std::vector<Prim> prims(md.n_triangles);
+        for (uint32_t t = 0; t < md.n_triangles; ++t) {
+            Prim& p = prims[t];
+            p.id = t;
+            p.box.reset();
+            for (int v = 0; v < 3; ++v) {
+                uint32_t vi = md.indices[3 * (size_t)t + v];
+                if (vi >= md.n_vertices) throw std::runtime_error("triangle index out of range");
+                p.box.grow(md.vertices + 6 * (size_t)vi);
+            }
+            for (int k = 0; k < 3; ++k) p.cen[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
+        }
+        std::vector<BvhNode> local;
+        auto [root, depth] = buildTree(prims, local, 4, blasLimit);
+        (void)root;
+        deepestBlas = std::max(deepestBlas, depth);
+        // relocate into the global arrays
+        const uint32_t nodeBase = (uint32_t)out.nodes.size();
+        const uint32_t triBase = (uint32_t)out.tris.size();
+        for (BvhNode n : local) {
+            if (n.count == 0) n.leftFirst += nodeBase;
+            else n.leftFirst += triBase;
+            out.nodes.push_back(n);
+        }
+        out.blasRoot.push_back(nodeBase);
+        for (const Prim& p : prims) {
+            TriRecord tr;
+            std::memset(&tr, 0, sizeof(tr));
+            const uint32_t* ix = md.indices + 3 * (size_t)p.id;
+            std::memcpy(tr.v0, md.vertices + 6 * (size_t)ix[0], 12);
+            std::memcpy(tr.v1, md.vertices + 6 * (size_t)ix[1], 12);
+            std::memcpy(tr.v2, md.vertices + 6 * (size_t)ix[2], 12);
+            tr.prim = p.id;
+            out.tris.push_back(tr);
+        }
+    }
+
+    // instances + TLAS
+    std::vector<Prim> iprims(n_instances);
+    out.instances.resize(n_instances);
+    for (uint32_t k = 0; k < n_instances; ++k) {
+        const thx_instance_desc& id = instances[k];
+        if (id.mesh >= n_meshes) throw std::runtime_error("instance references unknown mesh");
+        InstanceRecord& rec = out.instances[k];
+        std::memset(&rec, 0, sizeof(rec));
+        std::memcpy(rec.o2w, id.transform, sizeof(float) * 12);
+        invertAffine(rec.o2w, rec.w2o);
+        for (int q = 0; q < 12; ++q)
+            if (!std::isfinite(rec.w2o[q])) throw std::runtime_error("singular instance transform");
+        rec.blasRoot = out.blasRoot[id.mesh];
+        rec.customIndex = id.customIndex;
+        rec.geometry = k;
+        Prim& p = iprims[k];
+        p.id = k;
+        p.box.reset();
+        const thx_mesh_desc& md = meshes[id.mesh];
+        for (uint32_t v = 0; v < md.n_vertices; ++v) {
+            const float* q = md.vertices + 6 * (size_t)v;
+            float w[3];
+            for (int a = 0; a < 3; ++a)
+                w[a] = rec.o2w[a * 4 + 3] + (rec.o2w[a * 4 + 0] * q[0] + rec.o2w[a * 4 + 1] * q[1] + rec.o2w[a * 4 + 2] * q[2]);
+            p.box.grow(w);
+        }
+        for (int a = 0; a < 3; ++a) { // transform rounding slack
+            float pad = 4e-6f * std::max(std::fabs(p.box.lo[a]), std::fabs(p.box.hi[a])) + 1e-30f;
+            p.box.lo[a] -= pad;
+            p.box.hi[a] += pad;
+            p.cen[a] = 0.5f * (p.box.lo[a] + p.box.hi[a]);
+        }
+    }
+    std::vector<BvhNode> tl;
+    uint32_t tlasLimit = max_stack_depth - deepestBlas - 2;
+    auto [troot, tdepth] = buildTree(iprims, tl, 1, tlasLimit);
+    (void)troot;
+    if (tl.size() > tlasMax) throw std::runtime_error("internal: TLAS larger than reserved");
+    for (size_t i = 0; i < tl.size(); ++i) out.nodes[i] = tl[i]; // child indices are already absolute (base 0)
+    // unused reserved slots stay zero-filled and unreachable
+    out.tlasRoot = 0;
+    out.tlasInstance.resize(n_instances);
+    for (uint32_t s = 0; s < n_instances; ++s) out.tlasInstance[s] = iprims[s].id;
+    out.maxDepth = tdepth + 1 + deepestBlas;
+    if (out.maxDepth + 1 > max_stack_depth)
+        throw std::runtime_error("scene hierarchy deeper than the traversal stack");
+    return out;
+}
+
+} // namespace thx

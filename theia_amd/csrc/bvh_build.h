@@ -1,0 +1,32 @@
+// Host-side acceleration-structure builder (replaces what the reference leaves
+// to the Vulkan driver: hp.GeometryStore / hp.AccelerationStructure,
+// src/theia/scene.py:550, 668). Produces one node array holding the TLAS and
+// every mesh's BLAS, the leaf-ordered triangle records and the instance records.
+#pragma once
+#include <cstdint>
+#include <vector>
+
+#include "../../include/theia_hip.h"
+#include "thx_layout.h"
+
+namespace thx {
+
+struct BuiltScene {
+    std::vector<BvhNode> nodes;         // [TLAS | BLAS 0 | BLAS 1 | ...]
+    std::vector<TriRecord> tris;        // leaf order, all meshes
+    std::vector<InstanceRecord> instances;
+    std::vector<uint32_t> tlasInstance; // TLAS leaf slot -> instance id
+    uint32_t tlasRoot = 0;
+    uint32_t maxDepth = 0;              // TLAS depth + 1 + deepest BLAS (stack bound)
+    std::vector<uint32_t> blasRoot;     // per mesh
+};
+
+// throws std::runtime_error on invalid input
+BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
+                      const thx_instance_desc* instances, uint32_t n_instances,
+                      uint32_t max_stack_depth);
+
+// world->object 3x4 from object->world 3x4 (double precision cofactors)
+void invertAffine(const float m[12], float out[12]);
+
+} // namespace thx

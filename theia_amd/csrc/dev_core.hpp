@@ -1,0 +1,356 @@
+// Device-side building blocks of the photon path: vector math, Philox4x32-10,
+// table look-ups, medium constants, phase-function sampling, Mueller/Stokes
+// updates. Written for gfx950 (wave64); every function cites the reference
+// shader it restates (paths relative to /root/reference/src/theia/shader).
+//
+// Arithmetic conventions (the GLSL spec leaves them open; fixed so that the
+// kernels and the CPU oracle round identically -- build with -ffp-contract=off):
+//   dot(a,b)      = (a.x*b.x + a.y*b.y) + a.z*b.z
+//   normalize(v)  = v * (1 / sqrt(dot(v,v)))
+//   mat3 * v      = (c0*v.x + c1*v.y) + c2*v.z
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/theia_hip.h"
+#include "thx_layout.h"
+
+namespace thx {
+
+#define THX_DEV __device__ __forceinline__
+
+struct f3 {
+    float x, y, z;
+};
+struct f4 {
+    float x, y, z, w;
+};
+struct m3 { // columns
+    f3 c0, c1, c2;
+};
+
+THX_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+THX_DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+THX_DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
+THX_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
+THX_DEV f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
+THX_DEV f3 operator*(f3 a, float s) { return f3{a.x * s, a.y * s, a.z * s}; }
+THX_DEV float dot(f3 a, f3 b) { return (a.x * b.x + a.y * b.y) + a.z * b.z; }
+THX_DEV float length(f3 a) { return sqrtf(dot(a, a)); }
+THX_DEV float distance(f3 a, f3 b) { return length(a - b); }
+THX_DEV f3 normalize(f3 a) { return a * (1.0f / sqrtf(dot(a, a))); }
+THX_DEV f3 cross(f3 a, f3 b) { // GLSL cross()
+    return f3{a.y * b.z - b.y * a.z, a.z * b.x - b.z * a.x, a.x * b.y - b.x * a.y};
+}
+THX_DEV f3 mul(const m3& m, f3 v) { return (m.c0 * v.x + m.c1 * v.y) + m.c2 * v.z; }
+THX_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
+THX_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
+THX_DEV float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
+
+// math.glsl:8-16, material.glsl:6
+constexpr float TWO_PI = 6.283185307179586477f;
+constexpr float INV_4PI = 0.0795774715459476679f;
+constexpr float SPEED_OF_LIGHT = 0.299792458f;
+
+// result.glsl:10-28
+enum : int {
+    RESULT_CODE_SUCCESS = 0,
+    RESULT_CODE_RAY_CREATED = 1,
+    RESULT_CODE_RAY_SCATTERED = 2,
+    RESULT_CODE_RAY_HIT = 3,
+    RESULT_CODE_RAY_DETECTED = 4,
+    RESULT_CODE_VOLUME_HIT = 5,
+    RESULT_CODE_RAY_LOST = -1,
+    RESULT_CODE_RAY_DECAYED = -2,
+    RESULT_CODE_RAY_ABSORBED = -3,
+    RESULT_CODE_RAY_MISSED = -4,
+    RESULT_CODE_MAX_ITER = -5,
+    ERROR_CODE_MAX_VALUE = -10,
+    ERROR_CODE_MEDIA_MISMATCH = -11,
+    ERROR_CODE_TRACE_ABORT = -12,
+    ERROR_CODE_RAY_BAD = -13
+};
+
+// material.glsl:79-86
+constexpr uint32_t MATERIAL_BLACK_BODY_BIT = 0x01u;
+constexpr uint32_t MATERIAL_DETECTOR_BIT = 0x02u;
+constexpr uint32_t MATERIAL_NO_REFLECT_BWD_BIT = 0x10u;
+constexpr uint32_t MATERIAL_NO_TRANSMIT_BWD_BIT = 0x40u;
+constexpr uint32_t MATERIAL_VOLUME_BORDER_BIT = 0x80u;
+
+// counter slots (theia_hip.h: THX_N_STATS)
+enum : int {
+    ST_CREATED, ST_SCATTERED, ST_HIT, ST_DETECTED, ST_VOLUME, ST_LOST, ST_DECAYED, ST_ABSORBED,
+    ST_MISSED, ST_MAXITER, ST_ERROR, ST_MISMATCH,
+    ST_QUERIES, ST_NODES, ST_TRIS, ST_INSTANCES, ST_HITS, ST_LUT, ST_RESPONSES, ST_STEPS
+};
+
+// Per-lane counters of the instrumented build; empty otherwise.
+template <bool ON>
+struct Counters {
+    uint32_t v[THX_N_STATS];
+    THX_DEV void clear() {
+#pragma unroll
+        for (int i = 0; i < THX_N_STATS; ++i) v[i] = 0;
+    }
+    THX_DEV void add(int slot, uint32_t n = 1) { v[slot] += n; }
+};
+template <>
+struct Counters<false> {
+    THX_DEV void clear() {}
+    THX_DEV void add(int, uint32_t = 1) {}
+};
+
+// ---------------------------------------------------------------- math.glsl
+
+// math.glsl:18-20
+THX_DEV float signBit(float f) {
+    return __uint_as_float((__float_as_uint(f) & 0x80000000u) | 0x3F800000u);
+}
+// math.glsl:24-29 (`precise`: explicit fma, no contraction elsewhere)
+THX_DEV float prodDiff(float a, float b, float c, float d) {
+    float cd = c * d;
+    float diff = __fmaf_rn(a, b, -cd);
+    float err = __fmaf_rn(-c, d, cd);
+    return diff + err;
+}
+// math.glsl:33-39
+THX_DEV f3 crosser(f3 v, f3 w) {
+    return f3{prodDiff(v.y, w.z, v.z, w.y), prodDiff(v.z, w.x, v.x, w.z),
+              prodDiff(v.x, w.y, v.y, w.x)};
+}
+// math.glsl:45-55
+THX_DEV m3 createLocalCOSY(f3 vz) {
+    float s = signBit(vz.z);
+    float a = -1.0f / (s + vz.z);
+    float b = vz.x * vz.y * a;
+    f3 vx = f3{1.0f + s * vz.x * vz.x * a, s * b, -s * vz.x};
+    f3 vy = f3{b, s + vz.y * vz.y * a, -vz.y};
+    return m3{normalize(vx), normalize(vy), vz};
+}
+// math.glsl:58-77
+THX_DEV f3 perpendicularTo(f3 v) {
+    float s = signBit(v.z);
+    float a = -1.0f / (s + v.z);
+    float b = v.x * v.y * a;
+    return f3{b, s + v.y * v.y * a, -v.y};
+}
+THX_DEV f3 perpendicularTo(f3 a, f3 b) {
+    f3 c = crosser(a, b);
+    float len = length(c);
+    if (len < 1e-5f) return perpendicularTo(a);
+    return f3{c.x / len, c.y / len, c.z / len};
+}
+
+// ------------------------------------------------- random.philox.glsl / util
+
+// random.philox.glsl:15-52. counter = baseCount + (i << 2) with carry chain
+// and roll-over, key = key + stream; ten rounds.
+THX_DEV void philox4x32(const thx_philox_params& p, uint32_t stream, uint32_t i, uint32_t out[4]) {
+    uint32_t carry = i << 2;
+    uint32_t sx = p.offset[0], sy = p.offset[1], sz = p.offset[2], sw = p.offset[3];
+    uint32_t t;
+    t = sx + carry; carry = t < sx ? 1u : 0u; sx = t;
+    t = sy + carry; carry = t < sy ? 1u : 0u; sy = t;
+    t = sz + carry; carry = t < sz ? 1u : 0u; sz = t;
+    t = sw + carry; carry = t < sw ? 1u : 0u; sw = t;
+    sx += carry;
+    uint32_t kx = p.key[0], ky = p.key[1];
+    t = kx + stream; carry = t < kx ? 1u : 0u; kx = t;
+    t = ky + carry; carry = t < ky ? 1u : 0u; ky = t;
+    kx += carry;
+    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        uint32_t hi0 = __umulhi(M0, sx), lo0 = M0 * sx;
+        uint32_t hi1 = __umulhi(M1, sz), lo1 = M1 * sz;
+        uint32_t nx = hi1 ^ sy ^ kx, nz = hi0 ^ sw ^ ky;
+        sx = nx; sy = lo1; sz = nz; sw = lo0;
+        kx += 0x9E3779B9u;
+        ky += 0xBB67AE85u;
+    }
+    out[0] = sx; out[1] = sy; out[2] = sz; out[3] = sw;
+}
+
+// random.philox.glsl:54-77: the cached block is never reused by the reference
+// (philoxBufferCount stays 0), so random_s(stream,i) == philox(stream,i)[i & 3].
+THX_DEV uint32_t random_u32(const thx_philox_params& p, uint32_t stream, uint32_t i) {
+    uint32_t s[4];
+    philox4x32(p, stream, i, s);
+    uint32_t l = i & 3u;
+    return l == 0 ? s[0] : (l == 1 ? s[1] : (l == 2 ? s[2] : s[3]));
+}
+// random.util.glsl:4-9 (uint->float conversion: round to nearest even)
+THX_DEV float normalizeUint(uint32_t i) {
+    return fminf(__uint_as_float(0x3F7FFFFFu), __uint2float_rn(i) * __uint_as_float(0x2F800000u));
+}
+// random.philox.glsl:84-94
+THX_DEV float rnd(const thx_philox_params& p, uint32_t stream, uint32_t& dim) {
+    float r = normalizeUint(random_u32(p, stream, dim));
+    dim += 1;
+    return r;
+}
+
+// ------------------------------------------------- lookup.glsl / material.glsl
+
+struct MediumConstants {
+    float n, vg, mu_s, mu_e;
+};
+
+// lookup.glsl:14-28
+template <bool ST>
+THX_DEV float lookUp(uint64_t table, float u, float nullValue, Counters<ST>& cnt) {
+    if (table == 0) return nullValue;
+    const int32_t* hdr = reinterpret_cast<const int32_t*>(table);
+    const float* samples = reinterpret_cast<const float*>(hdr + 1);
+    cnt.add(ST_LUT);
+    u = clampf(u, 0.0f, 1.0f);
+    u *= (float)(hdr[0] - 1);
+    float fl = floorf(u);
+    int lo = (int)fl;
+    int hi = (int)ceilf(u);
+    float l = u - fl;
+    return samples[lo] * (1.0f - l) + samples[hi] * l;
+}
+
+// material.glsl:37-39
+THX_DEV float normalize_lambda(const MediumGLSL* m, float lambda) {
+    return clampf((lambda - m->lambda_min) / (m->lambda_max - m->lambda_min), 0.0f, 1.0f);
+}
+
+// material.glsl:50-74
+template <bool ST>
+THX_DEV MediumConstants lookUpMedium(uint64_t medium, float lambda, Counters<ST>& cnt) {
+    if (medium == 0) return MediumConstants{1.0f, SPEED_OF_LIGHT, 0.0f, 0.0f};
+    const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+    float u = normalize_lambda(m, lambda);
+    float mu_a = lookUp(m->mu_a, u, 0.0f, cnt);
+    float mu_s = lookUp(m->mu_s, u, 0.0f, cnt);
+    MediumConstants c;
+    c.mu_e = mu_a + mu_s;
+    c.n = lookUp(m->n, u, 1.0f, cnt);
+    c.vg = lookUp(m->vg, u, SPEED_OF_LIGHT, cnt);
+    c.mu_s = mu_s;
+    return c;
+}
+
+// --------------------------------------------------------- polarization.glsl
+
+// frame-rotation Mueller matrix (polarization.glsl:29-33, column major) times a
+// Stokes vector
+THX_DEV f4 rotApply(float c, float s, f4 v) {
+    return f4{v.x, c * v.y + (-s) * v.z, s * v.y + c * v.z, v.w};
+}
+
+// polarization.glsl:38-68 -> (cos 2phi, sin 2phi, new reference)
+THX_DEV void rotatePolRef(f3 dir, f3 ref, f3 nw, f3& new_ref, float& c, float& s) {
+    f3 nr = crosser(dir, nw);
+    float len = length(nr);
+    if (len > 1.0e-7f) {
+        nr = f3{nr.x / len, nr.y / len, nr.z / len};
+    } else {
+        new_ref = ref;
+        c = 1.0f;
+        s = 0.0f;
+        return;
+    }
+    float cos_phi = dot(ref, nr);
+    float sin_phi = dot(crosser(ref, nr), dir);
+    c = 2.0f * cos_phi * cos_phi - 1.0f;
+    s = 2.0f * cos_phi * sin_phi;
+    new_ref = nr;
+}
+
+// polarization.glsl:21-34
+THX_DEV void alignPolRef(f3 rayDir, f3 oldRef, f3 newRef, float& c, float& s) {
+    float cos_phi = dot(oldRef, newRef);
+    float sin_phi = dot(crosser(oldRef, newRef), rayDir);
+    c = 2.0f * cos_phi * cos_phi - 1.0f;
+    s = 2.0f * cos_phi * sin_phi;
+}
+
+// polarization.glsl:109-120 times a Stokes vector
+THX_DEV f4 polarizerApply(float p, float s, f4 v) {
+    float att = p * p + s * s;
+    float m12 = (p * p - s * s) / att;
+    float m33 = (2.0f * p * s) / att;
+    return f4{v.x + m12 * v.y, m12 * v.x + v.y, m33 * v.z, m33 * v.w};
+}
+
+// ray.scatter.glsl:46-54: (phase * rotate) * stokes with the phase matrix of
+// polarization.glsl:88-107. This 4x4 contraction is the one spot the north star
+// earmarks for MFMA; with the block-sparse structure it is 14 multiplies per
+// photon, so it stays on the VALU ("Mueller contraction").
+template <bool ST>
+THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, f4 v,
+                            Counters<ST>& cnt) {
+    float m12 = 0.0f, m22 = 1.0f, m33 = 1.0f, m34 = 0.0f;
+    if (medium != 0) {
+        const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+        float t = 0.5f * (cos_theta + 1.0f);
+        m12 = lookUp(m->phase_m12, t, 0.0f, cnt);
+        m22 = lookUp(m->phase_m22, t, 0.0f, cnt);
+        m33 = lookUp(m->phase_m33, t, 0.0f, cnt);
+        m34 = lookUp(m->phase_m34, t, 0.0f, cnt);
+    }
+    f4 o;
+    o.x = (v.x + (m12 * c) * v.y) + (m12 * (-s)) * v.z;
+    o.y = (m12 * v.x + (m22 * c) * v.y) + (m22 * (-s)) * v.z;
+    o.z = ((m33 * s) * v.y + (m33 * c) * v.z) + m34 * v.w;
+    o.w = (((-m34) * s) * v.y + ((-m34) * c) * v.z) + m33 * v.w;
+    return o;
+}
+
+// --------------------------------------------------------- scatter.volume.glsl
+
+// scatter.volume.glsl:7-26
+THX_DEV f3 scatterDir(f3 prevDir, float cos_theta, float phi) {
+    prevDir = normalize(prevDir);
+    float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    f3 local = f3{sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+    local = normalize(local);
+    m3 trafo = createLocalCOSY(prevDir);
+    return normalize(mul(trafo, local));
+}
+
+// scatter.volume.glsl:28-45
+template <bool ST>
+THX_DEV float sampleScatterDir(uint64_t medium, float u0, float u1, float& cos_theta, float& phi,
+                               Counters<ST>& cnt) {
+    phi = u0 * TWO_PI;
+    const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+    if (medium != 0 && m->phase_sampling != 0) {
+        float ct = lookUp(m->phase_sampling, u1, 0.0f, cnt);
+        ct = clampf(ct, -1.0f, 1.0f);
+        cos_theta = ct;
+        return expf(lookUp(m->log_phase, 0.5f * (ct + 1.0f), 0.0f, cnt));
+    }
+    cos_theta = 2.0f * u1 - 1.0f;
+    return INV_4PI;
+}
+
+// scatter.volume.glsl:47-52
+template <bool ST>
+THX_DEV f3 scatter(uint64_t medium, f3 inDir, float u0, float u1, float& p, Counters<ST>& cnt) {
+    float cos_theta, phi;
+    p = sampleScatterDir(medium, u0, u1, cos_theta, phi, cnt);
+    return scatterDir(inDir, cos_theta, phi);
+}
+
+// scatter.volume.glsl:54-65
+template <bool ST>
+THX_DEV float scatterProb(uint64_t medium, f3 inDir, f3 outDir, Counters<ST>& cnt) {
+    const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+    if (medium == 0 || m->log_phase == 0) return INV_4PI;
+    float cos_theta = dot(inDir, outDir);
+    float log_p = lookUp(m->log_phase, 0.5f * (cos_theta + 1.0f), 0.0f, cnt);
+    return expf(log_p);
+}
+
+// util.sample.glsl:10-17
+THX_DEV f3 sphericalToCartessian(float phi, float cos_theta) {
+    float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    return f3{sin_theta * sinf(phi), sin_theta * cosf(phi), cos_theta};
+}
+
+} // namespace thx

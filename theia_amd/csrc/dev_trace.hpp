@@ -1,0 +1,1038 @@
+// Photon state, propagation, surface interaction, detector response and the
+// two-level BVH walk. One lane = one photon; all per-photon state lives in
+// registers. References are to /root/reference/src/theia/shader.
+#pragma once
+#include "dev_core.hpp"
+
+namespace thx {
+
+// compile-time specialisation of one kernel variant (the reference specialises
+// through GLSL macros, trace.py:660-666 / :1226-1235)
+template <bool POL_, bool MIS_, bool STATS_, bool TRACK_>
+struct Variant {
+    static constexpr bool POL = POL_;     // POLARIZATION
+    static constexpr bool MIS = MIS_;     // !DISABLE_MIS
+    static constexpr bool STATS = STATS_; // EventStatisticCallback + traversal counters
+    static constexpr bool TRACK = TRACK_; // per-event dump
+};
+
+// ray.glsl:22-36 (+163-170 polarized part)
+struct Ray {
+    f3 position, direction;
+    uint64_t medium;
+    float wavelength, time, lin_contrib, log_contrib;
+    MediumConstants constants;
+    f4 stokes;
+    f3 polRef;
+};
+
+// per-launch constants; lives in kernel-argument (scalar) memory
+struct LaunchArgs {
+    thx_run_params p;
+    uint32_t flags;
+    uint32_t path_length;
+    uint32_t n_bins;
+    uint32_t photons_per_wave; // contiguous photon range owned by one wavefront
+    uint32_t track_events;
+    uint32_t stack_depth;      // LDS traversal stack entries per lane
+    float* slabs;              // [gridDim.x][n_bins] partial histograms
+    unsigned long long* stats; // [THX_N_STATS]
+    float* track;              // [batch][track_events][THX_TRACK_WORDS] or null
+    SceneView scene;
+};
+
+// Dynamic LDS of a tracing workgroup: [n_bins floats, padded to 16 B][per-wave
+// traversal stacks: stack_depth x 64 words each]. Accessed through the
+// __shared__ symbol so that the compiler keeps the LDS address space (ds_*).
+extern __shared__ __attribute__((aligned(16))) unsigned char thx_smem[];
+THX_DEV float* ldsHist() { return reinterpret_cast<float*>(thx_smem); }
+THX_DEV uint32_t* ldsWords() { return reinterpret_cast<uint32_t*>(thx_smem); }
+
+// what a lane needs besides its ray
+template <class V>
+struct Lane {
+    const LaunchArgs* a;
+    uint32_t stackBase; // word index of this lane's stack slot 0; entry e at +e*64
+    Counters<V::STATS> cnt;
+    uint32_t idx;   // photon index == RNG stream
+    uint32_t local; // index inside the batch
+    uint32_t dim;   // RNG dimension
+};
+
+template <class V>
+THX_DEV float draw(Lane<V>& L) {
+    return rnd(L.a->p.philox, L.idx, L.dim);
+}
+
+// ray.glsl:136-143
+THX_DEV bool isRayBad(const Ray& r) {
+    f3 p = r.position, d = r.direction;
+    return isnan(p.x) || isnan(p.y) || isnan(p.z) || isinf(p.x) || isinf(p.y) || isinf(p.z) ||
+           isnan(d.x) || isnan(d.y) || isnan(d.z) || isinf(d.x) || isinf(d.y) || isinf(d.z) ||
+           length(d) <= 0.0f;
+}
+
+// ---------------------------------------------------------------- callbacks
+
+// callback.stat.glsl:29-70 (counted per lane, flushed once per wave) and the
+// optional per-event dump
+template <class V>
+THX_DEV void onEvent(Lane<V>& L, const Ray& r, int code, uint32_t i) {
+    if constexpr (V::STATS) {
+        switch (code) {
+        case RESULT_CODE_RAY_CREATED: L.cnt.add(ST_CREATED); break;
+        case RESULT_CODE_RAY_SCATTERED: L.cnt.add(ST_SCATTERED); break;
+        case RESULT_CODE_RAY_HIT: L.cnt.add(ST_HIT); break;
+        case RESULT_CODE_RAY_DETECTED: L.cnt.add(ST_DETECTED); break;
+        case RESULT_CODE_VOLUME_HIT: L.cnt.add(ST_VOLUME); break;
+        case RESULT_CODE_RAY_LOST: L.cnt.add(ST_LOST); break;
+        case RESULT_CODE_RAY_DECAYED: L.cnt.add(ST_DECAYED); break;
+        case RESULT_CODE_RAY_ABSORBED: L.cnt.add(ST_ABSORBED); break;
+        case RESULT_CODE_RAY_MISSED: L.cnt.add(ST_MISSED); break;
+        case RESULT_CODE_MAX_ITER: L.cnt.add(ST_MAXITER); break;
+        case ERROR_CODE_MEDIA_MISMATCH: L.cnt.add(ST_MISMATCH); break;
+        default: break;
+        }
+        if (code <= ERROR_CODE_MAX_VALUE) L.cnt.add(ST_ERROR);
+    }
+    if constexpr (V::TRACK) {
+        if (L.a->track != nullptr && i < L.a->track_events) {
+            float* t = L.a->track + ((size_t)L.local * L.a->track_events + i) * THX_TRACK_WORDS;
+            t[0] = (float)code;
+            t[1] = r.position.x; t[2] = r.position.y; t[3] = r.position.z;
+            t[4] = r.direction.x; t[5] = r.direction.y; t[6] = r.direction.z;
+            t[7] = r.time; t[8] = r.lin_contrib; t[9] = r.log_contrib;
+            t[10] = r.wavelength; t[11] = (float)L.dim;
+        }
+    }
+}
+
+// ------------------------------------------------------ response.histogram.glsl
+
+struct HitItem {
+    float time, contrib;
+};
+
+// response.histogram.glsl:59-68 + response.uniform.glsl:4-6. The bin update is an
+// LDS float atomic (ds_add_f32), the partial histogram is flushed per workgroup.
+template <class V>
+THX_DEV void response(Lane<V>& L, const HitItem& item) {
+    float f = floorf((item.time - L.a->p.response.t0) / L.a->p.response.binSize);
+    L.cnt.add(ST_RESPONSES);
+    // `uint bin = int(floor(..))`: negative values wrap and fail bin < N_BINS
+    if (f >= 0.0f && f < (float)L.a->n_bins) {
+        uint32_t bin = (uint32_t)f;
+        if (bin < L.a->n_bins) atomicAdd(&ldsHist()[bin], item.contrib);
+    }
+}
+
+// ray.response.glsl:18-56 / :63-84. Only time and contribution feed the
+// histogram response; the polarized contribution picks up S0 after the frame
+// alignment (whose first row is (1,0,0,0), so S0 is the ray's S0).
+template <class V>
+THX_DEV HitItem createHit(const Ray& r) {
+    float contrib = r.lin_contrib * expf(r.log_contrib);
+    if constexpr (V::POL) contrib *= r.stokes.x;
+    return HitItem{r.time, contrib};
+}
+
+// ----------------------------------------------------------- ray.scatter.glsl
+
+// ray.scatter.glsl:46-54
+template <class V>
+THX_DEV void scatterPolRay(Lane<V>& L, Ray& r, uint64_t medium, f3 dir, float cos_theta) {
+    f3 polRef;
+    float c, s;
+    rotatePolRef(r.direction, r.polRef, dir, polRef, c, s);
+    r.stokes = phaseRotateApply(medium, cos_theta, c, s, r.stokes, L.cnt);
+    r.polRef = polRef;
+}
+// ray.scatter.glsl:12-15, :70-74
+template <class V>
+THX_DEV void scatterRayIS(Lane<V>& L, Ray& r, uint64_t medium, f3 dir) {
+    if constexpr (V::POL) {
+        float cos_theta = dot(r.direction, dir);
+        scatterPolRay(L, r, medium, dir, cos_theta);
+    }
+    r.direction = dir;
+    r.lin_contrib *= r.constants.mu_s;
+}
+// ray.scatter.glsl:31-38, :92-100
+template <class V>
+THX_DEV void scatterRay(Lane<V>& L, Ray& r, uint64_t medium, float u0, float u1) {
+    float cos_theta, phi;
+    sampleScatterDir(medium, u0, u1, cos_theta, phi, L.cnt);
+    f3 newDir = scatterDir(r.direction, cos_theta, phi);
+    if constexpr (V::POL) scatterPolRay(L, r, medium, newDir, cos_theta);
+    r.direction = newDir;
+    r.lin_contrib *= r.constants.mu_s;
+}
+
+// --------------------------------------------------------- ray.propagate.glsl
+
+// ray.propagate.glsl:32-49
+THX_DEV float sampleScatterLength(const Ray& r, const thx_propagate_params& p, float u) {
+    float dist = p.maxDist;
+    float sampleCoef = p.scatterCoefficient >= 0.0f ? p.scatterCoefficient : r.constants.mu_s;
+    bool canScatter = r.constants.mu_s > 0.0f;
+    if (canScatter && sampleCoef != 0.0f) dist = -logf(1.0f - u) / sampleCoef;
+    return dist;
+}
+// ray.propagate.glsl:70-80
+THX_DEV int updateRay(Ray& r, float dist, const thx_propagate_params& p) {
+    r.log_contrib -= r.constants.mu_e * dist;
+    r.time += dist / r.constants.vg;
+    return r.time <= p.maxTime ? RESULT_CODE_SUCCESS : RESULT_CODE_RAY_DECAYED;
+}
+// ray.propagate.glsl:101-130
+THX_DEV void updateRayIS(Ray& r, float dist, const thx_propagate_params& p, bool hit) {
+    bool canScatter = r.constants.mu_s > 0.0f;
+    if (!canScatter) return;
+    float sampleCoef = p.scatterCoefficient >= 0.0f ? p.scatterCoefficient : r.constants.mu_s;
+    r.log_contrib += sampleCoef * dist;
+    if (!hit) r.lin_contrib /= sampleCoef;
+}
+// ray.propagate.glsl:153-166
+THX_DEV int propagateRay(Ray& r, float dist, const thx_propagate_params& p) {
+    r.position = r.position + r.direction * dist;
+    f3 q = r.position;
+    bool outside = q.x < p.lowerBBoxCorner[0] || q.y < p.lowerBBoxCorner[1] ||
+                   q.z < p.lowerBBoxCorner[2] || q.x > p.upperBBoxCorner[0] ||
+                   q.y > p.upperBBoxCorner[1] || q.z > p.upperBBoxCorner[2];
+    int result = updateRay(r, dist, p);
+    return outside ? RESULT_CODE_RAY_LOST : result;
+}
+// ray.propagate.glsl:193-202
+template <class V>
+THX_DEV void alignRayToHit(Ray& r, f3 hitNormal) {
+    if constexpr (V::POL) {
+        f3 polRef;
+        float c, s;
+        rotatePolRef(r.direction, r.polRef, hitNormal, polRef, c, s);
+        r.stokes = rotApply(c, s, r.stokes);
+        r.polRef = polRef;
+    }
+}
+// ray.propagate.glsl:237-265
+template <class V>
+THX_DEV int propagateRayToHit(Ray& r, f3 hitPos, f3 hitNormal, const thx_propagate_params& p) {
+    alignRayToHit<V>(r, hitNormal);
+    float dist = distance(r.position, hitPos);
+    r.position = hitPos;
+    return updateRay(r, dist, p);
+}
+
+// ------------------------------------------------- light / wavelength source
+
+// tracer.*.forward.glsl sampleRay; wavelengthsource.const.glsl:10-12;
+// wavelengthsource.uniform.glsl:12-16; lightsource.spherical.glsl:16-34;
+// lightsource.common.glsl:59-86; ray.glsl:38-79, 188-211
+template <class V>
+THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
+    const thx_run_params& P = L.a->p;
+    float wavelength, wcontrib;
+    if (L.a->flags & THX_FLAG_WAVELENGTH_UNIFORM) {
+        float u = draw(L);
+        wavelength = mixf(P.wavelength.p0, P.wavelength.p1, u);
+        wcontrib = P.wavelength.p2;
+    } else {
+        wavelength = P.wavelength.p0;
+        wcontrib = 1.0f;
+    }
+    MediumConstants constants = lookUpMedium(medium, wavelength, L.cnt);
+    float u0 = draw(L);
+    float u1 = draw(L);
+    f3 rayDir = sphericalToCartessian(TWO_PI * u0, 2.0f * u1 - 1.0f);
+    float v = draw(L);
+    Ray r;
+    r.position = ld3(P.light.position);
+    r.direction = rayDir;
+    r.medium = medium;
+    r.wavelength = wavelength;
+    r.time = mixf(P.light.t_min, P.light.t_max, v);
+    r.lin_contrib = wcontrib * P.light.contribFwd;
+    r.log_contrib = 0.0f;
+    r.constants = constants;
+    r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
+    r.polRef = f3{0.0f, 0.0f, 0.0f};
+    if constexpr (V::POL) r.polRef = createLocalCOSY(rayDir).c0;
+    return r;
+}
+
+// ============================================================================
+// VOLUME TRACER (tracer.volume.forward.glsl, target.sphere.glsl, math.sphere.glsl)
+// ============================================================================
+
+struct TargetSample {
+    f3 position, normal;
+    float dist, prob;
+    bool valid;
+};
+
+// math.sphere.glsl:14-39 (nearest root)
+THX_DEV float intersectSphereNear(f3 center, float radius, f3 origin, f3 direction) {
+    f3 f = origin - center;
+    float b2 = dot(f, direction);
+    float r2 = radius * radius;
+    f3 fd = f - direction * b2;
+    float discr = r2 - dot(fd, fd);
+    float rx = INFINITY;
+    if (discr >= 0.0f) {
+        float cc = dot(f, f) - r2;
+        float q = -b2 - signBit(b2) * sqrtf(discr);
+        rx = cc / q;
+        float ry = q;
+        if (rx > ry) rx = ry;
+    }
+    return rx;
+}
+
+// target.sphere.glsl:45-78 (objPosition = objNormal = normal, worldToObj = 1/r)
+THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f3 direction) {
+    f3 center = ld3(tp.position);
+    float t = intersectSphereNear(center, tp.radius, observer, direction);
+    TargetSample s;
+    bool hit = (t > 0.0f) && !isinf(t);
+    if (!hit) { // target.common.glsl:79-91
+        s.position = f3{0, 0, 0};
+        s.normal = f3{0, 0, 0};
+        s.dist = INFINITY;
+        s.prob = 0.0f;
+        s.valid = false;
+        return s;
+    }
+    f3 pos = observer + direction * t;
+    f3 nrm = normalize(pos - center);
+    float d = distance(observer, center);
+    float cosOpening = tp.radius / d;
+    float prob = tp.hemisphereProb / (1.0f - cosOpening);
+    bool valid = !isinf(prob);
+    if (!valid) prob = 0.0f;
+    s.position = pos; s.normal = nrm; s.dist = t; s.prob = prob; s.valid = valid;
+    return s;
+}
+
+// target.sphere.glsl:18-43
+template <class V>
+THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 observer) {
+    f3 center = ld3(tp.position);
+    f3 dir = normalize(observer - center);
+    float d = distance(observer, center);
+    float cosOpening = tp.radius / d;
+    float u0 = draw(L);
+    float u1 = draw(L);
+    float phi = TWO_PI * u0; // util.sample.glsl:23-27
+    float cos_theta = (1.0f - u1) + cosOpening * u1;
+    f3 normal = mul(createLocalCOSY(dir), sphericalToCartessian(phi, cos_theta));
+    f3 pos = normal * tp.radius + center;
+    float prob = tp.hemisphereProb / (1.0f - cosOpening);
+    bool valid = !isinf(prob);
+    if (!valid) prob = 0.0f;
+    TargetSample s;
+    s.position = pos; s.normal = normal; s.dist = distance(pos, observer); s.prob = prob;
+    s.valid = valid;
+    return s;
+}
+
+// tracer.volume.forward.glsl:51-82 (ray by value)
+template <class V>
+THX_DEV void volCreateResponse(Lane<V>& L, Ray ray, const TargetSample& hit, f3 dir, float weight,
+                               bool scattered, uint64_t medium) {
+    if (!hit.valid) return;
+    if (scattered) scatterRayIS(L, ray, medium, dir);
+    int code = propagateRayToHit<V>(ray, hit.position, hit.normal, L.a->p.volume.propagation);
+    if (code < 0) return;
+    ray.lin_contrib *= weight;
+    HitItem item = createHit<V>(ray);
+    if (item.contrib > 0.0f) response(L, item);
+}
+
+// tracer.volume.forward.glsl:103-114
+THX_DEV float jacobian_dAdW(f3 obs, f3 pos, f3 nrm) {
+    f3 dir = pos - obs;
+    float d2 = dot(dir, dir);
+    dir = normalize(dir);
+    float factor = d2 / fabsf(dot(dir, nrm));
+    if (isinf(factor)) factor = 0.0f;
+    return factor;
+}
+
+// tracer.volume.forward.glsl:116-149
+template <class V>
+THX_DEV void volSampleTargetMIS(Lane<V>& L, const Ray& ray, uint64_t med) {
+    const thx_target_params& tg = L.a->p.target;
+    f3 obs = ray.position, dir = ray.direction;
+    float pPP;
+    float u0 = draw(L);
+    float u1 = draw(L);
+    f3 dirPhase = scatter(med, dir, u0, u1, pPP, L.cnt);
+    TargetSample phaseHit = intersectTarget(tg, obs, dirPhase);
+    TargetSample targetHit = sampleTarget(L, tg, obs);
+    f3 dirTarget = normalize(targetHit.position - obs);
+    float pTT = targetHit.prob * jacobian_dAdW(obs, targetHit.position, targetHit.normal);
+    float pPT = scatterProb(med, dir, dirTarget, L.cnt);
+    float pTP = phaseHit.prob * jacobian_dAdW(obs, phaseHit.position, phaseHit.normal);
+    float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
+    float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
+    volCreateResponse(L, ray, phaseHit, dirPhase, wPhase, true, med);
+    volCreateResponse(L, ray, targetHit, dirTarget, wTarget, true, med);
+}
+
+// tracer.volume.forward.glsl:153-208
+template <class V>
+THX_DEV int volTrace(Lane<V>& L, Ray& ray, uint64_t med, bool allowResponse) {
+    const thx_propagate_params& prop = L.a->p.volume.propagation;
+    L.cnt.add(ST_STEPS);
+    float u = draw(L);
+    float dist = sampleScatterLength(ray, prop, u);
+    TargetSample hit = intersectTarget(L.a->p.target, ray.position, ray.direction);
+    bool hitValid = hit.valid && (hit.dist <= dist);
+    dist = fminf(hit.dist, dist);
+    int result = propagateRay(ray, dist, prop);
+    updateRayIS(ray, dist, prop, hitValid);
+    if (result < 0) return result;
+    if (hitValid && allowResponse) {
+        alignRayToHit<V>(ray, hit.normal);
+        HitItem item = createHit<V>(ray);
+        if (item.contrib > 0.0f) response(L, item);
+        return RESULT_CODE_RAY_DETECTED;
+    } else if (hitValid) {
+        return RESULT_CODE_RAY_ABSORBED;
+    }
+    if constexpr (V::MIS) volSampleTargetMIS(L, ray, med);
+    return RESULT_CODE_RAY_SCATTERED;
+}
+
+// One lane-step of tracer.volume.forward.glsl:231-276. step 0 = birth + the first
+// (special) trace, step k>0 = scatter + trace; the trace itself has one call
+// site. Returns false when the photon is finished.
+template <class V>
+THX_DEV bool volStep(Lane<V>& L, Ray& ray, uint32_t& step) {
+    const LaunchArgs& A = *L.a;
+    const uint64_t med = (uint64_t)A.p.volume.medium[0] | ((uint64_t)A.p.volume.medium[1] << 32);
+    const bool disable_direct = (A.flags & THX_FLAG_DISABLE_DIRECT) != 0;
+    bool allow;
+    if (step == 0) {
+        ray = sampleRay(L, med);
+        onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
+        // target.sphere.glsl:80-83
+        if (distance(ray.position, ld3(A.p.target.position)) <= A.p.target.radius) {
+            onEvent(L, ray, ERROR_CODE_TRACE_ABORT, 0);
+            return false;
+        }
+        if constexpr (V::MIS) {
+            if (!disable_direct) {
+                TargetSample directHit = intersectTarget(A.p.target, ray.position, ray.direction);
+                volCreateResponse(L, ray, directHit, ray.direction, 1.0f, false, med);
+            }
+        }
+        allow = !V::MIS && !disable_direct; // DIRECT_LIGHTING, :211-215
+    } else {
+        float u0 = draw(L);
+        float u1 = draw(L);
+        scatterRay(L, ray, med, u0, u1);
+        allow = !V::MIS; // ALLOW_RESPONSE, :217-221
+    }
+    int result = volTrace(L, ray, med, allow);
+    onEvent(L, ray, result, step + 1);
+    if (result < 0) return false;
+    if (step == A.path_length) {
+        onEvent(L, ray, RESULT_CODE_MAX_ITER, A.path_length + 2);
+        return false;
+    }
+    step += 1;
+    return true;
+}
+
+// ============================================================================
+// SCENE: BVH walk (replaces the driver's VK_KHR_ray_query) + surface physics
+// ============================================================================
+
+struct QueryHit {
+    bool valid;
+    uint32_t instance, prim;
+    float t, b1, b2; // b1, b2 = barycentric weights of v1, v2
+};
+
+struct WoopRay {
+    int kx, ky, kz;
+    float Sx, Sy, Sz;
+};
+
+// Watertight ray/triangle intersection (Woop, Benthin, Wald 2013): shear
+// constants per (object-space) ray.
+THX_DEV WoopRay woopSetup(f3 d) {
+    WoopRay w;
+    float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
+    int kz = 0;
+    if (ay > ax) kz = 1;
+    if (az > (kz == 0 ? ax : ay)) kz = 2;
+    int kx = kz + 1; if (kx == 3) kx = 0;
+    int ky = kx + 1; if (ky == 3) ky = 0;
+    if (comp(d, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
+    w.kx = kx; w.ky = ky; w.kz = kz;
+    w.Sx = comp(d, kx) / comp(d, kz);
+    w.Sy = comp(d, ky) / comp(d, kz);
+    w.Sz = 1.0f / comp(d, kz);
+    return w;
+}
+
+THX_DEV bool woopTri(const WoopRay& w, f3 org, f3 p0, f3 p1, f3 p2, float& t_io, float& b1,
+                     float& b2) {
+    f3 A = p0 - org, B = p1 - org, C = p2 - org;
+    float Akz = comp(A, w.kz), Bkz = comp(B, w.kz), Ckz = comp(C, w.kz);
+    float Ax = comp(A, w.kx) - w.Sx * Akz, Ay = comp(A, w.ky) - w.Sy * Akz;
+    float Bx = comp(B, w.kx) - w.Sx * Bkz, By = comp(B, w.ky) - w.Sy * Bkz;
+    float Cx = comp(C, w.kx) - w.Sx * Ckz, Cy = comp(C, w.ky) - w.Sy * Ckz;
+    float U = Cx * By - Cy * Bx;
+    float Vv = Ax * Cy - Ay * Cx;
+    float W = Bx * Ay - By * Ax;
+    if (U == 0.0f || Vv == 0.0f || W == 0.0f) { // edge-on: decide in double
+        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
+        Vv = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
+        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+    }
+    if ((U < 0.0f || Vv < 0.0f || W < 0.0f) && (U > 0.0f || Vv > 0.0f || W > 0.0f)) return false;
+    float det = (U + Vv) + W;
+    if (det == 0.0f) return false;
+    float Az = w.Sz * Akz, Bz = w.Sz * Bkz, Cz = w.Sz * Ckz;
+    float T = (U * Az + Vv * Bz) + W * Cz;
+    float rcpDet = 1.0f / det;
+    float t = T * rcpDet;
+    if (!(t > 0.0f && t < t_io)) return false;
+    t_io = t;
+    b1 = Vv * rcpDet;
+    b2 = W * rcpDet;
+    return true;
+}
+
+// slab test against a 32-B node; returns entry distance or -1 for a miss
+THX_DEV float slabNode(const float4 a, const float4 b, f3 o, f3 inv, float tmax) {
+    float tx0 = (a.x - o.x) * inv.x, tx1 = (b.x - o.x) * inv.x;
+    float ty0 = (a.y - o.y) * inv.y, ty1 = (b.y - o.y) * inv.y;
+    float tz0 = (a.z - o.z) * inv.z, tz1 = (b.z - o.z) * inv.z;
+    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+    return tn <= tf * 1.0000004f ? tn : -1.0f;
+}
+
+constexpr uint32_t WALK_DONE = 0xFFFFFFFFu;     // low bits 7
+constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current instance
+
+// Closest-hit query: opaque, no culling, 0 < t < tmax, committed closest triangle
+// (what scene.traverse.glsl:312-323 / :198-205 ask of the driver). Two-level
+// BVH2 with 32-B nodes; the per-lane stack lives in LDS (lane-strided so a
+// push/pop of the whole wave touches 64 consecutive banks). A node is fetched
+// exactly once, together with its sibling, when its parent is opened.
+template <class V>
+THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
+    const SceneView& sc = L.a->scene;
+    const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* tris = reinterpret_cast<const float4*>(sc.tris);
+    QueryHit h;
+    h.valid = false; h.instance = 0; h.prim = 0; h.t = tmax; h.b1 = 0.0f; h.b2 = 0.0f;
+    L.cnt.add(ST_QUERIES);
+
+    const uint32_t depth = L.a->stack_depth;
+    uint32_t* stack = ldsWords() + L.stackBase;
+    uint32_t sp = 0;
+    // active ray: world space in the TLAS, object space inside an instance
+    f3 ao = org;
+    f3 ainv = f3{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    const f3 winv = ainv;
+    WoopRay w;
+    w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
+    bool inBlas = false;
+    uint32_t curInst = 0;
+
+    uint32_t cur;
+    {
+        float4 n0 = nodes[2 * sc.tlasRoot], n1 = nodes[2 * sc.tlasRoot + 1];
+        L.cnt.add(ST_NODES);
+        cur = slabNode(n0, n1, ao, ainv, h.t) >= 0.0f
+                  ? ((__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w))
+                  : WALK_DONE;
+    }
+    while (cur != WALK_DONE) {
+        // open inner nodes until this lane holds a leaf
+        while ((cur & 7u) == 0u) {
+            uint32_t left = cur >> 3;
+            float4 l0 = nodes[2 * left], l1 = nodes[2 * left + 1];
+            float4 r0 = nodes[2 * left + 2], r1 = nodes[2 * left + 3];
+            L.cnt.add(ST_NODES, 2);
+            float tl = slabNode(l0, l1, ao, ainv, h.t);
+            float tr = slabNode(r0, r1, ao, ainv, h.t);
+            uint32_t ml = (__float_as_uint(l0.w) << 3) | __float_as_uint(l1.w);
+            uint32_t mr = (__float_as_uint(r0.w) << 3) | __float_as_uint(r1.w);
+            if (tl >= 0.0f && tr >= 0.0f) {
+                bool leftFirst = tl <= tr;
+                if (sp < depth) { stack[sp * 64] = leftFirst ? mr : ml; ++sp; }
+                cur = leftFirst ? ml : mr;
+            } else if (tl >= 0.0f) {
+                cur = ml;
+            } else if (tr >= 0.0f) {
+                cur = mr;
+            } else {
+                cur = sp > 0 ? stack[(--sp) * 64] : WALK_DONE;
+            }
+        }
+        if (cur == WALK_DONE) break;
+        if (cur == WALK_SENTINEL) { // back to world space
+            inBlas = false;
+            ao = org; ainv = winv;
+            cur = sp > 0 ? stack[(--sp) * 64] : WALK_DONE;
+            continue;
+        }
+        uint32_t first = cur >> 3, count = cur & 7u;
+        if (!inBlas) {
+            // TLAS leaves hold exactly one instance: transform the ray and dive
+            curInst = sc.tlasInstance[first];
+            const float4* rec = reinterpret_cast<const float4*>(sc.instances + curInst);
+            float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
+            uint32_t blasRoot = __float_as_uint(rec[6].x);
+            L.cnt.add(ST_INSTANCES);
+            ao = f3{m0.w + ((m0.x * org.x + m0.y * org.y) + m0.z * org.z),
+                    m1.w + ((m1.x * org.x + m1.y * org.y) + m1.z * org.z),
+                    m2.w + ((m2.x * org.x + m2.y * org.y) + m2.z * org.z)};
+            f3 od = f3{(m0.x * dir.x + m0.y * dir.y) + m0.z * dir.z,
+                       (m1.x * dir.x + m1.y * dir.y) + m1.z * dir.z,
+                       (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
+            ainv = f3{1.0f / od.x, 1.0f / od.y, 1.0f / od.z};
+            w = woopSetup(od);
+            inBlas = true;
+            if (sp < depth) { stack[sp * 64] = WALK_SENTINEL; ++sp; }
+            float4 n0 = nodes[2 * blasRoot], n1 = nodes[2 * blasRoot + 1];
+            L.cnt.add(ST_NODES);
+            if (slabNode(n0, n1, ao, ainv, h.t) >= 0.0f)
+                cur = (__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w);
+            else
+                cur = stack[(--sp) * 64]; // pops the sentinel
+            (void)count;
+        } else {
+            for (uint32_t i = 0; i < count; ++i) {
+                const float4* tr = tris + 3 * (size_t)(first + i);
+                float4 a = tr[0], b = tr[1], c = tr[2];
+                L.cnt.add(ST_TRIS);
+                if (woopTri(w, ao, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z}, h.t,
+                            h.b1, h.b2)) {
+                    h.valid = true;
+                    h.instance = curInst;
+                    h.prim = __float_as_uint(a.w);
+                }
+            }
+            cur = sp > 0 ? stack[(--sp) * 64] : WALK_DONE;
+        }
+    }
+    if (h.valid) L.cnt.add(ST_HITS);
+    return h;
+}
+
+// scene.types.glsl:29-57 (what the path needs of it)
+struct SurfaceHit {
+    bool valid, inward;
+    int customId;
+    uint32_t flags;
+    uint64_t mat_inside, mat_outside;
+    f3 worldPos, rayNrm;
+};
+
+// scene.intersect.glsl:23-99. `rayDir` is ray.state.direction (not normalised).
+template <class V>
+THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const QueryHit& q,
+                            SurfaceHit& hit) {
+    const SceneView& sc = L.a->scene;
+    hit.valid = q.valid;
+    hit.inward = false; hit.customId = 0; hit.flags = 0;
+    hit.mat_inside = 0; hit.mat_outside = 0;
+    hit.worldPos = f3{0, 0, 0}; hit.rayNrm = f3{0, 0, 0};
+    if (!hit.valid) return RESULT_CODE_RAY_MISSED;
+    const InstanceRecord* inst = sc.instances + q.instance;
+    const GeometryGLSL geom = sc.geometries[inst->geometry];
+    hit.customId = inst->customIndex;
+    const uint32_t* ix = reinterpret_cast<const uint32_t*>(geom.indices) + 3 * (size_t)q.prim;
+    const float* vb = reinterpret_cast<const float*>(geom.vertices);
+    const float* a = vb + 6 * (size_t)ix[0];
+    const float* b = vb + 6 * (size_t)ix[1];
+    const float* c = vb + 6 * (size_t)ix[2];
+    f3 p0 = ld3(a), p1 = ld3(b), p2 = ld3(c);
+    f3 n0 = ld3(a + 3), n1v = ld3(b + 3), n2v = ld3(c + 3);
+    float bx = q.b1, by = q.b2;
+    f3 e1 = p1 - p0, e2 = p2 - p0;
+    f3 objPos = f3{p0.x + __fmaf_rn(bx, e1.x, by * e2.x), p0.y + __fmaf_rn(bx, e1.y, by * e2.y),
+                   p0.z + __fmaf_rn(bx, e1.z, by * e2.z)};
+    f3 objNrm = cross(e1, e2);
+    f3 n1 = n1v - n0, n2 = n2v - n0;
+    f3 intNrm = f3{n0.x + __fmaf_rn(bx, n1.x, by * n2.x), n0.y + __fmaf_rn(bx, n1.y, by * n2.y),
+                   n0.z + __fmaf_rn(bx, n1.z, by * n2.z)};
+    objNrm = objNrm * signBit(dot(objNrm, intNrm));
+    objNrm = normalize(objNrm);
+
+    const float* W = inst->w2o; // row-major 3x4; mat3(world2Obj) columns:
+    m3 worldToObj{f3{W[0], W[4], W[8]}, f3{W[1], W[5], W[9]}, f3{W[2], W[6], W[10]}};
+    f3 objDir = normalize(mul(worldToObj, rayDir));
+    hit.inward = dot(objDir, objNrm) <= 0.0f;
+
+    uint32_t flagsIn = 0, flagsOut = 0;
+    hit.mat_inside = 0; hit.mat_outside = 0;
+    if (geom.material != 0) {
+        const MaterialGLSL* mat = reinterpret_cast<const MaterialGLSL*>(geom.material);
+        hit.mat_inside = mat->inside; hit.mat_outside = mat->outside;
+        flagsIn = mat->flagsInwards; flagsOut = mat->flagsOutwards;
+    }
+    hit.flags = hit.inward ? flagsIn : flagsOut;
+    uint64_t medium = hit.inward ? hit.mat_outside : hit.mat_inside;
+    if (rayMedium != medium) return ERROR_CODE_MEDIA_MISMATCH;
+
+    // vec3(objNrm * world2Obj): row vector times matrix (inverse-transpose normal)
+    f3 wn = f3{dot(objNrm, worldToObj.c0), dot(objNrm, worldToObj.c1), dot(objNrm, worldToObj.c2)};
+    wn = normalize(wn);
+    hit.rayNrm = wn * (2.0f * (hit.inward ? 1.0f : 0.0f) - 1.0f);
+
+    const float* M = inst->o2w;
+    hit.worldPos.x = M[3] + __fmaf_rn(M[0], objPos.x, __fmaf_rn(M[1], objPos.y, M[2] * objPos.z));
+    hit.worldPos.y = M[7] + __fmaf_rn(M[4], objPos.x, __fmaf_rn(M[5], objPos.y, M[6] * objPos.z));
+    hit.worldPos.z = M[11] + __fmaf_rn(M[8], objPos.x, __fmaf_rn(M[9], objPos.y, M[10] * objPos.z));
+    return RESULT_CODE_SUCCESS;
+}
+
+struct Reflectance {
+    float n_in, n_tr, r_s, r_p;
+};
+
+// scatter.surface.glsl:21-51
+template <class V>
+THX_DEV Reflectance fresnelReflect(Lane<V>& L, const Ray& ray, const SurfaceHit& hit) {
+    float cos_i = clampf(dot(ray.direction, hit.rayNrm), -1.0f, 1.0f);
+    float sin_i = sqrtf(fmaxf(1.0f - cos_i * cos_i, 0.0f));
+    uint64_t otherMed = hit.inward ? hit.mat_inside : hit.mat_outside;
+    float n_i = ray.constants.n;
+    float n_t = 1.0f;
+    if (otherMed != 0) {
+        const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(otherMed);
+        float u_t = normalize_lambda(m, ray.wavelength);
+        n_t = lookUp(m->n, u_t, 1.0f, L.cnt);
+    }
+    float sin_t = sin_i * n_i / n_t;
+    float cos_t = sqrtf(fmaxf(1.0f - sin_t * sin_t, 0.0f));
+    cos_i = fabsf(cos_i);
+    Reflectance r;
+    r.n_in = n_i; r.n_tr = n_t;
+    r.r_s = (n_i * cos_i - n_t * cos_t) / (n_i * cos_i + n_t * cos_t);
+    r.r_p = (n_t * cos_i - n_i * cos_t) / (n_t * cos_i + n_i * cos_t);
+    return r;
+}
+
+// ray.surface.glsl:22-36 (integer-ULP nudge against self-intersection)
+THX_DEV f3 offsetRay(f3 p, f3 n) {
+    int ox = (int)(256.0f * n.x), oy = (int)(256.0f * n.y), oz = (int)(256.0f * n.z);
+    f3 pi = f3{__int_as_float(__float_as_int(p.x) + ((p.x < 0.0f) ? -ox : ox)),
+               __int_as_float(__float_as_int(p.y) + ((p.y < 0.0f) ? -oy : oy)),
+               __int_as_float(__float_as_int(p.z) + ((p.z < 0.0f) ? -oz : oz))};
+    return f3{fabsf(p.x) < (1.0f / 32.0f) ? p.x + (1.0f / 65536.0f) * n.x : pi.x,
+              fabsf(p.y) < (1.0f / 32.0f) ? p.y + (1.0f / 65536.0f) * n.y : pi.y,
+              fabsf(p.z) < (1.0f / 32.0f) ? p.z + (1.0f / 65536.0f) * n.z : pi.z};
+}
+
+// ray.surface.glsl:44-55
+template <class V>
+THX_DEV void crossBorder(Lane<V>& L, Ray& ray, const SurfaceHit& hit) {
+    ray.position = offsetRay(hit.worldPos, -hit.rayNrm);
+    uint64_t medium = hit.inward ? hit.mat_inside : hit.mat_outside;
+    ray.medium = medium;
+    ray.constants = lookUpMedium(medium, ray.wavelength, L.cnt);
+}
+
+THX_DEV f3 glslReflect(f3 I, f3 N) { return I - N * (2.0f * dot(N, I)); }
+THX_DEV f3 glslRefract(f3 I, f3 N, float eta) {
+    float d = dot(N, I);
+    float k = 1.0f - eta * eta * (1.0f - d * d);
+    if (k < 0.0f) return f3{0.0f, 0.0f, 0.0f};
+    return I * eta - N * (eta * d + sqrtf(k));
+}
+
+// ray.surface.glsl:65-92, :147-166. IS = reflectance not applied.
+template <class V, bool IS>
+THX_DEV void reflectRay(Ray& ray, const SurfaceHit& hit, const Reflectance& refl) {
+    ray.position = offsetRay(hit.worldPos, hit.rayNrm);
+    ray.direction = normalize(glslReflect(ray.direction, hit.rayNrm));
+    if constexpr (!IS) {
+        float s = refl.r_s, p = refl.r_p;
+        ray.lin_contrib *= 0.5f * (s * s + p * p);
+    }
+    if constexpr (V::POL) ray.stokes = polarizerApply(refl.r_p, refl.r_s, ray.stokes);
+}
+// ray.surface.glsl:102-132, :193-218
+template <class V, bool IS>
+THX_DEV void transmitRay(Lane<V>& L, Ray& ray, const SurfaceHit& hit, const Reflectance& refl) {
+    crossBorder(L, ray, hit);
+    float eta = refl.n_in / refl.n_tr;
+    ray.direction = normalize(glslRefract(ray.direction, hit.rayNrm, eta));
+    if constexpr (!IS) {
+        float s = refl.r_s, p = refl.r_p;
+        ray.lin_contrib *= 1.0f - 0.5f * (s * s + p * p);
+    }
+    if constexpr (V::POL) {
+        float t_s = refl.r_s + 1.0f;
+        float t_p = (refl.r_p + 1.0f) * eta;
+        ray.stokes = polarizerApply(t_p, t_s, ray.stokes);
+    }
+}
+
+// ------------------------------------------------- target_guide.sphere.glsl
+
+struct GuideSample {
+    f3 dir;
+    float dist, prob;
+};
+
+// target_guide.sphere.glsl:17-31 == :55-69
+THX_DEV void guideCone(const thx_guide_params& g, f3 observer, float& d, f3& viewDir,
+                       float& cosMin, float& prob) {
+    f3 center = ld3(g.position);
+    d = distance(center, observer);
+    viewDir = normalize(center - observer);
+    float sinMax = g.radius / d;
+    float sin2Max = sinMax * sinMax;
+    cosMin = 1.0f - sqrtf(fmaxf(1.0f - sin2Max, 0.0f));
+    if (sin2Max < 0.00068523f) cosMin = 0.5f * sin2Max;
+    prob = 1.0f / (TWO_PI * cosMin);
+    prob *= (d > g.radius) ? 1.0f : 0.0f;
+}
+// target_guide.sphere.glsl:15-51
+template <class V>
+THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
+    const thx_guide_params& g = L.a->p.guide;
+    float d, cosMin, prob;
+    f3 viewDir;
+    guideCone(g, observer, d, viewDir, cosMin, prob);
+    float cosTheta = 1.0f - cosMin * draw(L);
+    float sinTheta = sqrtf(fmaxf(1.0f - cosTheta * cosTheta, 0.0f));
+    float phi = TWO_PI * draw(L);
+    f3 local = f3{sinTheta * sinf(phi), sinTheta * cosf(phi), cosTheta};
+    GuideSample s;
+    s.dir = mul(createLocalCOSY(viewDir), local);
+    s.dist = d + g.radius;
+    s.prob = prob;
+    return s;
+}
+// target_guide.sphere.glsl:53-81
+THX_DEV GuideSample evalTargetGuide(const thx_guide_params& g, f3 observer, f3 direction) {
+    float d, cosMin, prob;
+    f3 viewDir;
+    guideCone(g, observer, d, viewDir, cosMin, prob);
+    float cosDir = dot(viewDir, direction);
+    prob *= (cosMin >= 1.0f - cosDir) ? 1.0f : 0.0f;
+    return GuideSample{direction, d + g.radius, prob};
+}
+
+// ----------------------------------------------------- scene.traverse.glsl
+
+// scene.traverse.glsl:33-68 (ray by value)
+template <class V>
+THX_DEV void sceneCreateResponse(Lane<V>& L, Ray ray, const SurfaceHit& hit,
+                                 const Reflectance& surface, bool absorb) {
+    if (!absorb) {
+        // HIT_USE_TRANSMITTED_DIR only changes the recorded direction, which the
+        // histogram response does not read; the transmission factor applies either way
+        transmitRay<V, false>(L, ray, hit, surface);
+    }
+    HitItem item = createHit<V>(ray);
+    if (item.contrib > 0.0f) response(L, item);
+}
+
+// scene.traverse.glsl:160-180 (ray by value; `hit` already checked for validity)
+template <class V>
+THX_DEV void processShadowRay(Lane<V>& L, Ray ray, const SurfaceHit& hit) {
+    const int targetId = L.a->p.scene.targetId;
+    bool isTarget = (hit.flags & MATERIAL_DETECTOR_BIT) != 0;
+    bool correctId = targetId < 0 || targetId == hit.customId;
+    if (!hit.valid || !correctId || !isTarget) return;
+    if (propagateRayToHit<V>(ray, hit.worldPos, hit.rayNrm, L.a->p.scene.propagation) < 0) return;
+    Reflectance surface = fresnelReflect(L, ray, hit);
+    bool black = (hit.flags & MATERIAL_BLACK_BODY_BIT) != 0;
+    sceneCreateResponse(L, ray, hit, surface, black);
+}
+
+// scene.traverse.glsl:73-154
+template <class V>
+THX_DEV int processHit(Lane<V>& L, Ray& ray, const SurfaceHit& hit, bool allowResponse) {
+    const LaunchArgs& A = *L.a;
+    const int targetId = A.p.scene.targetId;
+    int result = propagateRayToHit<V>(ray, hit.worldPos, hit.rayNrm, A.p.scene.propagation);
+    if (result < 0) return result;
+    result = RESULT_CODE_RAY_HIT;
+    bool isAbs = (hit.flags & MATERIAL_BLACK_BODY_BIT) != 0;
+    bool isTarget = (hit.flags & MATERIAL_DETECTOR_BIT) != 0;
+    bool volBorder = (hit.flags & MATERIAL_VOLUME_BORDER_BIT) != 0;
+    bool canTransmit = (hit.flags & MATERIAL_NO_TRANSMIT_BWD_BIT) == 0;
+    bool canReflect = (hit.flags & MATERIAL_NO_REFLECT_BWD_BIT) == 0;
+    Reflectance surface = fresnelReflect(L, ray, hit);
+    if (allowResponse && isTarget && (targetId < 0 || hit.customId == targetId)) {
+        sceneCreateResponse(L, ray, hit, surface, isAbs);
+        result = RESULT_CODE_RAY_DETECTED;
+    }
+    if (isAbs) return RESULT_CODE_RAY_ABSORBED;
+    if (!(A.flags & THX_FLAG_DISABLE_VOLUME_BORDER)) {
+        if (volBorder) {
+            crossBorder(L, ray, hit);
+            return RESULT_CODE_VOLUME_HIT;
+        }
+    }
+    if (!(A.flags & THX_FLAG_DISABLE_TRANSMISSION)) {
+        float r = 0.5f * (surface.r_s * surface.r_s + surface.r_p * surface.r_p);
+        if (canReflect && canTransmit) {
+            if (draw(L) < r) reflectRay<V, true>(ray, hit, surface);
+            else transmitRay<V, true>(L, ray, hit, surface);
+        } else if (canReflect) {
+            reflectRay<V, false>(ray, hit, surface);
+        } else if (canTransmit) {
+            transmitRay<V, false>(L, ray, hit, surface);
+        } else {
+            result = RESULT_CODE_RAY_ABSORBED;
+        }
+    } else {
+        if (canReflect) reflectRay<V, false>(ray, hit, surface);
+        else result = RESULT_CODE_RAY_ABSORBED;
+    }
+    return result;
+}
+
+// One lane-step of tracer.scene.forward.glsl:58-106 = trace()
+// (scene.traverse.glsl:280-352) + processInteraction() (:361-397).
+//
+// The up-to-three closest-hit queries of a step (primary, MIS phase shadow ray,
+// MIS target shadow ray; :312-323, :185-214) run through ONE walk loop so that
+// the traversal code exists once and all lanes of the wave traverse together.
+// RNG draw order is the reference's: free path, [reflect/transmit], MIS phase
+// (2), MIS guide (2), scatter (2)  (SURVEY.md 3.4).
+template <class V>
+THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse) {
+    const LaunchArgs& A = *L.a;
+    const thx_propagate_params& prop = A.p.scene.propagation;
+    if (step == 0) {
+        const uint64_t medium =
+            (uint64_t)A.p.scene.sceneMedium[0] | ((uint64_t)A.p.scene.sceneMedium[1] << 32);
+        ray = sampleRay(L, medium);
+        onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
+        allowResponse = (A.flags & THX_FLAG_DISABLE_DIRECT) == 0;
+        step = 1;
+        if (A.path_length == 0) {
+            onEvent(L, ray, RESULT_CODE_MAX_ITER, 1);
+            return false;
+        }
+    }
+    const bool last = step == A.path_length;
+    L.cnt.add(ST_STEPS);
+
+    int result = RESULT_CODE_SUCCESS;
+    bool pending = true; // step still needs its primary query
+    f3 dir = f3{0, 0, 1};
+    float dist = 0.0f, sampledDist = 0.0f;
+    bool mis_target = false;
+    if (isRayBad(ray)) {
+        result = ERROR_CODE_RAY_BAD;
+        pending = false;
+    } else {
+        dir = normalize(ray.direction);
+        dist = sampleScatterLength(ray, prop, draw(L));
+        sampledDist = dist;
+        if constexpr (V::MIS) {
+            GuideSample gs = evalTargetGuide(A.p.guide, ray.position, dir);
+            mis_target = allowResponse && gs.prob > 0.0f;
+            if (mis_target) {
+                mis_target = gs.dist > dist;
+                dist = fmaxf(gs.dist, dist);
+            }
+        }
+    }
+
+    // MIS shadow-ray set-up, filled in after the primary query missed
+    bool doShadow = false;
+    f3 dirPhase = f3{0, 0, 1}, dirTarget = f3{0, 0, 1};
+    float distPhase = 0.0f, distTarget = 0.0f, wPhase = 0.0f, wTarget = 0.0f;
+    bool scatterAfter = false;
+
+    constexpr int NQ = V::MIS ? 3 : 1;
+#pragma unroll 1
+    for (int q = 0; q < NQ; ++q) {
+        const bool need = q == 0 ? pending : doShadow;
+        f3 qd = q == 0 ? dir : (q == 1 ? dirPhase : dirTarget);
+        float qmax = q == 0 ? dist : (q == 1 ? distPhase : distTarget);
+        QueryHit qh;
+        qh.valid = false;
+        if (need) qh = rayQuery(L, ray.position, qd, qmax);
+        if (!need) continue;
+
+        // the ray whose state the hit is evaluated with
+        Ray s = ray;
+        if (q > 0) scatterRayIS(L, s, ray.medium, qd); // scene.traverse.glsl:195
+        SurfaceHit hit;
+        int queryResult = processRayQuery(L, s.direction, s.medium, qh, hit);
+
+        if (q > 0) { // traceShadowRay, scene.traverse.glsl:207-213
+            if (queryResult < 0) continue;
+            s.lin_contrib *= (q == 1 ? wPhase : wTarget);
+            processShadowRay(L, s, hit);
+            continue;
+        }
+
+        // ---- rest of trace(), scene.traverse.glsl:329-351
+        if (hit.valid) dist = distance(ray.position, hit.worldPos);
+        if constexpr (V::MIS) {
+            if (mis_target && hit.valid && dist > sampledDist && queryResult >= 0) {
+                processShadowRay(L, ray, hit);
+                hit.valid = false;
+                dist = sampledDist;
+            }
+        }
+        int propResult = propagateRay(ray, dist, prop);
+        updateRayIS(ray, dist, prop, hit.valid);
+        result = queryResult <= ERROR_CODE_MAX_VALUE ? queryResult : propResult;
+        if (result < 0) continue;
+
+        // ---- processInteraction(), scene.traverse.glsl:361-397
+        if (hit.valid) {
+            result = processHit(L, ray, hit, allowResponse);
+        } else {
+            if (!last) {
+                if constexpr (V::MIS) { // sampleTargetMIS, :234-269
+                    float pPP;
+                    float u0 = draw(L);
+                    float u1 = draw(L);
+                    dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
+                    GuideSample ts = sampleTargetGuide(L, ray.position);
+                    float pTT = ts.prob;
+                    GuideSample ps = evalTargetGuide(A.p.guide, ray.position, dirPhase);
+                    float pTP = ps.prob;
+                    float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
+                    wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
+                    wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
+                    dirTarget = ts.dir;
+                    distPhase = ps.dist;
+                    distTarget = ts.dist;
+                    doShadow = true;
+                }
+                scatterAfter = true;
+            }
+            result = RESULT_CODE_RAY_SCATTERED;
+        }
+    }
+    if (scatterAfter) { // scene.traverse.glsl:391
+        float u0 = draw(L);
+        float u1 = draw(L);
+        scatterRay(L, ray, ray.medium, u0, u1);
+    }
+
+    onEvent(L, ray, result, step);
+    if (result < 0) return false;
+    if constexpr (V::MIS) allowResponse = result != RESULT_CODE_RAY_SCATTERED;
+    else allowResponse = true;
+    if (last) {
+        onEvent(L, ray, RESULT_CODE_MAX_ITER, A.path_length + 1);
+        return false;
+    }
+    step += 1;
+    return true;
+}
+
+} // namespace thx

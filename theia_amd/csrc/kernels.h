@@ -1,0 +1,40 @@
+// Host-visible launch entry points of the HIP kernels (internal to the library).
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include "dev_trace.hpp"
+
+namespace thx {
+
+constexpr uint32_t kTraceBlock = 256;  // threads per tracing workgroup (4 wavefronts)
+constexpr uint32_t kStackDepth = 32;   // LDS traversal stack entries per lane
+
+// dynamic LDS bytes of a tracing workgroup
+inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block) {
+    size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
+    size_t stack = kind == THX_TRACER_SCENE_FORWARD ? (size_t)(block / 64) * kStackDepth * 64 * 4 : 0;
+    return hist + stack;
+}
+
+// one function pair per compiled variant (trace_variant.hip, built once per
+// KIND x POL x MIS); `debug` selects the instrumented (statistics + track) kernel
+typedef hipError_t (*trace_launch_fn)(bool debug, const LaunchArgs& args, uint32_t grid,
+                                      uint32_t block, size_t lds, hipStream_t stream);
+typedef int (*trace_occupancy_fn)(bool debug, uint32_t block, size_t lds);
+
+struct TraceVariant {
+    trace_launch_fn launch;
+    trace_occupancy_fn occupancy;
+};
+// index = kind * 4 + pol * 2 + mis
+const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis);
+
+hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
+                        float norm, hipStream_t stream);
+hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,
+                         uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
+                         float* out_f32, hipStream_t stream);
+hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, float* out6,
+                       hipStream_t stream);
+
+} // namespace thx

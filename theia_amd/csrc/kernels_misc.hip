@@ -1,0 +1,113 @@
+// Small kernels: histogram slab reduction, RNG probe, ray-query probe; plus the
+// table that maps (kind, polarized, mis) to the separately compiled variants.
+#include <cstring>
+
+#include "kernels.h"
+
+namespace thx {
+
+#define THX_DECL(k, p, m)                                                                        \
+    hipError_t traceLaunch_##k##_##p##_##m(bool, const LaunchArgs&, uint32_t, uint32_t, size_t,  \
+                                           hipStream_t);                                         \
+    int traceOccupancy_##k##_##p##_##m(bool, uint32_t, size_t);
+THX_DECL(0, 0, 0) THX_DECL(0, 0, 1) THX_DECL(0, 1, 0) THX_DECL(0, 1, 1)
+THX_DECL(1, 0, 0) THX_DECL(1, 0, 1) THX_DECL(1, 1, 0) THX_DECL(1, 1, 1)
+#undef THX_DECL
+
+const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis) {
+#define THX_ENT(k, p, m) TraceVariant{traceLaunch_##k##_##p##_##m, traceOccupancy_##k##_##p##_##m}
+    static const TraceVariant table[8] = {THX_ENT(0, 0, 0), THX_ENT(0, 0, 1), THX_ENT(0, 1, 0),
+                                          THX_ENT(0, 1, 1), THX_ENT(1, 0, 0), THX_ENT(1, 0, 1),
+                                          THX_ENT(1, 1, 0), THX_ENT(1, 1, 1)};
+#undef THX_ENT
+    return table[(kind & 1u) * 4 + (pol ? 2 : 0) + (mis ? 1 : 0)];
+}
+
+// estimator.reduce.glsl:17-35: out[b] = norm * KahanSum_h slab[h][b]. One thread
+// per bin; for a fixed h the wave reads consecutive floats (coalesced).
+// (-ffp-contract=off keeps the compensation from being folded away.)
+__global__ void reduceKernel(const float* __restrict__ slabs, float* __restrict__ out,
+                             uint32_t n_bins, uint32_t n_hist, float norm) {
+    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    if (idx >= n_bins) return;
+    float result = 0.0f, c = 0.0f;
+    size_t i = idx;
+    for (uint32_t n = 0; n < n_hist; ++n, i += n_bins) {
+        float y = slabs[i] - c;
+        float t = result + y;
+        c = (t - result) - y;
+        result = t;
+    }
+    out[idx] = result * norm;
+}
+
+hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
+                        float norm, hipStream_t stream) {
+    uint32_t block = 128; // response.py:1075 default blockSize
+    uint32_t grid = (n_bins + block - 1) / block;
+    hipLaunchKernelGGL(reduceKernel, dim3(grid), dim3(block), 0, stream, slabs, out, n_bins, n_hist, norm);
+    return hipGetLastError();
+}
+
+// random.sink.glsl equivalent: raw words + floats behind random(stream, dim)
+__global__ void rngFillKernel(thx_philox_params p, uint32_t base_stream, uint32_t n_streams,
+                              uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
+                              float* out_f32) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n_streams * n_samples;
+    if (i >= total) return;
+    uint32_t s = (uint32_t)(i / n_samples), k = (uint32_t)(i % n_samples);
+    uint32_t v = random_u32(p, base_stream + s, first_dim + k);
+    if (out_u32) out_u32[i] = v;
+    if (out_f32) out_f32[i] = normalizeUint(v);
+}
+
+hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,
+                         uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
+                         float* out_f32, hipStream_t stream) {
+    size_t total = (size_t)n_streams * n_samples;
+    uint32_t block = 256;
+    uint32_t grid = (uint32_t)((total + block - 1) / block);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(rngFillKernel, dim3(grid), dim3(block), 0, stream, p, base_stream, n_streams,
+                       first_dim, n_samples, out_u32, out_f32);
+    return hipGetLastError();
+}
+
+// closest-hit probe for BVH parity tests
+__global__ void __launch_bounds__(kTraceBlock) queryKernel(LaunchArgs args, const float* rays7,
+                                                           uint32_t n, float* out6) {
+    using V = Variant<false, false, false, false>;
+    uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    Lane<V> L;
+    L.a = &args;
+    L.stackBase = (threadIdx.x >> 6) * args.stack_depth * 64u + (threadIdx.x & 63u);
+    L.idx = 0; L.local = 0; L.dim = 0;
+    if (i >= n) return;
+    const float* r = rays7 + 7 * (size_t)i;
+    QueryHit h = rayQuery(L, f3{r[0], r[1], r[2]}, f3{r[3], r[4], r[5]}, r[6]);
+    float* o = out6 + 6 * (size_t)i;
+    o[0] = h.valid ? 1.0f : 0.0f;
+    o[1] = (float)h.instance;
+    o[2] = (float)h.prim;
+    o[3] = h.t;
+    o[4] = h.b1;
+    o[5] = h.b2;
+}
+
+hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, float* out6,
+                       hipStream_t stream) {
+    LaunchArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.scene = scene;
+    a.stack_depth = kStackDepth;
+    a.n_bins = 0;
+    uint32_t block = kTraceBlock;
+    uint32_t grid = (n + block - 1) / block;
+    if (grid == 0) return hipSuccess;
+    size_t lds = (size_t)(block / 64) * kStackDepth * 64 * 4;
+    hipLaunchKernelGGL(queryKernel, dim3(grid), dim3(block), lds, stream, a, rays7, n, out6);
+    return hipGetLastError();
+}
+
+} // namespace thx
