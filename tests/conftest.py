@@ -1,0 +1,45 @@
+import os
+import sys
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+
+
+def pytest_configure(config):
+    config.addinivalue_line("markers", "gpu: needs a real MI355X (run with -m gpu on the GPU box)")
+    config.addinivalue_line("markers", "slow: long-running statistical test")
+
+
+@pytest.fixture
+def oracle_backend():
+    """Installs the CPU-oracle stand-in as theia_amd's backend for one test."""
+    from oracle_backend import OracleBackend
+    from theia_amd import _backend
+
+    prev = _backend._backend
+    be = OracleBackend(threads=min(8, os.cpu_count() or 1))
+    _backend._backend = be
+    yield be
+    _backend._backend = prev
+
+
+@pytest.fixture(scope="session")
+def hip():
+    """The real HIP backend (fails loudly when libtheia_hip.so or the GPU is missing)."""
+    from theia_amd import _backend
+
+    return _backend.HipBackend()
+
+
+@pytest.fixture
+def hip_backend(hip):
+    from theia_amd import _backend
+
+    prev = _backend._backend
+    _backend._backend = hip
+    yield hip
+    _backend._backend = prev

@@ -1,0 +1,173 @@
+"""
+TEST INFRASTRUCTURE: a stand-in for theia_amd's device backend that executes
+on the CPU oracle (oracle/). It lets the `-m "not gpu"` suite drive the *host*
+logic of theia_amd (stages, pipelines, parameter translation, sharding) on a
+machine without a GPU, and gives the GPU parity tests the oracle's answer for
+the same scenario description. It is never importable from the product.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import sys
+
+import numpy as np
+
+_ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(_ROOT, "oracle"))
+import oracle as orc  # noqa: E402
+
+from theia_amd import _capi as capi  # noqa: E402
+
+
+def _copy(dst, src) -> None:
+    assert C.sizeof(dst) == C.sizeof(src), (type(dst), type(src))
+    C.memmove(C.addressof(dst), C.addressof(src), C.sizeof(dst))
+
+
+class _Tracer:
+    def __init__(self, spec, scene) -> None:
+        self.spec = spec
+        self.scene = scene
+        self.raw = [np.zeros(spec.n_bins, np.float32) for _ in range(2)]
+        self.out = [np.zeros(spec.n_bins, np.float32) for _ in range(2)]
+        self.stats = np.zeros(orc.N_STATS, np.uint64)
+        self.track = None
+
+
+class OracleBackend:
+    name = "oracle"
+
+    def __init__(self, threads: int = 0, brute_force: bool = False) -> None:
+        self.threads = threads
+        self.brute_force = brute_force
+        self._blobs: dict[int, orc.HostBlob] = {}
+        self._scenes: dict[int, orc.Scene] = {}
+        self._tracers: dict[int, _Tracer] = {}
+        self._next = 1
+
+    # device
+    def device_name(self) -> str:
+        return "CPU oracle (test stand-in)"
+
+    def device_info(self) -> dict:
+        return {"compute_units": os.cpu_count(), "lds_per_cu": 0, "hbm_bytes": 0}
+
+    def sync(self) -> None:
+        pass
+
+    # memory
+    def alloc(self, nbytes: int) -> int:
+        blob = orc.HostBlob(nbytes)
+        self._blobs[blob.address] = blob
+        return blob.address
+
+    def free(self, addr: int) -> None:
+        self._blobs.pop(addr, None)
+
+    def upload(self, addr: int, data) -> None:
+        self._blobs[addr].upload(bytes(data))
+
+    def download(self, addr: int, nbytes: int) -> bytes:
+        return self._blobs[addr].buf[:nbytes].tobytes()
+
+    # scene
+    def scene_create(self, meshes, instances) -> int:
+        h = self._next
+        self._next += 1
+        self._scenes[h] = orc.Scene(meshes, instances)
+        return h
+
+    def scene_destroy(self, scene: int) -> None:
+        self._scenes.pop(scene, None)
+
+    def scene_info(self, scene: int) -> dict:
+        return {}
+
+    def scene_query(self, scene: int, origins, dirs, tmax) -> np.ndarray:
+        o = np.asarray(origins, np.float32).reshape(-1, 3)
+        d = np.asarray(dirs, np.float32).reshape(-1, 3)
+        t = np.broadcast_to(np.asarray(tmax, np.float32), (o.shape[0],))
+        out = np.zeros((o.shape[0], 6), np.float32)
+        for i in range(o.shape[0]):
+            hit, r = self._scenes[scene].query(o[i], d[i], float(t[i]), self.brute_force)
+            out[i, 0] = 1.0 if hit else 0.0
+            out[i, 1:] = r
+        return out
+
+    # tracer
+    def tracer_create(self, spec, scene) -> int:
+        h = self._next
+        self._next += 1
+        self._tracers[h] = _Tracer(spec, self._scenes[scene] if scene else None)
+        return h
+
+    def tracer_destroy(self, tracer: int) -> None:
+        self._tracers.pop(tracer, None)
+
+    def tracer_run(self, tracer: int, cfg: int, params: capi.RunParams, stream: int = 0) -> None:
+        t = self._tracers[tracer]
+        spec = t.spec
+        c = orc.Common()
+        flags = spec.flags & 0x7F
+        if self.brute_force:
+            flags |= orc.FLAG_BRUTE_FORCE
+        c.flags = flags
+        c.path_length = spec.path_length
+        c.block_size = spec.block_size
+        c.n_bins = spec.n_bins
+        c.batch_size = params.dispatch.batchSize
+        c.photon_offset = params.photon_offset
+        c.normalization = 1.0
+        _copy(c.philox, params.philox)
+        _copy(c.light, params.light)
+        _copy(c.wavelength, params.wavelength)
+        _copy(c.response, params.response)
+        want_track = bool(spec.flags & capi.FLAG_TRACK)
+        if spec.kind == capi.TRACER_VOLUME_FORWARD:
+            tp, tg = orc.VolumeTraceParams(), orc.TargetParams()
+            _copy(tp, params.volume)
+            _copy(tg, params.target)
+            hist, stats, track = orc.trace_volume(c, tp, tg, threads=self.threads, track=want_track)
+        else:
+            tp, g = orc.SceneTraceParams(), orc.GuideParams()
+            _copy(tp, params.scene)
+            _copy(g, params.guide)
+            guide = None if (spec.flags & capi.FLAG_DISABLE_MIS) else g
+            hist, stats, track = orc.trace_scene(c, tp, guide, t.scene, threads=self.threads, track=want_track)
+        t.raw[cfg] = hist
+        t.stats += stats
+        t.track = track
+
+    def tracer_reduce(self, tracer: int, cfg: int, norm: float, d_out: int = 0, stream: int = 0) -> None:
+        t = self._tracers[tracer]
+        t.out[cfg] = (t.raw[cfg] * np.float32(norm)).astype(np.float32)
+
+    def tracer_read_hist(self, tracer: int, cfg: int, n_bins: int) -> np.ndarray:
+        return self._tracers[tracer].out[cfg].copy()
+
+    def tracer_hist_ptr(self, tracer: int, cfg: int) -> int:
+        return int(self._tracers[tracer].out[cfg].ctypes.data)
+
+    def tracer_read_stats(self, tracer: int) -> np.ndarray:
+        return self._tracers[tracer].stats.copy()
+
+    def tracer_reset_stats(self, tracer: int) -> None:
+        self._tracers[tracer].stats[:] = 0
+
+    def tracer_read_track(self, tracer: int, batch: int, events: int) -> np.ndarray:
+        return self._tracers[tracer].track[:batch]
+
+    def tracer_launch_info(self, tracer: int, batch: int) -> dict:
+        return {"grid": 0, "block": 0, "lds_bytes": 0}
+
+    def tracer_last_kernel_ms(self, tracer: int, cfg: int) -> float:
+        return float("nan")
+
+    def rng_fill(self, key, offset, base_stream, n_streams, first_dim, n_samples):
+        return orc.rng_fill(key, offset, base_stream, n_streams, first_dim, n_samples)
+
+    def close(self) -> None:
+        self._tracers.clear()
+        self._scenes.clear()
+        self._blobs.clear()

@@ -1,0 +1,196 @@
+"""
+ctypes binding of ``libtheia_hip.so`` (C ABI declared in ``include/theia_hip.h``).
+
+The library is the product's only compute path; loading fails loudly when the
+shared object is missing (run ``python -c "import __graft_entry__ as g; g.build()"``
+or ``make -C theia_amd/csrc``) and creating a context fails loudly when no HIP
+device is present. There is no CPU fallback.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+from ctypes import POINTER, Structure, c_char_p, c_float, c_int, c_int32, c_size_t, c_uint32, c_uint64, c_void_p
+
+__all__ = [
+    "lib", "lib_path", "check", "ThxError",
+    "DispatchParams", "PhiloxParams", "LightParams", "WavelengthParams", "TargetParams",
+    "GuideParams", "PropagateParams", "VolumeTraceParams", "SceneTraceParams", "ResponseParams",
+    "RunParams", "TracerDesc", "MeshDesc", "InstanceDesc", "SceneInfo",
+    "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
+    "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
+    "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
+    "FLAG_STATISTICS", "FLAG_TRACK", "EXPORTED_SYMBOLS",
+]
+
+TRACER_VOLUME_FORWARD = 0
+TRACER_SCENE_FORWARD = 1
+FLAG_POLARIZED = 1 << 0
+FLAG_DISABLE_DIRECT = 1 << 1
+FLAG_DISABLE_MIS = 1 << 2
+FLAG_DISABLE_TRANSMISSION = 1 << 3
+FLAG_DISABLE_VOLUME_BORDER = 1 << 4
+FLAG_HIT_USE_TRANSMITTED = 1 << 5
+FLAG_WAVELENGTH_UNIFORM = 1 << 6
+FLAG_STATISTICS = 1 << 8
+FLAG_TRACK = 1 << 9
+N_STATS = 20
+TRACK_WORDS = 12
+STAT_NAMES = (
+    "created", "scattered", "hit", "detected", "volume", "lost", "decayed", "absorbed", "missed",
+    "maxIter", "error", "mismatch",
+    "queries", "nodes", "triangles", "instances", "hits", "lut_reads", "responses", "steps",
+)
+
+
+class ThxError(RuntimeError):
+    """Error reported by libtheia_hip.so"""
+
+    def __init__(self, code: int, text: str) -> None:
+        super().__init__(f"libtheia_hip error {code}: {text}")
+        self.code = code
+
+
+class _Packed(Structure):
+    _pack_ = 4
+
+
+class DispatchParams(_Packed):
+    _fields_ = [("batchSize", c_uint32), ("groupCountX", c_uint32), ("groupCountY", c_uint32), ("groupCountZ", c_uint32)]
+
+
+class PhiloxParams(_Packed):
+    _fields_ = [("key", c_uint32 * 2), ("offset", c_uint32 * 4)]
+
+
+class LightParams(_Packed):
+    _fields_ = [("position", c_float * 3), ("contribFwd", c_float), ("contribBwd", c_float), ("t_min", c_float), ("t_max", c_float)]
+
+
+class WavelengthParams(_Packed):
+    _fields_ = [("p0", c_float), ("p1", c_float), ("p2", c_float)]
+
+
+class TargetParams(_Packed):
+    _fields_ = [("position", c_float * 3), ("radius", c_float), ("invPos", c_float * 3), ("invRad", c_float), ("hemisphereProb", c_float)]
+
+
+class GuideParams(_Packed):
+    _fields_ = [("position", c_float * 3), ("radius", c_float), ("prob", c_float)]
+
+
+class PropagateParams(_Packed):
+    _fields_ = [("scatterCoefficient", c_float), ("lowerBBoxCorner", c_float * 3), ("upperBBoxCorner", c_float * 3), ("maxTime", c_float), ("maxDist", c_float)]
+
+
+class VolumeTraceParams(_Packed):
+    _fields_ = [("medium", c_uint32 * 2), ("objectId", c_int32), ("propagation", PropagateParams)]
+
+
+class SceneTraceParams(_Packed):
+    _fields_ = [("targetId", c_int32), ("sceneMedium", c_uint32 * 2), ("propagation", PropagateParams)]
+
+
+class ResponseParams(_Packed):
+    _fields_ = [("t0", c_float), ("binSize", c_float)]
+
+
+class RunParams(_Packed):
+    _fields_ = [
+        ("dispatch", DispatchParams),
+        ("photon_offset", c_uint32),
+        ("philox", PhiloxParams),
+        ("light", LightParams),
+        ("wavelength", WavelengthParams),
+        ("response", ResponseParams),
+        ("volume", VolumeTraceParams),
+        ("target", TargetParams),
+        ("scene", SceneTraceParams),
+        ("guide", GuideParams),
+    ]
+
+
+class TracerDesc(Structure):
+    _fields_ = [
+        ("kind", c_uint32), ("flags", c_uint32), ("path_length", c_uint32), ("block_size", c_uint32),
+        ("n_bins", c_uint32), ("capacity", c_uint32), ("reserved", c_uint32 * 6),
+    ]
+
+
+class MeshDesc(Structure):
+    _fields_ = [("vertices", POINTER(c_float)), ("n_vertices", c_uint32), ("indices", POINTER(c_uint32)), ("n_triangles", c_uint32)]
+
+
+class InstanceDesc(Structure):
+    _fields_ = [("mesh", c_uint32), ("transform", c_float * 12), ("customIndex", c_int32), ("material", c_uint64)]
+
+
+class SceneInfo(Structure):
+    _fields_ = [
+        ("n_nodes", c_uint32), ("n_triangles", c_uint32), ("n_instances", c_uint32), ("max_depth", c_uint32),
+        ("bytes_nodes", c_uint64), ("bytes_triangles", c_uint64), ("bytes_instances", c_uint64), ("bytes_total", c_uint64),
+    ]
+
+
+# every symbol include/theia_hip.h declares: name -> (restype, argtypes)
+_PROTOS = {
+    "thx_last_error": (c_char_p, []),
+    "thx_device_count": (c_int, [POINTER(c_int)]),
+    "thx_ctx_create": (c_int, [c_int, POINTER(c_void_p)]),
+    "thx_ctx_destroy": (c_int, [c_void_p]),
+    "thx_ctx_device_name": (c_int, [c_void_p, c_char_p, c_size_t]),
+    "thx_ctx_device_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
+    "thx_ctx_sync": (c_int, [c_void_p]),
+    "thx_mem_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_uint64)]),
+    "thx_mem_free": (c_int, [c_void_p, c_uint64]),
+    "thx_mem_upload": (c_int, [c_void_p, c_uint64, c_void_p, c_size_t]),
+    "thx_mem_download": (c_int, [c_void_p, c_void_p, c_uint64, c_size_t]),
+    "thx_scene_create": (c_int, [c_void_p, POINTER(MeshDesc), c_uint32, POINTER(InstanceDesc), c_uint32, POINTER(c_void_p)]),
+    "thx_scene_destroy": (c_int, [c_void_p]),
+    "thx_scene_get_info": (c_int, [c_void_p, POINTER(SceneInfo)]),
+    "thx_scene_query": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_float)]),
+    "thx_tracer_create": (c_int, [c_void_p, POINTER(TracerDesc), c_void_p, POINTER(c_void_p)]),
+    "thx_tracer_destroy": (c_int, [c_void_p]),
+    "thx_tracer_run": (c_int, [c_void_p, c_uint32, POINTER(RunParams), c_void_p]),
+    "thx_tracer_reduce": (c_int, [c_void_p, c_uint32, c_float, c_uint64, c_void_p]),
+    "thx_tracer_read_hist": (c_int, [c_void_p, c_uint32, POINTER(c_float), c_uint32]),
+    "thx_tracer_hist_device_ptr": (c_int, [c_void_p, c_uint32, POINTER(c_uint64)]),
+    "thx_tracer_read_stats": (c_int, [c_void_p, POINTER(c_uint64), c_uint32]),
+    "thx_tracer_reset_stats": (c_int, [c_void_p]),
+    "thx_tracer_read_track": (c_int, [c_void_p, POINTER(c_float), c_size_t]),
+    "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
+    "thx_tracer_last_kernel_ms": (c_int, [c_void_p, c_uint32, POINTER(c_float)]),
+    "thx_rng_fill": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_float)]),
+}
+EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
+
+_lib = None
+
+
+def lib_path() -> str:
+    return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtheia_hip.so")
+
+
+def lib() -> C.CDLL:
+    """Loads libtheia_hip.so (once). Raises if it has not been built."""
+    global _lib
+    if _lib is None:
+        path = lib_path()
+        if not os.path.exists(path):
+            raise RuntimeError(
+                f"{path} not found: the HIP extension has not been built. Run "
+                "`make -C theia_amd/csrc` (or __graft_entry__.build()). theia_amd has no CPU fallback."
+            )
+        handle = C.CDLL(path)
+        for name, (res, args) in _PROTOS.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _lib = handle
+    return _lib
+
+
+def check(code: int) -> None:
+    if code != 0:
+        text = lib().thx_last_error()
+        raise ThxError(code, text.decode("utf-8", "replace") if text else "unknown error")

@@ -1,0 +1,299 @@
+"""
+Pipeline protocol the host components are written against: `PipelineStage`
+(ctypes parameter blocks, double buffered for configs 0/1), `SourceCodeMixin`,
+`Pipeline`, `PipelineScheduler`, `runPipeline`.
+
+Restates the contract of `hephaistos.pipeline` as documented by the reference
+(docs/pipeline/pipeline.md:22-92, docs/pipeline/extend.md:216-346): stages expose
+public fields of their blocks as attributes and through get/setParams, names
+starting with `_` are private, `extra` names are python-side properties,
+`_finishParams(i)` runs right before config `i` is committed, `run(i)` returns
+the commands of config `i`, pipeline parameters are addressed as
+``stage__param``. Commands here are callables that enqueue work on the HIP
+stream instead of Vulkan command buffers.
+"""
+from __future__ import annotations
+
+import ctypes
+import threading
+from ctypes import Array, Structure
+from queue import Queue
+from typing import Any, Callable, Iterable
+
+__all__ = ["Command", "PipelineStage", "SourceCodeMixin", "Pipeline", "PipelineScheduler", "runPipeline"]
+
+Command = Callable[[], None]
+
+
+def _to_python(value: Any) -> Any:
+    if isinstance(value, Structure):
+        if isinstance(getattr(type(value), "value", None), property):
+            return value.value
+        if hasattr(value, "__iter__"):
+            return tuple(_to_python(v) for v in value)
+        if hasattr(value, "data") and isinstance(value.data, Array):
+            return tuple(value.data)
+        return value
+    if isinstance(value, Array):
+        return tuple(_to_python(v) for v in value)
+    return value
+
+
+def _assign(struct: Structure, name: str, ftype, value: Any) -> None:
+    if issubclass(ftype, Structure):
+        field = getattr(struct, name)
+        if isinstance(value, ftype):
+            ctypes.memmove(ctypes.addressof(field), ctypes.addressof(value), ctypes.sizeof(ftype))
+        elif isinstance(getattr(ftype, "value", None), property):
+            field.value = int(value)
+        elif hasattr(field, "data") and isinstance(field.data, Array):
+            import numpy as np
+
+            flat = np.asarray(value, dtype=np.float32).reshape(-1)
+            for k in range(len(field.data)):
+                field.data[k] = float(flat[k])
+        else:
+            for (fname, *_), v in zip(ftype._fields_, value):
+                setattr(field, fname, v)
+    elif issubclass(ftype, Array):
+        setattr(struct, name, ftype(*value))
+    else:
+        setattr(struct, name, value)
+
+
+class PipelineStage:
+    """Base of everything that takes part in a pipeline."""
+
+    name = "stage"
+
+    def __init__(self, params: dict[str, type[Structure]] = {}, extra: set[str] = set()) -> None:
+        object.__setattr__(self, "_blocks", {n: t() for n, t in params.items()})
+        object.__setattr__(self, "_configs", [{n: t() for n, t in params.items()} for _ in range(2)])
+        object.__setattr__(self, "_extra", set(extra))
+        fields: dict[str, tuple[str, Any]] = {}
+        for bname, btype in params.items():
+            for fname, ftype, *_ in btype._fields_:
+                fields[fname] = (bname, ftype)
+        object.__setattr__(self, "_fieldmap", fields)
+
+    # attribute access to public fields ------------------------------------
+    def __getattr__(self, name: str):
+        fields = self.__dict__.get("_fieldmap")
+        if fields is not None and name in fields and not name.startswith("_"):
+            return self.getParam(name)
+        raise AttributeError(f"'{type(self).__name__}' object has no attribute '{name}'")
+
+    def __setattr__(self, name: str, value) -> None:
+        fields = self.__dict__.get("_fieldmap")
+        if (fields is not None and name in fields and not name.startswith("_")
+                and not isinstance(getattr(type(self), name, None), property)):
+            self.setParam(name, value)
+        else:
+            object.__setattr__(self, name, value)
+
+    # parameter api --------------------------------------------------------
+    @property
+    def fields(self) -> tuple[str, ...]:
+        return tuple(self._fieldmap.keys())
+
+    def getParam(self, name: str):
+        if name in self._fieldmap:
+            block, _ = self._fieldmap[name]
+            return _to_python(getattr(self._blocks[block], name))
+        if name in self._extra:
+            return getattr(self, name)
+        raise ValueError(f"No parameter with name {name}")
+
+    def setParam(self, name: str, value) -> None:
+        if name in self._fieldmap:
+            block, ftype = self._fieldmap[name]
+            _assign(self._blocks[block], name, ftype, value)
+        elif name in self._extra:
+            setattr(self, name, value)
+        else:
+            raise ValueError(f"No parameter with name {name}")
+
+    def getParams(self) -> dict[str, Any]:
+        out = {n: self.getParam(n) for n in self._fieldmap if not n.startswith("_")}
+        out.update({n: getattr(self, n) for n in self._extra})
+        return out
+
+    def setParams(self, **kwargs) -> None:
+        for name, value in kwargs.items():
+            if name in self._fieldmap or name in self._extra:
+                self.setParam(name, value)
+
+    def _finishParams(self, i: int) -> None:
+        """Hook: called before the local state is committed to config `i`."""
+
+    def update(self, i: int) -> None:
+        self._finishParams(i)
+        for name, block in self._blocks.items():
+            ctypes.memmove(ctypes.addressof(self._configs[i][name]), ctypes.addressof(block), ctypes.sizeof(block))
+
+    def _getParamsBlock(self, name: str, i: int) -> Structure:
+        """The committed parameter block of config `i` (the reference's UBO tensor)."""
+        return self._configs[i][name]
+
+    def _bindParams(self, program, i: int) -> None:
+        """Binds this stage's own blocks; the HIP backend reads them at launch."""
+
+    def bindParams(self, program, i: int) -> None:
+        self._bindParams(program, i)
+
+    def run(self, i: int) -> list[Command]:
+        return []
+
+
+class SourceCodeMixin(PipelineStage):
+    """Components that contribute device code. The HIP backend selects compiled
+    kernel variants by component *type*; `sourceCode` is kept for API parity and
+    names the device implementation."""
+
+    @property
+    def sourceCode(self) -> str:
+        return f"// {type(self).__name__}: implemented in libtheia_hip.so (theia_amd/csrc)\n"
+
+
+class Pipeline:
+    """Ordered stages sharing the double-buffered configs."""
+
+    def __init__(self, stages: Iterable) -> None:
+        named = []
+        used: dict[str, int] = {}
+        for entry in stages:
+            if isinstance(entry, tuple):
+                name, stage = entry
+            else:
+                name, stage = entry.name, entry
+            if name in used:
+                used[name] += 1
+                name = f"{name}{used[name]}"
+            else:
+                used[name] = 1
+            named.append((name, stage))
+        self._stages = named
+        self._byName = dict(named)
+        self._commands = [[cmd for _, st in named for cmd in st.run(i)] for i in range(2)]
+
+    @property
+    def stages(self) -> list[tuple[str, PipelineStage]]:
+        return list(self._stages)
+
+    def getParams(self) -> dict[str, Any]:
+        return {f"{n}__{p}": v for n, st in self._stages for p, v in st.getParams().items()}
+
+    def setParams(self, **params) -> None:
+        grouped: dict[str, dict[str, Any]] = {}
+        for key, value in params.items():
+            stage, sep, param = key.partition("__")
+            if not sep:
+                raise ValueError(f'"{key}" is not of the form stage__param')
+            grouped.setdefault(stage, {})[param] = value
+        for stage, kv in grouped.items():
+            if stage not in self._byName:
+                raise ValueError(f'There is no stage with name "{stage}"')
+            self._byName[stage].setParams(**kv)
+
+    def update(self, i: int) -> None:
+        for _, st in self._stages:
+            st.update(i)
+
+    def run(self, i: int, *, update: bool = True) -> None:
+        if update:
+            self.update(i)
+        for cmd in self._commands[i]:
+            cmd()
+
+
+def runPipeline(stages: Iterable, i: int = 0, *, update: bool = True) -> None:
+    """Creates a throw-away pipeline from the stages and runs config `i` once."""
+    Pipeline([s if isinstance(s, tuple) else (f"stage{k}", s) for k, s in enumerate(stages)]).run(i, update=update)
+
+
+class PipelineScheduler:
+    """Feeds a list of tasks (parameter dicts) through a pipeline, alternating
+    configs 0/1, and calls `processFn(config, batch, args)` after each one. Work
+    runs on a background thread; `wait()` blocks until everything submitted so
+    far has been processed."""
+
+    def __init__(self, pipeline, *, queueSize: int = 0, processFn: Callable[[int, int, Any], None] | None = None) -> None:
+        self._pipelines = pipeline if isinstance(pipeline, dict) else {None: pipeline}
+        self._process = processFn
+        self._queue: Queue = Queue(queueSize)
+        self._total = 0
+        self._finished = 0
+        self._cv = threading.Condition()
+        self._error: BaseException | None = None
+        self._alive = True
+        self._thread = threading.Thread(target=self._worker, name="theia-scheduler", daemon=True)
+        self._thread.start()
+
+    @property
+    def tasksFinished(self) -> int:
+        return self._finished
+
+    @property
+    def totalTasks(self) -> int:
+        return self._total
+
+    @property
+    def tasksScheduled(self) -> int:
+        return self._total - self._finished
+
+    def schedule(self, tasks: Iterable, *, timeout: float | None = None) -> None:
+        for task in tasks:
+            with self._cv:
+                self._total += 1
+            self._queue.put(task, timeout=timeout)
+
+    def wait(self) -> None:
+        with self._cv:
+            self._cv.wait_for(lambda: self._finished >= self._total or self._error is not None)
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def destroy(self) -> None:
+        if self._alive:
+            self._alive = False
+            self._queue.put(None)
+            self._thread.join(timeout=5.0)
+
+    def __del__(self) -> None:
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def _worker(self) -> None:
+        batch = 0
+        while True:
+            task = self._queue.get()
+            if task is None:
+                return
+            try:
+                if self._error is None:
+                    name, params, args = None, task, None
+                    if isinstance(task, tuple):
+                        name, params = task[0], task[1]
+                        args = task[2] if len(task) > 2 else None
+                    if name not in self._pipelines:
+                        if name is None and len(self._pipelines) == 1:
+                            name = next(iter(self._pipelines))
+                        else:
+                            raise ValueError(f"There is no pipeline with name {name}")
+                    pipe = self._pipelines[name]
+                    cfg = batch % 2
+                    if params:
+                        pipe.setParams(**params)
+                    pipe.run(cfg)
+                    if self._process is not None:
+                        self._process(cfg, batch, args)
+                    batch += 1
+            except BaseException as exc:  # surfaced by wait()
+                self._error = exc
+            finally:
+                with self._cv:
+                    self._finished += 1
+                    self._cv.notify_all()

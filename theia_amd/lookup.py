@@ -1,0 +1,111 @@
+"""
+Look-up tables as the kernels read them: an ``int32`` sample count per axis
+followed by the ``float32`` samples (1-D: ``Table1D{int nx; float samples[];}``,
+reference shader/lookup.glsl:4-12, host side src/theia/lookup.py:29-131).
+
+Sampling points are equidistant on the table's range; the kernel interpolates
+linearly (lookup.glsl:14-28).
+"""
+from __future__ import annotations
+
+from typing import Literal
+
+import numpy as np
+
+from . import _backend
+
+__all__ = ["Table", "getTableSize", "uploadTables", "sampleTable1D", "evalTable"]
+
+
+class Table:
+    """Header + samples of one table (1-D or 2-D)."""
+
+    ALIGNMENT = 4
+
+    def __init__(self, data) -> None:
+        self._data = np.ascontiguousarray(data, dtype=np.float32)
+        self._header = np.asarray(self._data.shape, dtype=np.int32)
+
+    @property
+    def data(self) -> np.ndarray:
+        return self._data
+
+    @property
+    def nbytes(self) -> int:
+        return int(self._header.nbytes + self._data.nbytes)
+
+    def tobytes(self) -> bytes:
+        return self._header.tobytes() + self._data.tobytes()
+
+
+def getTableSize(a) -> int:
+    """Bytes a table of the given data/shape occupies on the device (0 for None)."""
+    if a is None:
+        return 0
+    shape = a if isinstance(a, tuple) else np.shape(a)
+    if len(shape) == 0:
+        raise RuntimeError("table cannot have zero shape!")
+    return 4 * (len(shape) + int(np.prod(shape)))
+
+
+class DeviceBlob:
+    """A device allocation that frees itself with its owner."""
+
+    def __init__(self, nbytes: int) -> None:
+        self._be = _backend.get()
+        self.nbytes = int(nbytes)
+        self.address = self._be.alloc(self.nbytes)
+
+    def upload(self, data: bytes) -> None:
+        self._be.upload(self.address, data)
+
+    def __del__(self) -> None:
+        try:
+            if self.address:
+                self._be.free(self.address)
+                self.address = 0
+        except Exception:
+            pass
+
+
+def uploadTables(data: list) -> tuple[DeviceBlob, list[int]]:
+    """Uploads the given arrays as consecutive tables; returns the allocation and
+    the device address of every table (src/theia/lookup.py:101-131)."""
+    tables = [Table(d) for d in data]
+    blob = DeviceBlob(sum(t.nbytes for t in tables))
+    addresses, offset, payload = [], 0, b""
+    for t in tables:
+        addresses.append(blob.address + offset)
+        payload += t.tobytes()
+        offset += t.nbytes
+    blob.upload(payload)
+    return blob, addresses
+
+
+def sampleTable1D(data, nx: int = 1024, *, boundary=None, mode: Literal["linear", "cubic"] = "linear") -> Table:
+    """Resamples (x, f(x)) rows onto `nx` equidistant points."""
+    data = np.asarray(data, dtype=np.float64)
+    lo, hi = (data[:, 0].min(), data[:, 0].max()) if boundary is None else boundary
+    x = np.linspace(lo, hi, nx)
+    if mode == "linear":
+        return Table(np.interp(x, data[:, 0], data[:, 1]))
+    if mode == "cubic":
+        from scipy.interpolate import CubicSpline
+
+        return Table(CubicSpline(data[:, 0], data[:, 1])(x))
+    raise RuntimeError("Unknown interpolation mode!")
+
+
+def evalTable(f, *axes) -> Table:
+    """Samples `f` on a regular grid; each axis is a sample count (range [0,1])
+    or a tuple (min, max, count)."""
+    grids = []
+    for spec in axes:
+        if isinstance(spec, int):
+            grids.append(np.linspace(0.0, 1.0, spec))
+        elif isinstance(spec, tuple) and len(spec) == 3:
+            grids.append(np.linspace(*spec))
+        else:
+            raise RuntimeError(f"Cannot parse dimension: {spec}")
+    mesh = np.meshgrid(*grids, indexing="ij")
+    return Table(f(*mesh))

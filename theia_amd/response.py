@@ -1,0 +1,195 @@
+"""
+Detector responses. The supported path is the time-binned light curve:
+`HistogramHitResponse(UniformValueResponse())` (reference:
+src/theia/response.py:95-188, :440-495, :1065-1421; device side
+shader/response.histogram.glsl, response.uniform.glsl, estimator.reduce.glsl).
+
+On the device every workgroup bins hits into an LDS histogram and flushes it to
+a slab; the reducer Kahan-sums the slabs and applies the normalisation.
+"""
+from __future__ import annotations
+
+from ctypes import Structure, c_float
+from dataclasses import dataclass
+
+import numpy as np
+
+from . import units as u
+from .hp.pipeline import SourceCodeMixin
+
+__all__ = ["TraceConfig", "HitResponse", "EmptyResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse"]
+
+
+@dataclass
+class TraceConfig:
+    """What a tracer tells its response about itself (response.py:95-122)."""
+
+    batchSize: int
+    blockSize: int
+    capacity: int
+    maxHitsPerThread: int = 1
+    normalization: float = 1.0
+    polarized: bool = False
+
+
+class HitResponse(SourceCodeMixin):
+    """Base class of responses consuming the hits a tracer produces."""
+
+    name = "Hit Response"
+
+    def __init__(self, params: dict = {}, extra: set = set(), *, nRNGSamples: int = 0) -> None:
+        super().__init__(params, extra)
+        self._nRNGSamples = nRNGSamples
+
+    @property
+    def nRNGSamples(self) -> int:
+        """random numbers drawn per hit"""
+        return self._nRNGSamples
+
+    def prepare(self, config: TraceConfig) -> None:
+        """Called once by every tracer using this response during its construction."""
+
+    def updateConfig(self, config: TraceConfig) -> None:
+        """Called by the tracer whenever its configuration changes."""
+
+
+class EmptyResponse(HitResponse):
+    """Ignores all hits. Not executable on the HIP backend (no kernel variant)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+
+class ValueResponse(SourceCodeMixin):
+    """Maps a hit to the value that gets accumulated."""
+
+    name = "Value Response"
+
+    def __init__(self, params: dict = {}, extra: set = set(), *, nRNGSamples: int = 0) -> None:
+        super().__init__(params, extra)
+        self._nRNGSamples = nRNGSamples
+
+    @property
+    def nRNGSamples(self) -> int:
+        return self._nRNGSamples
+
+    def prepare(self, config: TraceConfig) -> None:
+        pass
+
+
+class UniformValueResponse(ValueResponse):
+    """Perfect isotropic detector: value = contribution of the hit."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+
+class HistogramHitResponse(HitResponse):
+    """
+    Histogram of hit times weighted by the value response.
+
+    Parameters: `response` (value response), `nBins=100`, `t0=0 ns`, `binSize=1 ns`,
+    `normalization=None` (None: use the tracer's 1/batchSize), `retrieve=True`,
+    `reduceBlockSize=128`, `updateResponse=True`, `useSharedMemory=True`.
+    Stage parameters: `t0`, `binSize`, `normalization`.
+    """
+
+    name = "Histogram Hit Response"
+    MAX_SHARED_MEMORY_BINS = 8192
+
+    class Params(Structure):
+        _fields_ = [("t0", c_float), ("binSize", c_float)]
+
+    def __init__(self, response: ValueResponse, *, nBins: int = 100, t0: float = 0.0 * u.ns, binSize: float = 1.0 * u.ns,
+                 normalization: float | None = None, retrieve: bool = True, reduceBlockSize: int = 128,
+                 updateResponse: bool = True, useSharedMemory: bool = True) -> None:
+        super().__init__({"ResponseParams": self.Params}, {"normalization"}, nRNGSamples=response.nRNGSamples)
+        if not isinstance(response, UniformValueResponse):
+            raise NotImplementedError(
+                "The HIP backend implements HistogramHitResponse(UniformValueResponse()); "
+                f"{type(response).__name__} has no compiled kernel variant (GLSL injection is not supported)")
+        if nBins > self.MAX_SHARED_MEMORY_BINS:
+            raise NotImplementedError(f"nBins > {self.MAX_SHARED_MEMORY_BINS} does not fit the LDS histogram")
+        self._response = response
+        self.setParams(t0=t0, binSize=binSize)
+        self._nBins = nBins
+        self._normalization = normalization
+        self._requestedNorm = 1.0
+        self._retrieve = retrieve
+        self._reduceBlockSize = reduceBlockSize
+        self._updateResponse = updateResponse
+        self._useSharedMemory = useSharedMemory
+        self._nHistMax = 0
+        self._program = None  # set by the tracer (bindParams)
+        self._norm = [1.0, 1.0]
+        self._buffer = [np.zeros(nBins, dtype=np.float32) for _ in range(2)]
+        self._prepared = False
+
+    @property
+    def nBins(self) -> int:
+        return self._nBins
+
+    @property
+    def normalization(self) -> float | None:
+        return self._normalization
+
+    @normalization.setter
+    def normalization(self, value: float | None) -> None:
+        self._normalization = value
+
+    @property
+    def reduceBlockSize(self) -> int:
+        return self._reduceBlockSize
+
+    @property
+    def response(self) -> ValueResponse:
+        return self._response
+
+    @property
+    def retrieve(self) -> bool:
+        return self._retrieve
+
+    @property
+    def useSharedMemory(self) -> bool:
+        return self._useSharedMemory
+
+    def result(self, i: int) -> np.ndarray | None:
+        """Histogram of the most recent batch run with config `i` (valid until
+        that config runs again)."""
+        if not self._prepared or not self._retrieve:
+            return None
+        return self._buffer[i]
+
+    def prepare(self, config: TraceConfig) -> None:
+        self._response.prepare(config)
+        self._requestedNorm = config.normalization
+        self._nHistMax = max(self._nHistMax, -(config.capacity // -config.blockSize))
+        self._prepared = True
+
+    def updateConfig(self, config: TraceConfig) -> None:
+        self._requestedNorm = config.normalization
+
+    def _bindParams(self, program, i: int) -> None:
+        super()._bindParams(program, i)
+        self._response.bindParams(program, i)
+        self._program = program
+
+    def update(self, i: int) -> None:
+        super().update(i)
+        self._norm[i] = self._normalization if self._normalization is not None else self._requestedNorm
+        if self._updateResponse:
+            self._response.update(i)
+
+    def run(self, i: int):
+        if not self._prepared:
+            raise RuntimeError("Response has not been prepared")
+
+        def reduce() -> None:
+            if self._program is None:
+                raise RuntimeError("HistogramHitResponse is not bound to a tracer")
+            self._program.reduce(i, self._norm[i])
+
+        def retrieve() -> None:
+            self._buffer[i][...] = self._program.read_hist(i)
+
+        return [reduce, retrieve] if self._retrieve else [reduce]

@@ -1,0 +1,564 @@
+"""
+Forward tracers: `VolumeForwardTracer` and `SceneForwardTracer`, the event
+callbacks and result codes (reference: src/theia/trace.py:48-187 callbacks,
+:308-343 codes, :346-497 Tracer, :499-771 volume, :1048-1337 scene).
+
+Constructor signatures, defaults, stage parameters, `nRNGSamples` /
+`maxHitsPerThread` / `normalization` formulas and `collectStages()` order are
+the reference's. Where the reference compiles GLSL with the components'
+source injected, this backend maps the *types* of the components to a compiled
+kernel variant of libtheia_hip.so and raises `NotImplementedError` for anything
+outside the supported closed set.
+"""
+from __future__ import annotations
+
+from abc import abstractmethod
+from ctypes import Structure, c_float, c_int32, c_uint32
+from enum import IntEnum
+
+import numpy as np
+
+from . import _backend
+from . import _capi as capi
+from . import units as u
+from .hp.glsl import buffer_reference, vec3
+from .hp.pipeline import PipelineStage, SourceCodeMixin
+from .light import ConstWavelengthSource, LightSource, SphericalLightSource, UniformWavelengthSource, WavelengthSource
+from .random import RNG, PhiloxRNG
+from .response import HistogramHitResponse, HitResponse, TraceConfig
+from .scene import RectBBox, Scene
+from .target import SphereTarget, SphereTargetGuide, Target, TargetGuide
+
+__all__ = [
+    "EmptyEventCallback", "EventResultCode", "EventStatisticCallback", "SceneForwardTracer", "Tracer",
+    "TraceEventCallback", "VolumeForwardTracer",
+]
+
+
+class TraceEventCallback(SourceCodeMixin):
+    """Base of callbacks invoked on tracing events (`onEvent(ray, code, idx, i)`)."""
+
+    name = "Trace Event Callback"
+
+    def __init__(self, *, params: dict = {}, extra: set = set()) -> None:
+        super().__init__(params, extra)
+
+
+class EmptyEventCallback(TraceEventCallback):
+    """Ignores all events (the production kernels carry no callback code)."""
+
+    def __init__(self) -> None:
+        super().__init__()
+
+
+class EventStatisticCallback(TraceEventCallback):
+    """
+    Counts events by type in device counters (reference: trace.py:77-187,
+    shader/callback.stat.glsl). Selects the instrumented kernel variant, which
+    also counts BVH work (`traversal` property) used for the roofline figures.
+    """
+
+    name = "Event Statistic"
+    _FIELDS = ("created", "scattered", "hit", "detected", "volume", "lost", "decayed", "absorbed", "missed", "maxIter", "error", "mismatch")
+
+    def __init__(self) -> None:
+        super().__init__()
+        self._program = None
+        self._cache = np.zeros(capi.N_STATS, dtype=np.uint64)
+
+    def _bindParams(self, program, i: int) -> None:
+        self._program = program
+
+    def _read(self) -> np.ndarray:
+        if self._program is not None and self._program.created:
+            self._cache = self._program.read_stats()
+        return self._cache
+
+    def reset(self) -> None:
+        if self._program is not None and self._program.created:
+            self._program.reset_stats()
+        self._cache = np.zeros(capi.N_STATS, dtype=np.uint64)
+
+    @property
+    def traversal(self) -> dict[str, int]:
+        """queries, nodes, triangles, instances, hits, lut_reads, responses, steps"""
+        s = self._read()
+        return {n: int(s[12 + k]) for k, n in enumerate(capi.STAT_NAMES[12:])}
+
+    def __str__(self) -> str:
+        s = self._read()
+        names = sorted(self._FIELDS)
+        just = max(len(f) for f in names)
+        return "\n".join(f"{f.rjust(just)}: {int(s[self._FIELDS.index(f)]):,}" for f in names)
+
+
+def _stat_property(slot: int, doc: str):
+    return property(lambda self: int(self._read()[slot]), doc=doc)
+
+
+for _k, _n in enumerate(EventStatisticCallback._FIELDS):
+    setattr(EventStatisticCallback, _n, _stat_property(_k, f"number of '{_n}' events"))
+
+
+class EventResultCode(IntEnum):
+    """Result codes passed to event callbacks; negative codes stop the photon
+    (shader/result.glsl:10-28)."""
+
+    SUCCESS = 0
+    RAY_CREATED = 1
+    RAY_SCATTERED = 2
+    RAY_HIT = 3
+    RAY_DETECTED = 4
+    VOLUME_HIT = 5
+    RAY_LOST = -1
+    RAY_DECAYED = -2
+    RAY_ABSORBED = -3
+    RAY_MISSED = -4
+    MAX_ITER = -5
+    ERROR_CODE_MAX_VALUE = -10
+    ERROR_UNKNOWN = -10
+    ERROR_MEDIA_MISMATCH = -11
+    ERROR_TRACE_ABORT = -12
+    ERROR_RAY_BAD = -13
+
+
+class _Program:
+    """The compiled-variant handle a tracer owns (stands where hp.Program stood).
+    Created lazily so that building stages does not need a device."""
+
+    def __init__(self, spec: _backend.TracerSpec, scene: Scene | None) -> None:
+        self._spec = spec
+        self._scene = scene
+        self._handle = None
+        self._be = None
+
+    @property
+    def created(self) -> bool:
+        return self._handle is not None
+
+    @property
+    def handle(self) -> int:
+        if self._handle is None:
+            self._be = _backend.get()
+            self._handle = self._be.tracer_create(self._spec, self._scene.handle if self._scene is not None else None)
+        return self._handle
+
+    @property
+    def backend(self):
+        self.handle
+        return self._be
+
+    def run(self, cfg: int, params: capi.RunParams) -> None:
+        self.backend.tracer_run(self.handle, cfg, params)
+
+    def reduce(self, cfg: int, norm: float, d_out: int = 0) -> None:
+        self.backend.tracer_reduce(self.handle, cfg, norm, d_out)
+
+    def read_hist(self, cfg: int) -> np.ndarray:
+        return self.backend.tracer_read_hist(self.handle, cfg, self._spec.n_bins)
+
+    def hist_ptr(self, cfg: int) -> int:
+        return self.backend.tracer_hist_ptr(self.handle, cfg)
+
+    def read_stats(self) -> np.ndarray:
+        return self.backend.tracer_read_stats(self.handle)
+
+    def reset_stats(self) -> None:
+        self.backend.tracer_reset_stats(self.handle)
+
+    def read_track(self, batch: int) -> np.ndarray:
+        return self.backend.tracer_read_track(self.handle, batch, self._spec.path_length + 3)
+
+    def launch_info(self, batch: int) -> dict:
+        return self.backend.tracer_launch_info(self.handle, batch)
+
+    def last_kernel_ms(self, cfg: int) -> float:
+        return self.backend.tracer_last_kernel_ms(self.handle, cfg)
+
+    def __del__(self) -> None:
+        try:
+            if self._handle is not None:
+                self._be.tracer_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass
+
+
+def _unsupported(role: str, obj, supported: str):
+    return NotImplementedError(
+        f"{type(obj).__name__} is not supported as {role} by the HIP backend (supported: {supported}). "
+        "Components are mapped to compiled kernel variants; custom GLSL cannot be injected.")
+
+
+class Tracer(PipelineStage):
+    """Base of tracing algorithms turning light samples into detector responses."""
+
+    name = "Tracer"
+
+    class DispatchParams(Structure):
+        _fields_ = [("_batchSize", c_uint32), ("_groupCountX", c_uint32), ("_groupCountY", c_uint32), ("_groupCountZ", c_uint32)]
+
+    def __init__(self, response: HitResponse, params: dict = {}, extra: set = set(), *, batchSize: int, blockSize: int,
+                 capacity: int | None, nRNGSamples: int, maxHitsPerThread: int, polarized: bool = False) -> None:
+        params = {**params, "DispatchParams": self.DispatchParams}
+        extra = {*extra, "batchSize", "photonOffset"}
+        super().__init__(params, extra)
+        self._blockSize = blockSize
+        self._capacity = batchSize if capacity is None else capacity
+        self._response = response
+        self._maxHitsPerThread = maxHitsPerThread
+        self._nRNGSamples = nRNGSamples
+        self._polarized = polarized
+        self._photonOffset = 0
+        self._program: _Program | None = None
+        self.setParams(batchSize=batchSize, _groupCountY=1, _groupCountZ=1)
+        response.prepare(self._getTraceConfig())
+
+    @property
+    def batchSize(self) -> int:
+        """photons per run"""
+        return self.getParam("_batchSize")
+
+    @batchSize.setter
+    def batchSize(self, value: int) -> None:
+        if value < 0:
+            raise ValueError("batchSize must be at least zero!")
+        if value > self.capacity:
+            raise ValueError("batchSize cannot be larger than capacity!")
+        groups = max(-(value // -self.blockSize), 1)
+        self.setParams(_batchSize=value, _groupCountX=groups)
+
+    @property
+    def photonOffset(self) -> int:
+        """Index (= RNG stream) of the first photon of a batch. Extension of this
+        backend used to shard one logical batch over several GPUs."""
+        return self._photonOffset
+
+    @photonOffset.setter
+    def photonOffset(self, value: int) -> None:
+        self._photonOffset = int(value)
+
+    @property
+    def blockSize(self) -> int:
+        return self._blockSize
+
+    @property
+    def capacity(self) -> int:
+        return self._capacity
+
+    @property
+    def maxHits(self) -> int:
+        return self.maxHitsPerThread * self.batchSize
+
+    @property
+    def maxHitsPerThread(self) -> int:
+        return self._maxHitsPerThread
+
+    @property
+    def normalization(self) -> float:
+        """factor turning accumulated contributions into an estimate"""
+        return 1.0 / self.batchSize
+
+    @property
+    def nRNGSamples(self) -> int:
+        """random numbers budgeted per photon (use as `rng.autoAdvance`)"""
+        return self._nRNGSamples
+
+    @property
+    def polarized(self) -> bool:
+        return self._polarized
+
+    @property
+    def response(self) -> HitResponse:
+        return self._response
+
+    @property
+    def program(self) -> _Program:
+        return self._program
+
+    def collectStages(self, *, useOriginalNames: bool = False) -> list[tuple[str, PipelineStage]]:
+        """All stages of this tracer in pipeline order."""
+        stages = self._collectStages()
+        if useOriginalNames:
+            return [(s.name, s) for _, s in stages]
+        return stages
+
+    @abstractmethod
+    def _collectStages(self) -> list[tuple[str, PipelineStage]]:
+        ...
+
+    def _getTraceConfig(self) -> TraceConfig:
+        return TraceConfig(self.batchSize, self.blockSize, self.capacity, self.maxHitsPerThread, self.normalization, self.polarized)
+
+    def _finishParams(self, i: int) -> None:
+        super()._finishParams(i)
+        self.response.updateConfig(self._getTraceConfig())
+        self._offsets = getattr(self, "_offsets", [0, 0])
+        self._offsets[i] = self._photonOffset
+
+    # ---- component -> parameter block translation -------------------------
+    def _commonParams(self, i: int, rng, source, wavelength, response) -> capi.RunParams:
+        P = capi.RunParams()
+        d = self._getParamsBlock("DispatchParams", i)
+        P.dispatch.batchSize = d._batchSize
+        P.dispatch.groupCountX, P.dispatch.groupCountY, P.dispatch.groupCountZ = d._groupCountX, d._groupCountY, d._groupCountZ
+        P.photon_offset = getattr(self, "_offsets", [0, 0])[i] & 0xFFFFFFFF
+        r = rng._getParamsBlock("PhiloxParams", i)
+        P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
+        for k in range(4):
+            P.philox.offset[k] = r.offset.word[k]
+        l = source._getParamsBlock("LightParams", i)
+        P.light.position[0], P.light.position[1], P.light.position[2] = l.position.x, l.position.y, l.position.z
+        P.light.contribFwd, P.light.contribBwd = l._contribFwd, l._contribBwd
+        P.light.t_min, P.light.t_max = l.timeRange.x, l.timeRange.y
+        w = wavelength._getParamsBlock("WavelengthParams", i)
+        if isinstance(wavelength, UniformWavelengthSource):
+            P.wavelength.p0, P.wavelength.p1, P.wavelength.p2 = w.lambdaRange.x, w.lambdaRange.y, w._contrib
+        else:
+            P.wavelength.p0 = w.wavelength
+        rp = response._getParamsBlock("ResponseParams", i)
+        P.response.t0, P.response.binSize = rp.t0, rp.binSize
+        return P
+
+    @staticmethod
+    def _fillPropagation(dst, block, lower: str, upper: str) -> None:
+        dst.scatterCoefficient = block.scatterCoefficient
+        lo, hi = getattr(block, lower), getattr(block, upper)
+        for k, c in enumerate("xyz"):
+            dst.lowerBBoxCorner[k] = getattr(lo, c)
+            dst.upperBBoxCorner[k] = getattr(hi, c)
+        dst.maxTime = block.maxTime
+        dst.maxDist = block._maxDist
+
+    @staticmethod
+    def _checkComponents(source, wavelength, response, rng, callback) -> None:
+        if not isinstance(source, SphericalLightSource):
+            raise _unsupported("light source", source, "SphericalLightSource")
+        if not isinstance(wavelength, (ConstWavelengthSource, UniformWavelengthSource)):
+            raise _unsupported("wavelength source", wavelength, "ConstWavelengthSource, UniformWavelengthSource")
+        if not isinstance(response, HistogramHitResponse):
+            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse())")
+        if not isinstance(rng, PhiloxRNG):
+            raise _unsupported("random number generator", rng, "PhiloxRNG")
+        if not isinstance(callback, (EmptyEventCallback, EventStatisticCallback)):
+            raise _unsupported("event callback", callback, "EmptyEventCallback, EventStatisticCallback")
+
+
+class VolumeForwardTracer(Tracer):
+    """
+    Path tracer for a homogeneous medium with an analytic (sphere) detector; no
+    scene intersection. Parameters and stage parameters as in the reference
+    (trace.py:499-771): `batchSize, source, target, wavelengthSource, response,
+    rng, *, medium, objectId=0, capacity=None, callback=EmptyEventCallback(),
+    nScattering=6, scatterCoefficient=NaN, traceBBox=(+-1 km), maxTime=1000 ns,
+    polarized=False, disableDirectLighting=False, disableTargetSampling=False,
+    blockSize=128, code=None`. `trackEvents=True` (extension) records every
+    event for parity probes.
+    """
+
+    name = "Volume Forward Tracer"
+
+    class TraceParams(Structure):
+        _fields_ = [
+            ("medium", buffer_reference), ("objectId", c_int32), ("scatterCoefficient", c_float),
+            ("lowerBBoxCorner", vec3), ("upperBBoxCorner", vec3), ("maxTime", c_float), ("_maxDist", c_float),
+        ]
+
+    def __init__(self, batchSize: int, source: LightSource, target: Target, wavelengthSource: WavelengthSource,
+                 response: HitResponse, rng: RNG, *, medium: int, objectId: int = 0, capacity: int | None = None,
+                 callback: TraceEventCallback | None = None, nScattering: int = 6,
+                 scatterCoefficient: float = float("NaN"),
+                 traceBBox: RectBBox | None = None, maxTime: float = 1000.0 * u.ns, polarized: bool = False,
+                 disableDirectLighting: bool = False, disableTargetSampling: bool = False, blockSize: int = 128,
+                 code: bytes | None = None, trackEvents: bool = False) -> None:
+        if callback is None:
+            callback = EmptyEventCallback()
+        if traceBBox is None:
+            traceBBox = RectBBox((-1.0 * u.km,) * 3, (1.0 * u.km,) * 3)
+        self._checkComponents(source, wavelengthSource, response, rng, callback)
+        if not isinstance(target, SphereTarget):
+            raise _unsupported("target", target, "SphereTarget")
+        # hits: one per scatter (+ one MIS sample each) + the direct one
+        maxHitsPerThread = nScattering
+        if not disableTargetSampling:
+            maxHitsPerThread *= 2
+        if not disableDirectLighting:
+            maxHitsPerThread += 1
+        # with MIS the last scatter happens inside the MIS step -> one trace less
+        pathLength = nScattering if disableTargetSampling else nScattering - 1
+        rngStride = 3 if disableTargetSampling else 7
+        nRNG = source.nRNGForward + wavelengthSource.nRNGSamples
+        nRNG += rngStride * pathLength
+        nRNG += maxHitsPerThread * response.nRNGSamples
+        super().__init__(response, {"TraceParams": self.TraceParams}, batchSize=batchSize, blockSize=blockSize,
+                         capacity=capacity, nRNGSamples=nRNG, maxHitsPerThread=maxHitsPerThread, polarized=polarized)
+        self._source, self._wavelengthSource, self._rng = source, wavelengthSource, rng
+        self._target, self._callback = target, callback
+        self._nScattering = nScattering
+        self._directLightingDisabled = disableDirectLighting
+        self._targetSamplingDisabled = disableTargetSampling
+        self.setParams(scatterCoefficient=scatterCoefficient, medium=medium, objectId=objectId,
+                       lowerBBoxCorner=traceBBox.lowerCorner, upperBBoxCorner=traceBBox.upperCorner,
+                       maxTime=maxTime, _maxDist=traceBBox.diagonal)
+        flags = 0
+        flags |= capi.FLAG_POLARIZED if polarized else 0
+        flags |= capi.FLAG_DISABLE_DIRECT if disableDirectLighting else 0
+        flags |= capi.FLAG_DISABLE_MIS if disableTargetSampling else 0
+        flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
+        flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
+        flags |= capi.FLAG_TRACK if trackEvents else 0
+        self._code = b"" if code is None else code
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, response.nBins, self.capacity), None)
+
+    callback = property(lambda self: self._callback, doc="callback called for each tracing event")
+    code = property(lambda self: self._code, doc="kept for API parity; kernels are precompiled")
+    directLightingDisabled = property(lambda self: self._directLightingDisabled)
+    nScattering = property(lambda self: self._nScattering)
+    rng = property(lambda self: self._rng)
+    source = property(lambda self: self._source)
+    target = property(lambda self: self._target)
+    targetSamplingDisabled = property(lambda self: self._targetSamplingDisabled)
+    wavelengthSource = property(lambda self: self._wavelengthSource)
+
+    @property
+    def traceBBox(self) -> RectBBox:
+        return RectBBox(self.getParam("lowerBBoxCorner"), self.getParam("upperBBoxCorner"))
+
+    @traceBBox.setter
+    def traceBBox(self, value: RectBBox) -> None:
+        self.setParams(lowerBBoxCorner=value.lowerCorner, upperBBoxCorner=value.upperCorner, _maxDist=value.diagonal)
+
+    def _collectStages(self):
+        return [("rng", self.rng), ("photons", self.wavelengthSource), ("lightSource", self.source),
+                ("target", self.target), ("tracer", self), ("callback", self.callback), ("response", self.response)]
+
+    def _finishParams(self, i: int) -> None:
+        super()._finishParams(i)
+        self.setParam("_maxDist", self.traceBBox.diagonal)
+
+    def _assemble(self, i: int) -> capi.RunParams:
+        P = self._commonParams(i, self._rng, self._source, self._wavelengthSource, self._response)
+        t = self._getParamsBlock("TraceParams", i)
+        P.volume.medium[0], P.volume.medium[1] = t.medium.lo, t.medium.hi
+        P.volume.objectId = t.objectId
+        self._fillPropagation(P.volume.propagation, t, "lowerBBoxCorner", "upperBBoxCorner")
+        g = self._target._getParamsBlock("TargetParams", i)
+        for k, c in enumerate("xyz"):
+            P.target.position[k] = getattr(g.position, c)
+            P.target.invPos[k] = getattr(g._invPos, c)
+        P.target.radius, P.target.invRad, P.target.hemisphereProb = g.radius, g._invRad, g._hemisphereProb
+        return P
+
+    def run(self, i: int):
+        self.callback.bindParams(self._program, i)
+        self.response.bindParams(self._program, i)
+        return [lambda: self._program.run(i, self._assemble(i))]
+
+
+class SceneForwardTracer(Tracer):
+    """
+    Path tracer against a triangle-mesh scene with surface reflection /
+    transmission and optional next-event estimation through a target guide.
+    Parameters and stage parameters as in the reference (trace.py:1048-1337):
+    `batchSize, source, wavelengthSource, response, rng, scene, *, capacity=None,
+    callback=EmptyEventCallback(), maxPathLength=6, targetId=-1, targetGuide=None,
+    scatterCoefficient=NaN, sourceMedium=None, maxTime=1000 ns, polarized=False,
+    disableDirectLighting=False, disableTransmission=False,
+    disableVolumeBorder=False, useRefractedHitDir=False, blockSize=128, code=None`.
+    """
+
+    name = "Scene Forward Tracer"
+
+    class TraceParams(Structure):
+        _fields_ = [
+            ("targetId", c_int32), ("sourceMedium", buffer_reference), ("scatterCoefficient", c_float),
+            ("_lowerBBoxCorner", vec3), ("_upperBBoxCorner", vec3), ("maxTime", c_float), ("_maxDist", c_float),
+        ]
+
+    def __init__(self, batchSize: int, source: LightSource, wavelengthSource: WavelengthSource, response: HitResponse,
+                 rng: RNG, scene: Scene, *, capacity: int | None = None, callback: TraceEventCallback | None = None,
+                 maxPathLength: int = 6, targetId: int = -1, targetGuide: TargetGuide | None = None,
+                 scatterCoefficient: float = float("NaN"), sourceMedium: int | None = None,
+                 maxTime: float = 1000.0 * u.ns, polarized: bool = False, disableDirectLighting: bool = False,
+                 disableTransmission: bool = False, disableVolumeBorder: bool = False,
+                 useRefractedHitDir: bool = False, blockSize: int = 128, code: bytes | None = None,
+                 trackEvents: bool = False) -> None:
+        if callback is None:
+            callback = EmptyEventCallback()
+        self._checkComponents(source, wavelengthSource, response, rng, callback)
+        if targetGuide is not None and not isinstance(targetGuide, SphereTargetGuide):
+            raise _unsupported("target guide", targetGuide, "SphereTargetGuide, None")
+        maxHits = maxPathLength - 1
+        rngStride = 4
+        if targetGuide is not None:
+            maxHits *= 2
+            rngStride += targetGuide.nRNGSamples
+        if not disableDirectLighting:
+            maxHits += 1
+        nRNG = source.nRNGForward + wavelengthSource.nRNGSamples
+        nRNG += rngStride * maxPathLength
+        nRNG += maxHits * response.nRNGSamples
+        super().__init__(response, {"TraceParams": self.TraceParams}, batchSize=batchSize, blockSize=blockSize,
+                         capacity=capacity, maxHitsPerThread=maxHits, nRNGSamples=nRNG, polarized=polarized)
+        if sourceMedium is None:
+            sourceMedium = scene.medium
+        self._source, self._wavelengthSource, self._callback, self._rng = source, wavelengthSource, callback, rng
+        self._scene, self._targetGuide = scene, targetGuide
+        self._maxPathLength = maxPathLength
+        self._directLightingDisabled = disableDirectLighting
+        self._transmissionDisabled = disableTransmission
+        self._volumeBorderDisabled = disableVolumeBorder
+        self._useRefractedHitDir = useRefractedHitDir
+        self.setParams(targetId=targetId, scatterCoefficient=scatterCoefficient, sourceMedium=sourceMedium, maxTime=maxTime,
+                       _lowerBBoxCorner=scene.bbox.lowerCorner, _upperBBoxCorner=scene.bbox.upperCorner,
+                       _maxDist=scene.bbox.diagonal)
+        flags = 0
+        flags |= capi.FLAG_POLARIZED if polarized else 0
+        flags |= capi.FLAG_DISABLE_DIRECT if disableDirectLighting else 0
+        flags |= capi.FLAG_DISABLE_MIS if targetGuide is None else 0
+        flags |= capi.FLAG_DISABLE_TRANSMISSION if disableTransmission else 0
+        flags |= capi.FLAG_DISABLE_VOLUME_BORDER if disableVolumeBorder else 0
+        flags |= capi.FLAG_HIT_USE_TRANSMITTED if useRefractedHitDir else 0
+        flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
+        flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
+        flags |= capi.FLAG_TRACK if trackEvents else 0
+        self._code = b"" if code is None else code
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, response.nBins, self.capacity), scene)
+
+    callback = property(lambda self: self._callback)
+    code = property(lambda self: self._code)
+    directLightingDisabled = property(lambda self: self._directLightingDisabled)
+    hitsUseRefractedDir = property(lambda self: self._useRefractedHitDir)
+    maxPathLength = property(lambda self: self._maxPathLength)
+    rng = property(lambda self: self._rng)
+    scene = property(lambda self: self._scene)
+    source = property(lambda self: self._source)
+    targetGuide = property(lambda self: self._targetGuide)
+    transmissionDisabled = property(lambda self: self._transmissionDisabled)
+    volumeBorderDisabled = property(lambda self: self._volumeBorderDisabled)
+    wavelengthSource = property(lambda self: self._wavelengthSource)
+
+    def _collectStages(self):
+        stages = [("rng", self.rng), ("photons", self.wavelengthSource), ("lightSource", self.source)]
+        if self.targetGuide is not None:
+            stages.append(("guide", self.targetGuide))
+        stages += [("tracer", self), ("callback", self.callback), ("response", self.response)]
+        return stages
+
+    def _assemble(self, i: int) -> capi.RunParams:
+        P = self._commonParams(i, self._rng, self._source, self._wavelengthSource, self._response)
+        t = self._getParamsBlock("TraceParams", i)
+        P.scene.targetId = t.targetId
+        P.scene.sceneMedium[0], P.scene.sceneMedium[1] = t.sourceMedium.lo, t.sourceMedium.hi
+        self._fillPropagation(P.scene.propagation, t, "_lowerBBoxCorner", "_upperBBoxCorner")
+        if self._targetGuide is not None:
+            g = self._targetGuide._getParamsBlock("TargetGuideParams", i)
+            for k, c in enumerate("xyz"):
+                P.guide.position[k] = getattr(g.position, c)
+            P.guide.radius, P.guide.prob = g.radius, g._prob
+        return P
+
+    def run(self, i: int):
+        self.callback.bindParams(self._program, i)
+        self.response.bindParams(self._program, i)
+        return [lambda: self._program.run(i, self._assemble(i))]
