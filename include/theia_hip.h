@@ -231,6 +231,9 @@ int thx_tracer_launch_info(thx_tracer* tracer, uint32_t batch, uint32_t* grid, u
 /* timing of the most recent thx_tracer_run on cfg, measured with HIP events on
  * the launch stream (ms); synchronises */
 int thx_tracer_last_kernel_ms(thx_tracer* tracer, uint32_t cfg, float* ms);
+/* durations (ms) of the last min(n, 64) tracing-kernel launches, oldest first; every
+ * launch is bracketed by a HIP event pair on its launch stream; synchronises */
+int thx_tracer_kernel_times(thx_tracer* tracer, float* ms_out, uint32_t n, uint32_t* n_written);
 
 /* ---- RNG probe (replaces RNGBufferSink, random.py:44-226): out[stream][sample]
  * = raw uint32 behind random(base_stream+stream, first_dim+sample) ---- */

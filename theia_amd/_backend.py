@@ -174,6 +174,13 @@ class HipBackend:
         capi.check(self._lib.thx_tracer_last_kernel_ms(C.c_void_p(tracer), int(cfg), C.byref(ms)))
         return float(ms.value)
 
+    def tracer_kernel_times(self, tracer: int, n: int = 64) -> np.ndarray:
+        """durations (ms) of the last min(n, 64) tracing-kernel launches, oldest first"""
+        out = np.zeros(int(n), dtype=np.float32)
+        got = C.c_uint32()
+        capi.check(self._lib.thx_tracer_kernel_times(C.c_void_p(tracer), out.ctypes.data_as(C.POINTER(C.c_float)), int(n), C.byref(got)))
+        return out[: got.value]
+
     # -- rng probe ---------------------------------------------------------
     def rng_fill(self, key: int, offset: int, base_stream: int, n_streams: int, first_dim: int, n_samples: int):
         p = capi.PhiloxParams()

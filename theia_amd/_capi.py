@@ -160,6 +160,7 @@ _PROTOS = {
     "thx_tracer_read_track": (c_int, [c_void_p, POINTER(c_float), c_size_t]),
     "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "thx_tracer_last_kernel_ms": (c_int, [c_void_p, c_uint32, POINTER(c_float)]),
+    "thx_tracer_kernel_times": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_uint32)]),
     "thx_rng_fill": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_float)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())

@@ -67,8 +67,11 @@ struct thx_tracer {
     float* track = nullptr;
     uint32_t trackEvents = 0;
     uint32_t lastBatch = 0;
-    hipEvent_t evStart[2] = {nullptr, nullptr}, evStop[2] = {nullptr, nullptr};
-    bool timed[2] = {false, false};
+    // ring of HIP event pairs bracketing the tracing kernel on its launch stream
+    static constexpr uint32_t kRing = 64;
+    hipEvent_t evStart[kRing] = {}, evStop[kRing] = {};
+    uint64_t launches = 0;       // total launches so far
+    int lastSlot[2] = {-1, -1};  // ring slot of the most recent launch per config
 };
 
 extern "C" {
@@ -316,7 +319,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (e == hipSuccess) e = hipMemset(t->slabs[i], 0, slabBytes);
         if (e == hipSuccess) e = hipMalloc((void**)&t->out[i], sizeof(float) * desc->n_bins);
         if (e == hipSuccess) e = hipMemset(t->out[i], 0, sizeof(float) * desc->n_bins);
-        if (e == hipSuccess) e = hipEventCreate(&t->evStart[i]);
+    }
+    for (uint32_t i = 0; i < thx_tracer::kRing && e == hipSuccess; ++i) {
+        e = hipEventCreate(&t->evStart[i]);
         if (e == hipSuccess) e = hipEventCreate(&t->evStop[i]);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
@@ -339,6 +344,8 @@ int thx_tracer_destroy(thx_tracer* t) {
     for (int i = 0; i < 2; ++i) {
         if (t->slabs[i]) hipFree(t->slabs[i]);
         if (t->out[i]) hipFree(t->out[i]);
+    }
+    for (uint32_t i = 0; i < thx_tracer::kRing; ++i) {
         if (t->evStart[i]) hipEventDestroy(t->evStart[i]);
         if (t->evStop[i]) hipEventDestroy(t->evStop[i]);
     }
@@ -395,10 +402,12 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.photons_per_wave = ppw;
     t->lastGrid[cfg] = grid;
     t->lastBatch = batch;
-    THX_HIP(hipEventRecord(t->evStart[cfg], s));
+    const uint32_t slot = (uint32_t)(t->launches % thx_tracer::kRing);
+    THX_HIP(hipEventRecord(t->evStart[slot], s));
     THX_HIP(t->variant.launch(t->debug, a, grid, t->block, t->lds, s));
-    THX_HIP(hipEventRecord(t->evStop[cfg], s));
-    t->timed[cfg] = true;
+    THX_HIP(hipEventRecord(t->evStop[slot], s));
+    t->lastSlot[cfg] = (int)slot;
+    t->launches += 1;
     return THX_OK;
 }
 
@@ -458,10 +467,24 @@ int thx_tracer_read_track(thx_tracer* t, float* out, size_t n_floats) {
 
 int thx_tracer_last_kernel_ms(thx_tracer* t, uint32_t cfg, float* ms) {
     if (!t || !ms || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
-    if (!t->timed[cfg]) return fail(THX_ERR_INVALID, "no launch recorded for this config");
+    if (t->lastSlot[cfg] < 0) return fail(THX_ERR_INVALID, "no launch recorded for this config");
     THX_HIP(hipSetDevice(t->ctx->device));
-    THX_HIP(hipEventSynchronize(t->evStop[cfg]));
-    THX_HIP(hipEventElapsedTime(ms, t->evStart[cfg], t->evStop[cfg]));
+    THX_HIP(hipEventSynchronize(t->evStop[t->lastSlot[cfg]]));
+    THX_HIP(hipEventElapsedTime(ms, t->evStart[t->lastSlot[cfg]], t->evStop[t->lastSlot[cfg]]));
+    return THX_OK;
+}
+
+int thx_tracer_kernel_times(thx_tracer* t, float* ms_out, uint32_t n, uint32_t* n_written) {
+    if (!t || !ms_out || !n_written) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    uint64_t have = std::min<uint64_t>(t->launches, thx_tracer::kRing);
+    uint32_t take = (uint32_t)std::min<uint64_t>(have, n);
+    for (uint32_t k = 0; k < take; ++k) { // oldest of the requested first
+        uint32_t slot = (uint32_t)((t->launches - take + k) % thx_tracer::kRing);
+        THX_HIP(hipEventSynchronize(t->evStop[slot]));
+        THX_HIP(hipEventElapsedTime(&ms_out[k], t->evStart[slot], t->evStop[slot]));
+    }
+    *n_written = take;
     return THX_OK;
 }
 

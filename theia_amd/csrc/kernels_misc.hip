@@ -23,29 +23,41 @@ const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis) {
     return table[(kind & 1u) * 4 + (pol ? 2 : 0) + (mis ? 1 : 0)];
 }
 
-// estimator.reduce.glsl:17-35: out[b] = norm * KahanSum_h slab[h][b]. One thread
-// per bin; for a fixed h the wave reads consecutive floats (coalesced).
+// estimator.reduce.glsl:17-35: out[b] = norm * sum_h slab[h][b] with compensated
+// (Kahan) summation. The reference walks the slabs with one thread per bin; with
+// a few hundred slabs that serial chain is latency bound (~110 us measured), so
+// here one wavefront owns a bin: lane l Kahan-sums slabs l, l+64, ... and the 64
+// partials (value + compensation) are combined in a fixed butterfly order, which
+// keeps the result deterministic for given slab contents.
 // (-ffp-contract=off keeps the compensation from being folded away.)
-__global__ void reduceKernel(const float* __restrict__ slabs, float* __restrict__ out,
-                             uint32_t n_bins, uint32_t n_hist, float norm) {
-    uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
-    if (idx >= n_bins) return;
+__global__ void __launch_bounds__(64) reduceKernel(const float* __restrict__ slabs, float* __restrict__ out,
+                                                   uint32_t n_bins, uint32_t n_hist, float norm) {
+    const uint32_t bin = blockIdx.x;
+    const uint32_t lane = threadIdx.x;
     float result = 0.0f, c = 0.0f;
-    size_t i = idx;
-    for (uint32_t n = 0; n < n_hist; ++n, i += n_bins) {
-        float y = slabs[i] - c;
+    for (uint32_t h = lane; h < n_hist; h += 64) {
+        float y = slabs[(size_t)h * n_bins + bin] - c;
         float t = result + y;
         c = (t - result) - y;
         result = t;
     }
-    out[idx] = result * norm;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        float other = __shfl_xor(result, off, 64);
+        float otherC = __shfl_xor(c, off, 64);
+        // Kahan-add the partner's partial sum (its compensation is a correction to it)
+        float y = (other - otherC) - c;
+        float t = result + y;
+        c = (t - result) - y;
+        result = t;
+    }
+    if (lane == 0) out[bin] = result * norm;
 }
 
 hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
                         float norm, hipStream_t stream) {
-    uint32_t block = 128; // response.py:1075 default blockSize
-    uint32_t grid = (n_bins + block - 1) / block;
-    hipLaunchKernelGGL(reduceKernel, dim3(grid), dim3(block), 0, stream, slabs, out, n_bins, n_hist, norm);
+    if (n_bins == 0) return hipSuccess;
+    hipLaunchKernelGGL(reduceKernel, dim3(n_bins), dim3(64), 0, stream, slabs, out, n_bins, n_hist, norm);
     return hipGetLastError();
 }
 

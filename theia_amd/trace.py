@@ -175,6 +175,9 @@ class _Program:
     def last_kernel_ms(self, cfg: int) -> float:
         return self.backend.tracer_last_kernel_ms(self.handle, cfg)
 
+    def kernel_times(self, n: int = 64) -> np.ndarray:
+        return self.backend.tracer_kernel_times(self.handle, n)
+
     def __del__(self) -> None:
         try:
             if self._handle is not None:
