@@ -1,0 +1,90 @@
+"""The C-ABI library: loads, exports every symbol include/theia_hip.h declares,
+its parameter blocks have the reference's packed layouts, and it fails loudly
+without a GPU (no CPU fallback). No compute calls here."""
+import ctypes as C
+import os
+import re
+
+import pytest
+
+import oracle as orc
+from theia_amd import _capi as capi
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    text = open(os.path.join(ROOT, "include", "theia_hip.h")).read()
+    return sorted(set(re.findall(r"\b(thx_[a-z_0-9]+)\s*\(", text)))
+
+
+def test_library_exports_every_declared_symbol():
+    lib = C.CDLL(capi.lib_path())
+    declared = _declared()
+    assert len(declared) >= 25
+    missing = [s for s in declared if not hasattr(lib, s)]
+    assert not missing, missing
+    assert sorted(capi.EXPORTED_SYMBOLS) == declared  # python binding covers the whole header
+
+
+def test_parameter_block_layouts():
+    # scalar layout sizes of the reference UBOs
+    assert C.sizeof(capi.PhiloxParams) == 24 and C.sizeof(capi.LightParams) == 28
+    assert C.sizeof(capi.TargetParams) == 36 and C.sizeof(capi.GuideParams) == 20
+    assert C.sizeof(capi.PropagateParams) == 36
+    assert C.sizeof(capi.VolumeTraceParams) == 48 and C.sizeof(capi.SceneTraceParams) == 48
+    assert capi.SceneTraceParams.sceneMedium.offset == 4  # uvec2 right behind the int
+    assert C.sizeof(capi.ResponseParams) == 8 and C.sizeof(capi.DispatchParams) == 16
+    # the oracle uses identical layouts
+    for a, b in [(capi.PhiloxParams, orc.PhiloxParams), (capi.LightParams, orc.LightParams), (capi.TargetParams, orc.TargetParams),
+                 (capi.GuideParams, orc.GuideParams), (capi.VolumeTraceParams, orc.VolumeTraceParams),
+                 (capi.SceneTraceParams, orc.SceneTraceParams), (capi.ResponseParams, orc.ResponseParams),
+                 (capi.WavelengthParams, orc.WavelengthParams)]:
+        assert C.sizeof(a) == C.sizeof(b)
+    # host stage blocks == C ABI blocks
+    from theia_amd.light import SphericalLightSource
+    from theia_amd.random import PhiloxRNG
+    from theia_amd.target import SphereTarget, SphereTargetGuide
+    from theia_amd.trace import SceneForwardTracer, VolumeForwardTracer
+
+    assert C.sizeof(SphericalLightSource.LightParams) == C.sizeof(capi.LightParams)
+    assert C.sizeof(PhiloxRNG.PhiloxParams) == C.sizeof(capi.PhiloxParams)
+    assert C.sizeof(SphereTarget.TargetParams) == C.sizeof(capi.TargetParams)
+    assert C.sizeof(SphereTargetGuide.TargetGuideParams) == C.sizeof(capi.GuideParams)
+    assert C.sizeof(VolumeForwardTracer.TraceParams) == C.sizeof(capi.VolumeTraceParams)
+    assert C.sizeof(SceneForwardTracer.TraceParams) == C.sizeof(capi.SceneTraceParams)
+
+
+def test_fails_loudly_without_gpu():
+    import torch
+
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is present")
+    lib = capi.lib()
+    ctx = C.c_void_p()
+    rc = lib.thx_ctx_create(0, C.byref(ctx))
+    assert rc == -3 and not ctx.value  # THX_ERR_NO_DEVICE
+    assert b"no HIP device" in lib.thx_last_error()
+    from theia_amd import _backend
+
+    prev = _backend._backend
+    _backend._backend = None
+    try:
+        with pytest.raises(capi.ThxError):
+            _backend.get()
+        from theia_amd.material import MaterialStore
+
+        with pytest.raises(capi.ThxError):
+            MaterialStore([])
+    finally:
+        _backend._backend = prev
+
+
+def test_product_never_imports_the_oracle():
+    """theia_amd/, theia/, hephaistos/ contain no reference to oracle/"""
+    for pkg in ("theia_amd", "theia", "hephaistos"):
+        for dirpath, _, files in os.walk(os.path.join(ROOT, pkg)):
+            for f in files:
+                if f.endswith((".py", ".cpp", ".hip", ".hpp", ".h")):
+                    text = open(os.path.join(dirpath, f)).read()
+                    assert "import oracle" not in text and "libtheia_oracle" not in text and "oracle_backend" not in text, os.path.join(dirpath, f)

@@ -1,0 +1,214 @@
+"""Host-side mirror of the reference's module API: signatures, formulas, stage
+parameters, pipeline protocol, error behaviour.
+Runs on the oracle stand-in backend -- no GPU."""
+import numpy as np
+import pytest
+
+import scenarios as S
+import theia_amd.units as u
+from theia_amd.hp import pipeline as pl
+from theia_amd.light import ConstWavelengthSource, SphericalLightSource, UniformWavelengthSource
+from theia_amd.random import PhiloxRNG
+from theia_amd.response import EmptyResponse, HistogramHitResponse, UniformValueResponse, ValueResponse
+from theia_amd.scene import RectBBox, Transform
+from theia_amd.target import SphereTarget, SphereTargetGuide
+from theia_amd.trace import EventStatisticCallback, SceneForwardTracer, VolumeForwardTracer
+
+
+def test_alias_packages_resolve():
+    import hephaistos as hp
+    import hephaistos.pipeline as hpl
+    import theia
+    import theia.units as tu
+    from hephaistos.glsl import vec3
+    from theia.material import MaterialStore
+    from theia.trace import SceneForwardTracer as T1, VolumeForwardTracer as T2
+
+    assert T1 is SceneForwardTracer and T2 is VolumeForwardTracer and tu.c is u.c
+    assert hpl.Pipeline is pl.Pipeline and hp.isRaytracingEnabled()
+    assert tuple(vec3(1, 2, 3)) == (1.0, 2.0, 3.0)
+
+
+def test_units():
+    assert (1.0, 2.0) * u.km == (1000.0, 2000.0) and 1.0 * u.c == 0.299792458
+    assert 0.05 / u.m == 0.05 and 5.0 * u.per_km == 0.005 and 50.0 * u.cm == 0.5
+    assert np.allclose(np.array([1.0, 2.0]) * u.deg, np.deg2rad([1.0, 2.0]))
+    assert u.convert(1500.0, u.um) == 1.5
+
+
+def test_stage_parameter_protocol():
+    light = SphericalLightSource(position=(1.0, 2.0, 3.0), timeRange=(0.0, 10.0), budget=5.0)
+    assert light.getParams() == {"position": (1.0, 2.0, 3.0), "timeRange": (0.0, 10.0), "budget": 5.0}
+    light.position = (4.0, 5.0, 6.0)  # attribute access to public fields
+    assert light.getParam("position") == (4.0, 5.0, 6.0)
+    light.setParams(budget=7.0, unknown=1)  # unknown names are ignored
+    assert light.budget == 7.0
+    with pytest.raises(AttributeError):
+        light._contribFwd  # private fields are not attributes
+    light.update(1)  # _finishParams fills the private fields, config 1 only
+    assert light._getParamsBlock("LightParams", 1)._contribFwd == 7.0
+    assert light._getParamsBlock("LightParams", 0)._contribFwd == 0.0
+    wl = UniformWavelengthSource(lambdaRange=(300.0, 700.0), normalize=False)
+    wl.update(0)
+    assert wl._getParamsBlock("WavelengthParams", 0)._contrib == 400.0 and wl.nRNGSamples == 1
+    tgt = SphereTarget(position=(-1.0, 0.0, 0.0), radius=0.5)
+    tgt.update(0)
+    b = tgt._getParamsBlock("TargetParams", 0)
+    assert b._hemisphereProb == pytest.approx(1 / (2 * np.pi * 0.25)) and tuple(b._invPos) == (2.0, 0.0, 0.0) and b._invRad == 2.0
+    rng = PhiloxRNG(key=(1 << 40) + 5, offset=(1 << 100) + 3)
+    assert rng.key == (1 << 40) + 5 and rng.offset == (1 << 100) + 3
+
+
+def test_tracer_formulas_match_reference(oracle_backend):
+    # VolumeForwardTracer, trace.py:623-634: nScattering 10, MIS on, direct on
+    sc = S.config1_volume(1000)
+    tr = sc.tracer
+    assert tr.maxHitsPerThread == 21 and tr.nRNGSamples == 3 + 0 + 7 * 9 and tr.maxHits == 21 * 1000
+    assert tr.normalization == 1e-3 and tr.capacity == 1000 and tr.blockSize == 128 and not tr.polarized
+    assert [n for n, _ in tr.collectStages()] == ["rng", "photons", "lightSource", "target", "tracer", "callback", "response"]
+    assert tr.collectStages(useOriginalNames=True)[4][0] == "Volume Forward Tracer"
+    sc = S.config1_volume(1000, disableTargetSampling=True, disableDirectLighting=True)
+    assert sc.tracer.maxHitsPerThread == 10 and sc.tracer.nRNGSamples == 3 + 3 * 10
+    # SceneForwardTracer, trace.py:1176-1187
+    sc = S.config2_sphere(2048)
+    tr = sc.tracer
+    assert tr.maxHitsPerThread == 9 * 2 + 1 and tr.nRNGSamples == 3 + 1 + (4 + 2) * 10
+    assert [n for n, _ in tr.collectStages()] == ["rng", "photons", "lightSource", "guide", "tracer", "callback", "response"]
+    sc = S.config2_sphere(2048, guide=False)
+    assert sc.tracer.maxHitsPerThread == 10 and sc.tracer.nRNGSamples == 3 + 1 + 4 * 10
+    assert "guide" not in [n for n, _ in sc.tracer.collectStages()]
+    # batch size rules, trace.py:399-408
+    tr = sc.tracer
+    tr.batchSize = 100
+    assert tr.getParam("_groupCountX") == 1 and tr.normalization == 0.01
+    with pytest.raises(ValueError):
+        tr.batchSize = 4096
+    with pytest.raises(ValueError):
+        tr.batchSize = -1
+
+
+def test_unsupported_components_raise_clearly(oracle_backend):
+    sc = S.config1_volume(100)
+
+    class MyValue(ValueResponse):
+        pass
+
+    with pytest.raises(NotImplementedError, match="UniformValueResponse"):
+        HistogramHitResponse(MyValue())
+    with pytest.raises(NotImplementedError, match="HistogramHitResponse"):
+        VolumeForwardTracer(10, sc.light, sc.target, sc.wavelength, EmptyResponse(), sc.rng, medium=0)
+    with pytest.raises(NotImplementedError, match="SphereTarget"):
+        VolumeForwardTracer(10, sc.light, SphereTargetGuide(), sc.wavelength, sc.response, sc.rng, medium=0)
+    with pytest.raises(NotImplementedError):
+        HistogramHitResponse(UniformValueResponse(), nBins=10000)
+
+
+def test_pipeline_and_scheduler_example01_flow(oracle_backend):
+    """examples/01_volume_tracing.ipynb cells 24-38 on BASELINE config 1 (plumbing, CPU)"""
+    sc = S.config1_volume(20_000)
+    pipeline = pl.Pipeline(sc.tracer.collectStages())
+    assert "lightSource__budget" in pipeline.getParams() and "tracer__scatterCoefficient" in pipeline.getParams()
+    hists, cfgs = [], []
+
+    def process(config, batch, args):
+        hists.append(sc.response.result(config).copy())
+        cfgs.append((config, batch))
+
+    scheduler = pl.PipelineScheduler(pipeline, processFn=process)
+    scheduler.schedule([{}] * 3)
+    scheduler.schedule([{"lightSource__budget": 2.0e5}])
+    scheduler.wait()
+    scheduler.destroy()
+    assert cfgs == [(0, 0), (1, 1), (0, 2), (1, 3)] and scheduler.tasksFinished == 4
+    assert sc.rng.offset == 4 * sc.tracer.nRNGSamples  # advanced once per batch
+    tot = [h.sum() for h in hists]
+    assert all(t > 0 for t in tot) and not np.array_equal(hists[0], hists[1])  # different random numbers
+    assert abs(tot[1] / tot[0] - 1) < 0.2 and abs(tot[3] / tot[0] - 2) < 0.4  # budget doubled
+    with pytest.raises(ValueError):
+        pipeline.setParams(nosuchstage__x=1)
+
+
+def test_scheduler_surfaces_errors(oracle_backend):
+    sc = S.config1_volume(100)
+    pipeline = pl.Pipeline(sc.tracer.collectStages())
+
+    def boom(config, batch, args):
+        raise RuntimeError("boom")
+
+    scheduler = pl.PipelineScheduler(pipeline, processFn=boom)
+    scheduler.schedule([{}])
+    with pytest.raises(RuntimeError, match="boom"):
+        scheduler.wait()
+    scheduler.destroy()
+
+
+def test_statistics_callback_counts(oracle_backend):
+    """event counters add up (reference tests/test_trace.py:947-1045)"""
+    n = 5000
+    sc = S.config2_sphere(n, stats=True)
+    S.run_batches(sc, 1)
+    cb = sc.callback
+    assert cb.created == n and cb.error == 0 and cb.mismatch == 0
+    assert cb.lost + cb.decayed + cb.absorbed + cb.maxIter == n  # every photon ends exactly once
+    assert cb.traversal["steps"] == cb.scattered + cb.hit + cb.detected + cb.volume + cb.lost + cb.decayed + cb.absorbed + cb.missed + cb.error
+    assert "created: 5,000" in str(cb)
+    cb.reset()
+    assert cb.created == 0
+
+
+def test_transform_and_bbox():
+    t = Transform.TRS(scale=2.0, rotate=(0.0, 0.0, 1.0, 90.0), translate=(1.0, 0.0, 0.0))
+    p = t.apply(np.array([[1.0, 0.0, 0.0]]))
+    assert np.allclose(p, [[1.0, 2.0, 0.0]])
+    assert np.allclose(t.inverse().apply(p), [[1.0, 0.0, 0.0]])
+    assert np.allclose((Transform.Translation(1, 2, 3) @ Transform.Scale(2)).numpy(), [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, 2, 3]])
+    with pytest.raises(ValueError):
+        Transform(np.zeros((4, 4)))
+    box = RectBBox((-1.0, -2.0, -3.0), (1.0, 2.0, 3.0))
+    assert box.diagonal == pytest.approx(np.sqrt(4 + 16 + 36))
+    moved = box.transform(Transform.Translation(10, 0, 0))
+    assert moved.lowerCorner == (9.0, -2.0, -3.0) and moved.upperCorner == (11.0, 2.0, 3.0)
+    v = Transform.View(position=(0, 0, 5), direction=(0, 0, -1), up=(0, 1, 0)).numpy()
+    assert np.allclose(v[:, 2], [0, 0, -1]) and np.allclose(v[:, 3], [0, 0, 5])
+
+
+def test_mesh_io_roundtrip(tmp_path):
+    from theia_amd.meshio import icosphere, load_mesh_arrays, save_stl
+
+    v, f = icosphere(3)
+    assert v.shape == (642, 6) and f.shape == (1280, 3)
+    assert np.allclose(np.linalg.norm(v[:, :3], axis=1), 1.0, atol=1e-6)
+    assert ((v[:, :3] * v[:, 3:]).sum(1) > 0.99).all()  # vertex normals point outwards
+    path = tmp_path / "ico.stl"
+    save_stl(path, v, f)
+    v2, f2 = load_mesh_arrays(path)
+    assert v2.shape == v.shape and f2.shape == f.shape  # vertices merged again
+    ref = S.bundled_mesh("sphere")
+    assert ref.vertices.shape == (642, 6) and ref.indices.shape == (1280, 3)
+    r = np.linalg.norm(ref.vertices[:, :3], axis=1)
+    assert r.min() > 0.99 and r.max() < 1.001
+    (tmp_path / "t.ply").write_text("ply\nformat ascii 1.0\nelement vertex 3\nproperty float x\nproperty float y\nproperty float z\n"
+                                    "element face 1\nproperty list uchar int vertex_indices\nend_header\n0 0 0\n1 0 0\n0 1 0\n3 0 1 2\n")
+    pv, pf = load_mesh_arrays(tmp_path / "t.ply")
+    assert pv.shape == (3, 6) and pf.tolist() == [[0, 1, 2]] and np.allclose(pv[:, 3:], [[0, 0, 1]] * 3)
+    (tmp_path / "x.obj").write_text("v 0 0 0\n")
+    with pytest.raises(ValueError):
+        load_mesh_arrays(tmp_path / "x.obj")
+
+
+def test_scene_validation(oracle_backend):
+    from theia_amd.material import Material, MaterialStore
+    from theia_amd.scene import MeshStore, Scene
+
+    store = MaterialStore([Material("m", None, None, flags="B")])
+    meshes = MeshStore({"sphere": S.bundled_mesh("sphere")})
+    with pytest.raises(ValueError, match="empty"):
+        Scene([], store.material)
+    inst = meshes.createInstance("sphere", "nope")
+    with pytest.raises(ValueError, match="Unknown material"):
+        Scene([inst], store.material)
+    inst = meshes.createInstance("sphere", "m", Transform.Translation(1, 2, 3), scale=2.0, detectorId=7)
+    assert inst.instance.customIndex == 7 and np.allclose(inst.transform.numpy(), [[2, 0, 0, 1], [0, 2, 0, 2], [0, 0, 2, 3]])
+    assert np.allclose(inst.bbox.lowerCorner, [-1, 0, 1], atol=1e-2)
+    sc = Scene([inst], store, medium=0)
+    assert sc.medium == 0 and sc.bbox.diagonal == pytest.approx(np.sqrt(3) * 2000.0)
