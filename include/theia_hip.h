@@ -204,6 +204,8 @@ int thx_scene_get_info(const thx_scene* scene, thx_scene_info* out);
 /* closest-hit probe: n rays (origin[3], dir[3], tmax) -> out[n][5] =
  * {hit, instance, primitive, t, bary.x, bary.y}[..] as floats (6 per ray) */
 int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out6);
+/* kernel time (ms) of the most recent thx_scene_query (HIP events, second of two runs) */
+int thx_scene_query_ms(const thx_scene* scene, float* ms);
 
 /* ---- tracer (replaces hp.Program(compileShader("tracer.*.forward.glsl")) +
  * Tracer.run/_dispatch, trace.py:478-481, 758-766, 1326-1336) ---- */
@@ -222,6 +224,9 @@ int thx_tracer_hist_device_ptr(thx_tracer* tracer, uint32_t cfg, uint64_t* out);
 /* EventStatisticCallback (trace.py:77-187) */
 int thx_tracer_read_stats(thx_tracer* tracer, uint64_t* out, uint32_t n);
 int thx_tracer_reset_stats(thx_tracer* tracer);
+/* development aid (library built with -DTHX_STAGE_PROFILE): per-stage cycles [0..15],
+ * rounds [16..31], photons [32..47] of the staged scene kernel since the last call */
+int thx_tracer_read_stage_profile(thx_tracer* tracer, uint64_t* out48);
 /* parity probe: per-event dump of the last run, [batch][path_length+3][THX_TRACK_WORDS] */
 int thx_tracer_read_track(thx_tracer* tracer, float* out, size_t n_floats);
 /* launch geometry chosen by the library: workgroups, threads per workgroup,

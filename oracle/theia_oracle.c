@@ -1114,11 +1114,19 @@ static int slab_test(const float lo[3], const float hi[3], vec3 o, vec3 inv, flo
 
 typedef struct { int valid; uint32_t instance, prim; float t, b1, b2; } QueryHit;
 
+/* diagnostic: histogram of BVH nodes visited per query (bins of 8, last bin = overflow) */
+static uint64_t g_node_hist[64];
+void orc_node_histogram(uint64_t out[64], int reset) {
+    memcpy(out, g_node_hist, sizeof(g_node_hist));
+    if (reset) memset(g_node_hist, 0, sizeof(g_node_hist));
+}
+
 static QueryHit ray_query(const orc_scene* s, vec3 origin, vec3 dir, float tmax, int brute,
                           Counters* cnt) {
     QueryHit q;
     memset(&q, 0, sizeof(q));
     q.t = tmax;
+    uint64_t nodes_before = cnt ? cnt->stats[ST_NODES] : 0;
     if (cnt) cnt->stats[ST_QUERIES]++;
     vec3 winv = V3(1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z);
     for (uint32_t k = 0; k < s->n_inst; ++k) {
@@ -1176,6 +1184,12 @@ static QueryHit ray_query(const orc_scene* s, vec3 origin, vec3 dir, float tmax,
         }
     }
     if (cnt && q.valid) cnt->stats[ST_HITS]++;
+    if (cnt) {
+        uint64_t nv = cnt->stats[ST_NODES] - nodes_before;
+        uint64_t b = nv / 8 > 63 ? 63 : nv / 8;
+#pragma omp atomic
+        g_node_hist[b]++;
+    }
     return q;
 }
 

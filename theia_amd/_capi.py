@@ -149,6 +149,7 @@ _PROTOS = {
     "thx_scene_destroy": (c_int, [c_void_p]),
     "thx_scene_get_info": (c_int, [c_void_p, POINTER(SceneInfo)]),
     "thx_scene_query": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_float)]),
+    "thx_scene_query_ms": (c_int, [c_void_p, POINTER(c_float)]),
     "thx_tracer_create": (c_int, [c_void_p, POINTER(TracerDesc), c_void_p, POINTER(c_void_p)]),
     "thx_tracer_destroy": (c_int, [c_void_p]),
     "thx_tracer_run": (c_int, [c_void_p, c_uint32, POINTER(RunParams), c_void_p]),
@@ -157,6 +158,7 @@ _PROTOS = {
     "thx_tracer_hist_device_ptr": (c_int, [c_void_p, c_uint32, POINTER(c_uint64)]),
     "thx_tracer_read_stats": (c_int, [c_void_p, POINTER(c_uint64), c_uint32]),
     "thx_tracer_reset_stats": (c_int, [c_void_p]),
+    "thx_tracer_read_stage_profile": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_read_track": (c_int, [c_void_p, POINTER(c_float), c_size_t]),
     "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "thx_tracer_last_kernel_ms": (c_int, [c_void_p, c_uint32, POINTER(c_float)]),
@@ -169,6 +171,9 @@ _lib = None
 
 
 def lib_path() -> str:
+    override = os.environ.get("THEIA_AMD_LIB")  # development: A/B builds of the same ABI
+    if override:
+        return override
     return os.path.join(os.path.dirname(os.path.abspath(__file__)), "lib", "libtheia_hip.so")
 
 

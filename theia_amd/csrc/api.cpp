@@ -48,6 +48,7 @@ struct thx_scene {
     thx_ctx* ctx = nullptr;
     SceneView view{};
     thx_scene_info info{};
+    float lastQueryMs = 0.0f;
     std::vector<void*> allocs;
 };
 
@@ -57,13 +58,22 @@ struct thx_tracer {
     thx_tracer_desc desc{};
     TraceVariant variant{};
     bool debug = false;
+    bool staged = false;          // staged (regrouped-in-LDS) scene kernel
+    uint32_t mode = 0;            // bit 0 instrumented, bit 1 staged
+    uint32_t stackDepth = kStackDepth;
+    bool stack16 = false;         // 16-bit stack entries (small scenes)
+    uint32_t pool = 0;            // staged kernel: photons per workgroup pool
+    uint32_t shadeMin = 1;        // staged kernel: see LaunchArgs::shade_min
+    uint32_t ldsNodes = 0;        // staged kernel: BVH nodes staged in LDS (0 = walk reads HBM/L2)
     uint32_t block = kTraceBlock;
     size_t lds = 0;
     uint32_t gridMax = 1;
+    uint32_t refillBelow = 63;
     float* slabs[2] = {nullptr, nullptr};
     float* out[2] = {nullptr, nullptr};
     uint32_t lastGrid[2] = {0, 0};
     unsigned long long* stats = nullptr;
+    unsigned long long* prof = nullptr;
     float* track = nullptr;
     uint32_t trackEvents = 0;
     uint32_t lastBatch = 0;
@@ -274,12 +284,27 @@ int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out
     hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * 6 * (size_t)n);
     if (e != hipSuccess) { hipFree(d_in); return hipFail(e, "hipMalloc"); }
     e = hipMemcpy(d_in, rays7, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice);
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    if (e == hipSuccess) e = hipEventCreate(&ev0);
+    if (e == hipSuccess) e = hipEventCreate(&ev1);
+    if (e == hipSuccess) e = launchQuery(scene->view, d_in, n, d_out, ctx->stream); // warm caches
+    if (e == hipSuccess) e = hipEventRecord(ev0, ctx->stream);
     if (e == hipSuccess) e = launchQuery(scene->view, d_in, n, d_out, ctx->stream);
+    if (e == hipSuccess) e = hipEventRecord(ev1, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipEventElapsedTime(&scene->lastQueryMs, ev0, ev1);
+    if (ev0) hipEventDestroy(ev0);
+    if (ev1) hipEventDestroy(ev1);
     if (e == hipSuccess) e = hipMemcpy(out6, d_out, sizeof(float) * 6 * (size_t)n, hipMemcpyDeviceToHost);
     hipFree(d_in);
     hipFree(d_out);
     if (e != hipSuccess) return hipFail(e, "thx_scene_query");
+    return THX_OK;
+}
+
+int thx_scene_query_ms(const thx_scene* scene, float* ms) {
+    if (!scene || !ms) return fail(THX_ERR_INVALID, "null argument");
+    *ms = scene->lastQueryMs;
     return THX_OK;
 }
 
@@ -306,12 +331,43 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     t->variant = traceVariant(desc->kind, pol, mis);
     t->debug = (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK)) != 0;
     t->block = kTraceBlock;
-    t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block);
-    int perCU = t->variant.occupancy(t->debug, t->block, t->lds);
+    if (scene) {
+        t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
+        t->stack16 = scene->info.n_nodes < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
+        if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
+    }
+    // kernel form: the staged scene kernel unless the scene exceeds its packed hit ids
+    // (12-bit instance, 20-bit primitive) or THX_KERNEL=lane asks for the lane kernel
+    t->staged = desc->kind == THX_TRACER_SCENE_FORWARD && scene->info.n_instances < 4096 &&
+                scene->info.n_triangles < (1u << 20) && desc->path_length >= 1;
+    if (const char* env = std::getenv("THX_KERNEL")) {
+        if (std::strcmp(env, "lane") == 0) t->staged = false;
+    }
+    t->mode = (t->debug ? 1u : 0u) | (t->staged ? 2u : 0u);
+    if (t->staged) {
+        t->block = kStagedBlock;
+        if (const char* env = std::getenv("THX_THREADS")) t->block = (uint32_t)std::min<int>(kStagedBlock, std::max(64, std::atoi(env) / 64 * 64));
+        size_t budget = (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor - 2048; // whole CU, one workgroup
+        if (const char* env = std::getenv("THX_POOL_LDS_KB")) budget = (size_t)std::max(16, std::atoi(env)) * 1024;
+        const uint32_t stackBytes = t->stackDepth * (t->stack16 ? 2u : 4u);
+        // stage the node array in LDS when it is small (<= 48 KB): LDS gathers are ~10x cheaper than L1 gathers
+        uint32_t ldsNodeLimit = 48 * 1024 / 32;
+        if (const char* env = std::getenv("THX_LDS_NODES")) ldsNodeLimit = (uint32_t)std::max(0, std::atoi(env));
+        t->ldsNodes = scene->info.n_nodes <= ldsNodeLimit ? scene->info.n_nodes : 0u;
+        if (t->ldsNodes) t->mode |= 4u;
+        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, t->ldsNodes);
+        if (const char* env = std::getenv("THX_SHADE_MIN")) t->shadeMin = (uint32_t)std::max(1, std::atoi(env));
+        if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(1024, std::max(64, std::atoi(env)));
+        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
+    } else {
+        t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
+    }
+    int perCU = t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
     uint32_t mult = 1;
     if (const char* env = std::getenv("THX_GRID_MULT")) mult = (uint32_t)std::max(1, std::atoi(env));
     t->gridMax = (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)perCU * mult;
+    if (const char* env = std::getenv("THX_REFILL")) t->refillBelow = (uint32_t)std::min(63, std::max(0, std::atoi(env)));
     const size_t slabBytes = sizeof(float) * (size_t)t->gridMax * desc->n_bins;
     hipError_t e = hipSuccess;
     for (int i = 0; i < 2 && e == hipSuccess; ++i) {
@@ -326,6 +382,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
     if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->prof, sizeof(unsigned long long) * 48);
+    if (e == hipSuccess) e = hipMemset(t->prof, 0, sizeof(unsigned long long) * 48);
     if (e == hipSuccess && (desc->flags & THX_FLAG_TRACK)) {
         t->trackEvents = desc->path_length + 3;
         size_t nb = sizeof(float) * THX_TRACK_WORDS * (size_t)t->trackEvents * desc->capacity;
@@ -350,12 +408,19 @@ int thx_tracer_destroy(thx_tracer* t) {
         if (t->evStop[i]) hipEventDestroy(t->evStop[i]);
     }
     if (t->stats) hipFree(t->stats);
+    if (t->prof) hipFree(t->prof);
     if (t->track) hipFree(t->track);
     delete t;
     return THX_OK;
 }
 
 static void launchGeometry(const thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* ppw) {
+    if (t->staged) { // one pool-owning workgroup per CU; each gets a contiguous photon range
+        uint64_t need = ((uint64_t)batch + t->pool - 1) / t->pool;
+        *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, need));
+        *ppw = 0;
+        return;
+    }
     const uint32_t wavesPerBlock = t->block / 64;
     uint64_t wavesNeeded = ((uint64_t)batch + 63) / 64;
     uint64_t blocksNeeded = (wavesNeeded + wavesPerBlock - 1) / wavesPerBlock;
@@ -392,9 +457,17 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.path_length = t->desc.path_length;
     a.n_bins = t->desc.n_bins;
     a.track_events = t->trackEvents;
-    a.stack_depth = kStackDepth;
+    a.stack_depth = t->stackDepth;
+    a.stack_wave_words = t->stackDepth * (t->stack16 ? 32u : 64u);
+    a.stack16 = t->stack16 ? 1u : 0u;
+    a.refill_below = t->refillBelow;
+    a.pool = t->pool;
+    a.shade_min = t->shadeMin;
+    a.lds_nodes_count = t->ldsNodes;
+    a.lds_nodes_word = (t->desc.n_bins + 3u) & ~3u;
     a.slabs = t->slabs[cfg];
     a.stats = t->stats;
+    a.prof = t->prof;
     a.track = t->track;
     if (t->scene) a.scene = t->scene->view;
     uint32_t grid, ppw;
@@ -404,7 +477,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     t->lastBatch = batch;
     const uint32_t slot = (uint32_t)(t->launches % thx_tracer::kRing);
     THX_HIP(hipEventRecord(t->evStart[slot], s));
-    THX_HIP(t->variant.launch(t->debug, a, grid, t->block, t->lds, s));
+    THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
     THX_HIP(hipEventRecord(t->evStop[slot], s));
     t->lastSlot[cfg] = (int)slot;
     t->launches += 1;
@@ -443,6 +516,15 @@ int thx_tracer_read_stats(thx_tracer* t, uint64_t* out, uint32_t n) {
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemcpy(out, t->stats, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
+    return THX_OK;
+}
+
+int thx_tracer_read_stage_profile(thx_tracer* t, uint64_t* out48) {
+    if (!t || !out48) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    THX_HIP(hipMemcpy(out48, t->prof, sizeof(uint64_t) * 48, hipMemcpyDeviceToHost));
+    THX_HIP(hipMemset(t->prof, 0, sizeof(uint64_t) * 48));
     return THX_OK;
 }
 

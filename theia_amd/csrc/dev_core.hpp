@@ -47,6 +47,22 @@ THX_DEV float clampf(float x, float lo, float hi) { return fminf(fmaxf(x, lo), h
 THX_DEV float mixf(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 THX_DEV float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 
+// Transcendentals. Default: the accurate ROCm device-library versions (<= 1-2 ulp), which
+// keeps the kernels comparable to the CPU oracle at the libm level. -DTHX_NATIVE_MATH
+// switches to the hardware approximations (v_sin/v_cos/v_exp/v_log based, what GLSL
+// drivers typically emit for the reference's shaders).
+#ifdef THX_NATIVE_MATH
+THX_DEV float thx_sin(float x) { return __sinf(x); }
+THX_DEV float thx_cos(float x) { return __cosf(x); }
+THX_DEV float thx_exp(float x) { return __expf(x); }
+THX_DEV float thx_log(float x) { return __logf(x); }
+#else
+THX_DEV float thx_sin(float x) { return sinf(x); }
+THX_DEV float thx_cos(float x) { return cosf(x); }
+THX_DEV float thx_exp(float x) { return expf(x); }
+THX_DEV float thx_log(float x) { return logf(x); }
+#endif
+
 // math.glsl:8-16, material.glsl:6
 constexpr float TWO_PI = 6.283185307179586477f;
 constexpr float INV_4PI = 0.0795774715459476679f;
@@ -162,8 +178,12 @@ THX_DEV void philox4x32(const thx_philox_params& p, uint32_t stream, uint32_t i,
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        uint32_t hi0 = __umulhi(M0, sx), lo0 = M0 * sx;
-        uint32_t hi1 = __umulhi(M1, sz), lo1 = M1 * sz;
+        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of mul_hi + mul_lo:
+        // integer multiplies are quarter rate, so this halves the cost of a round
+        const uint64_t p0 = (uint64_t)M0 * (uint64_t)sx;
+        const uint64_t p1 = (uint64_t)M1 * (uint64_t)sz;
+        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
         uint32_t nx = hi1 ^ sy ^ kx, nz = hi0 ^ sw ^ ky;
         sx = nx; sy = lo1; sz = nz; sw = lo0;
         kx += 0x9E3779B9u;
@@ -307,7 +327,7 @@ THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, 
 THX_DEV f3 scatterDir(f3 prevDir, float cos_theta, float phi) {
     prevDir = normalize(prevDir);
     float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
-    f3 local = f3{sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+    f3 local = f3{sin_theta * thx_cos(phi), sin_theta * thx_sin(phi), cos_theta};
     local = normalize(local);
     m3 trafo = createLocalCOSY(prevDir);
     return normalize(mul(trafo, local));
@@ -323,7 +343,7 @@ THX_DEV float sampleScatterDir(uint64_t medium, float u0, float u1, float& cos_t
         float ct = lookUp(m->phase_sampling, u1, 0.0f, cnt);
         ct = clampf(ct, -1.0f, 1.0f);
         cos_theta = ct;
-        return expf(lookUp(m->log_phase, 0.5f * (ct + 1.0f), 0.0f, cnt));
+        return thx_exp(lookUp(m->log_phase, 0.5f * (ct + 1.0f), 0.0f, cnt));
     }
     cos_theta = 2.0f * u1 - 1.0f;
     return INV_4PI;
@@ -344,13 +364,13 @@ THX_DEV float scatterProb(uint64_t medium, f3 inDir, f3 outDir, Counters<ST>& cn
     if (medium == 0 || m->log_phase == 0) return INV_4PI;
     float cos_theta = dot(inDir, outDir);
     float log_p = lookUp(m->log_phase, 0.5f * (cos_theta + 1.0f), 0.0f, cnt);
-    return expf(log_p);
+    return thx_exp(log_p);
 }
 
 // util.sample.glsl:10-17
 THX_DEV f3 sphericalToCartessian(float phi, float cos_theta) {
     float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
-    return f3{sin_theta * sinf(phi), sin_theta * cosf(phi), cos_theta};
+    return f3{sin_theta * thx_sin(phi), sin_theta * thx_cos(phi), cos_theta};
 }
 
 } // namespace thx

@@ -1,0 +1,529 @@
+// Staged scene tracer: the same per-photon algorithm as sceneStep() (dev_trace.hpp),
+// re-organised so that the lanes of a wavefront always run the SAME piece of it.
+//
+// Why: one-lane-one-photon execution of tracer.scene.forward.glsl is bound by VALU
+// issue at ~23 % lane utilisation on MI355X (rocprofv3: SQ_THREAD_CYCLES_VALU /
+// (64 * SQ_ACTIVE_INST_VALU)): per step only ~12 % of the photons need a deep BVH
+// walk for the primary ray, ~45 % need MIS sampling plus shadow rays, ~50 % are
+// being born, and a wavefront pays for every path any of its lanes takes.
+//
+// How: a workgroup owns a pool of up to 1024 photons in LDS (structure of float4
+// arrays, 112 B per photon, 144 B polarized) and a queue per stage
+//     BIRTH -> A (free path, guide) -> T0 (primary BVH walk + surface hit)
+//           -> BM (propagate, no hit) -> M (MIS sampling)
+//           -> TS (shadow-ray walk + detector response) -> C (scatter) -> A ...
+// Each round the workgroup runs the stage with the most waiting photons, on up to
+// blockDim.x of them, one photon per lane: wavefronts are dense, thin stages simply
+// wait until enough photons have piled up. Photons are independent and carry their own
+// RNG stream (= photon index) and dimension, so the order in which they advance
+// does not change any per-photon result; arithmetic, draw order and event order
+// are those of the lane kernel (the stage bodies call the same device functions).
+// Queue appends are wavefront-aggregated: one __ballot, a popcount prefix and one
+// LDS atomic per wavefront.
+#pragma once
+#include "dev_trace.hpp"
+
+namespace thx {
+
+constexpr uint32_t kSchedThreads = 1024; // upper bound of the workgroup size
+constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
+
+// counters (LDS words)
+enum : int { C_CURSOR, C_FREE, C_A, C_T0, C_BM, C_M, C_TS, C_C, C_NUM = 16 };
+// stage ids == queue ids == counter ids - 1
+enum : int { S_BIRTH = 0, S_A = 1, S_T0 = 2, S_BM = 3, S_M = 4, S_TS = 5, S_C = 6, S_NUM = 7 };
+
+// photon flags (meta.z)
+constexpr uint32_t F_ALIVE = 1u, F_ALLOW = 2u, F_MIS_TARGET = 4u;
+constexpr uint32_t F_STEP_SHIFT = 8, F_STEP_MASK = 0xFFFFu << 8; // step index
+constexpr uint32_t F_PEND_SHIFT = 28, F_PEND_ONE = 1u << 28;     // outstanding shadow walks
+
+template <bool POL>
+struct StagedLayout {
+    static constexpr uint32_t NCH = POL ? 7u : 5u; // state chunks (float4) per photon
+    static constexpr uint32_t NSC = 2u;            // scratch chunks per photon
+    // dynamic LDS: [hist][state+scratch (NCH+NSC)*P float4][stack depth*T u32]
+    //              [queues: 6 x P u16, TS-queue 2P u16][counters]
+    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, uint32_t ldsNodes = 0) {
+        size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
+        return hist + (size_t)ldsNodes * 32 + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * pool * 2 + C_NUM * 4;
+    }
+    // largest pool (multiple of 64, <= 1024) that fits `budget` bytes of LDS
+    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes = 0) {
+        uint32_t p = 1024;
+        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, ldsNodes) > budget) p -= 64;
+        return p;
+    }
+};
+
+template <class V>
+struct Pool {
+    float4* st;       // [NCH][P]
+    float4* sc;       // [NSC][P]
+    uint16_t* q;      // queues
+    uint32_t* ctr;    // counters
+    uint32_t P;
+    // queue s holds slot ids; the TS queue (last) has room for 2P entries
+    THX_DEV uint16_t* queue(int s) const { return q + (size_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * P; }
+    THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[4 * P + slot]) + 2; }
+};
+
+// ---- state <-> registers -------------------------------------------------
+// chunk0 {pos.xyz, time} chunk1 {dir.xyz, wavelength} chunk2 {lin, log, medium lo, hi}
+// chunk3 {n, vg, mu_s, mu_e} chunk4 {local idx, dim, flags, distShadow}
+// chunk5 {stokes} chunk6 {polRef.xyz, -}
+template <class V>
+THX_DEV Ray loadRay(const Pool<V>& p, uint32_t s) {
+    float4 c0 = p.st[0 * p.P + s], c1 = p.st[1 * p.P + s], c2 = p.st[2 * p.P + s], c3 = p.st[3 * p.P + s];
+    Ray r;
+    r.position = f3{c0.x, c0.y, c0.z};
+    r.time = c0.w;
+    r.direction = f3{c1.x, c1.y, c1.z};
+    r.wavelength = c1.w;
+    r.lin_contrib = c2.x;
+    r.log_contrib = c2.y;
+    r.medium = (uint64_t)__float_as_uint(c2.z) | ((uint64_t)__float_as_uint(c2.w) << 32);
+    r.constants = MediumConstants{c3.x, c3.y, c3.z, c3.w};
+    r.stokes = f4{1, 0, 0, 0};
+    r.polRef = f3{0, 0, 0};
+    if constexpr (V::POL) {
+        float4 c5 = p.st[5 * p.P + s], c6 = p.st[6 * p.P + s];
+        r.stokes = f4{c5.x, c5.y, c5.z, c5.w};
+        r.polRef = f3{c6.x, c6.y, c6.z};
+    }
+    return r;
+}
+template <class V>
+THX_DEV void storeRay(const Pool<V>& p, uint32_t s, const Ray& r) {
+    p.st[0 * p.P + s] = make_float4(r.position.x, r.position.y, r.position.z, r.time);
+    p.st[1 * p.P + s] = make_float4(r.direction.x, r.direction.y, r.direction.z, r.wavelength);
+    p.st[2 * p.P + s] = make_float4(r.lin_contrib, r.log_contrib, __uint_as_float((uint32_t)r.medium),
+                                    __uint_as_float((uint32_t)(r.medium >> 32)));
+    p.st[3 * p.P + s] = make_float4(r.constants.n, r.constants.vg, r.constants.mu_s, r.constants.mu_e);
+    if constexpr (V::POL) {
+        p.st[5 * p.P + s] = make_float4(r.stokes.x, r.stokes.y, r.stokes.z, r.stokes.w);
+        p.st[6 * p.P + s] = make_float4(r.polRef.x, r.polRef.y, r.polRef.z, 0.0f);
+    }
+}
+
+struct Meta {
+    uint32_t local, dim, flags;
+    float distShadow;
+};
+template <class V>
+THX_DEV Meta loadMeta(const Pool<V>& p, uint32_t s) {
+    float4 c = p.st[4 * p.P + s];
+    return Meta{__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), c.w};
+}
+template <class V>
+THX_DEV void storeMeta(const Pool<V>& p, uint32_t s, const Meta& m) {
+    p.st[4 * p.P + s] = make_float4(__uint_as_float(m.local), __uint_as_float(m.dim), __uint_as_float(m.flags), m.distShadow);
+}
+template <class V>
+THX_DEV void bindLane(Lane<V>& L, const Meta& m) {
+    L.local = m.local;
+    L.idx = L.a->p.photon_offset + m.local;
+    L.dim = m.dim;
+}
+
+// wavefront-aggregated queue append; must be reached by all lanes of the wave
+THX_DEV uint32_t queuePush(uint32_t* counter, bool pred) {
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return 0;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
+}
+template <class V>
+THX_DEV void pushTo(const Pool<V>& p, int stage, bool pred, uint32_t entry) {
+    const uint32_t pos = queuePush(&p.ctr[stage + 1], pred);
+    if (pred) p.queue(stage)[pos] = (uint16_t)entry;
+}
+
+// TLAS root test done by the requesting stage, so rays that miss the whole scene
+// never enter the traversal queue. Same test rayQuery() starts with.
+template <class V>
+THX_DEV bool rootHit(Lane<V>& L, f3 org, f3 dir, float tmax) {
+    const SceneView& sc = L.a->scene;
+    const float4* nodes = walkNodes(L);
+    float4 n0 = nodes[2 * sc.tlasRoot], n1 = nodes[2 * sc.tlasRoot + 1];
+    f3 inv = f3{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
+    bool hit = slabNode(n0, n1, org, inv, tmax) >= 0.0f;
+    if (!hit) { // account like rayQuery would have: one query, one node fetched
+        L.cnt.add(ST_QUERIES);
+        L.cnt.add(ST_NODES);
+    }
+    return hit;
+}
+
+// end of one loop iteration of tracer.scene.forward.glsl:70-105; returns true if
+// the photon goes on to another step
+template <class V>
+THX_DEV bool endStep(Lane<V>& L, const Ray& ray, Meta& m, int result) {
+    const uint32_t step = (m.flags & F_STEP_MASK) >> F_STEP_SHIFT;
+    onEvent(L, ray, result, step);
+    if (result < 0) {
+        m.flags &= ~F_ALIVE;
+        return false;
+    }
+    bool allow = true;
+    if constexpr (V::MIS) allow = result != RESULT_CODE_RAY_SCATTERED;
+    m.flags = (m.flags & ~F_ALLOW) | (allow ? F_ALLOW : 0u);
+    if (step == L.a->path_length) {
+        onEvent(L, ray, RESULT_CODE_MAX_ITER, L.a->path_length + 1);
+        m.flags &= ~F_ALIVE;
+        return false;
+    }
+    m.flags += 1u << F_STEP_SHIFT;
+    return true;
+}
+
+// trace() after the ray query + processInteraction() (scene.traverse.glsl:324-351,
+// 361-397) for one photon; `qh` is its primary query result. Returns the next
+// stage: 1 scatter stage(s), 2 next step, 3 finished.
+template <class V>
+THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const QueryHit& qh) {
+    const LaunchArgs& args = *L.a;
+    const thx_propagate_params& prop = args.p.scene.propagation;
+    Ray ray = loadRay(pool, slot);
+    Meta m = loadMeta(pool, slot);
+    bindLane(L, m);
+    const uint32_t step = (m.flags & F_STEP_MASK) >> F_STEP_SHIFT;
+    const bool last = step == args.path_length;
+    const bool allowResponse = (m.flags & F_ALLOW) != 0u;
+    float4 s0 = pool.sc[0 * pool.P + slot];
+    float dist = s0.x;
+    const float sampledDist = s0.y;
+    SurfaceHit hit;
+    hit.valid = false;
+    int queryResult = RESULT_CODE_RAY_MISSED;
+    if (qh.valid) {
+        queryResult = processRayQuery(L, ray.direction, ray.medium, qh, hit);
+        if (hit.valid) dist = distance(ray.position, hit.worldPos);
+        if constexpr (V::MIS) {
+            if ((m.flags & F_MIS_TARGET) && hit.valid && dist > sampledDist && queryResult >= 0) {
+                processShadowRay(L, ray, hit);
+                hit.valid = false;
+                dist = sampledDist;
+            }
+        }
+    }
+    int propResult = propagateRay(ray, dist, prop);
+    updateRayIS(ray, dist, prop, hit.valid);
+    int result = queryResult <= ERROR_CODE_MAX_VALUE ? queryResult : propResult;
+    bool scatterNeeded = false;
+    if (result >= 0) {
+        if (hit.valid) {
+            result = processHit(L, ray, hit, allowResponse);
+        } else {
+            scatterNeeded = !last;
+            result = RESULT_CODE_RAY_SCATTERED;
+        }
+    }
+    storeRay(pool, slot, ray);
+    int dest;
+    if (scatterNeeded) dest = 1;
+    else dest = endStep(L, ray, m, result) ? 2 : 3;
+    m.dim = L.dim;
+    storeMeta(pool, slot, m);
+    return dest;
+}
+
+template <class V>
+__device__ void sceneStagedBody(const LaunchArgs& args) {
+    using Lay = StagedLayout<V::POL>;
+    const uint32_t T = blockDim.x;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t lane = tid & 63u;
+    const uint32_t wave = tid >> 6;
+    const uint32_t n_bins = args.n_bins;
+    const uint32_t P = args.pool;
+
+    float* hist = ldsHist();
+    const uint32_t histWords = (n_bins + 3u) & ~3u;
+    Pool<V> pool;
+    pool.P = P;
+    const uint32_t nodeWords = V::LDSBVH ? args.lds_nodes_count * 8u : 0u; // == args.lds_nodes_word - histWords
+    pool.st = reinterpret_cast<float4*>(ldsWords() + histWords + nodeWords);
+    pool.sc = pool.st + Lay::NCH * P;
+    const uint32_t stackWord0 = histWords + nodeWords + (Lay::NCH + Lay::NSC) * P * 4;
+    if constexpr (V::LDSBVH) { // stage the node array (TLAS + every BLAS) into LDS, 16 B per lane
+        const float4* src = reinterpret_cast<const float4*>(args.scene.nodes);
+        float4* dst = reinterpret_cast<float4*>(ldsWords() + args.lds_nodes_word);
+        for (uint32_t i = tid; i < args.lds_nodes_count * 2u; i += T) dst[i] = src[i];
+    }
+    pool.q = reinterpret_cast<uint16_t*>(ldsWords() + stackWord0 + args.stack_wave_words * (T >> 6));
+    pool.ctr = reinterpret_cast<uint32_t*>(pool.q + 8 * P);
+
+    // response.histogram.glsl:20-29 initResponse; every slot starts free
+    for (uint32_t i = tid; i < n_bins; i += T) hist[i] = 0.0f;
+    for (uint32_t i = tid; i < P; i += T) pool.queue(S_BIRTH)[i] = (uint16_t)i;
+    if (tid < C_NUM) pool.ctr[tid] = 0;
+
+    Lane<V> L;
+    L.a = &args;
+    L.stackBase = stackWord0 + wave * args.stack_wave_words;
+    L.cnt.clear();
+    L.idx = 0; L.local = 0; L.dim = 0;
+
+    // contiguous photon range of this workgroup
+    const uint32_t batch = args.p.dispatch.batchSize;
+    const uint64_t per = ((uint64_t)batch + gridDim.x - 1) / gridDim.x;
+    const uint64_t b64 = per * blockIdx.x;
+    const uint32_t begin = b64 < batch ? (uint32_t)b64 : batch;
+    const uint32_t end = (b64 + per) < batch ? (uint32_t)(b64 + per) : batch;
+    __syncthreads();
+    if (tid == 0) {
+        pool.ctr[C_CURSOR] = begin;
+        pool.ctr[C_FREE] = P;
+    }
+
+    const thx_propagate_params& prop = args.p.scene.propagation;
+    const uint64_t sceneMedium = (uint64_t)args.p.scene.sceneMedium[0] | ((uint64_t)args.p.scene.sceneMedium[1] << 32);
+
+#ifdef THX_STAGE_PROFILE
+    unsigned long long profT0 = 0;
+    uint32_t profStage = 15, profItems = 0;
+#endif
+    while (true) {
+        __syncthreads(); // appends of the previous round are complete
+#ifdef THX_STAGE_PROFILE
+        if (tid == 0 && args.prof) {
+            unsigned long long now = __builtin_amdgcn_s_memtime();
+            if (profStage != 15) {
+                atomicAdd(&args.prof[profStage], now - profT0);
+                atomicAdd(&args.prof[16 + profStage], 1ull);
+                atomicAdd(&args.prof[32 + profStage], (unsigned long long)profItems);
+            }
+            profT0 = now;
+        }
+#endif
+        // ---- pick the next stage (workgroup-uniform decision): the shading stage with the
+        // most waiting photons; BVH walks only once every photon of the pool waits for one,
+        // so that a walk round has as many rays in flight as possible (it is latency bound)
+        const uint32_t cursor = pool.ctr[C_CURSOR];
+        uint32_t best = min(pool.ctr[C_FREE], end - cursor), stage = S_BIRTH;
+        {
+            const int shading[4] = {S_A, S_BM, S_M, S_C};
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                uint32_t c = pool.ctr[shading[k] + 1];
+                if (c > best) { best = c; stage = (uint32_t)shading[k]; }
+            }
+        }
+        const uint32_t cT0 = pool.ctr[C_T0], cTS = pool.ctr[C_TS];
+        uint32_t n, first, n0 = 0, firstTS = 0;
+        if (best < args.shade_min && cT0 + cTS > 0) { // walk round: primary rays first, then shadow rays
+            stage = S_T0;
+            n0 = min(cT0, T);
+            const uint32_t n1 = min(cTS, T - n0);
+            n = n0 + n1;
+            first = cT0 - n0;
+            firstTS = cTS - n1;
+        } else {
+            if (best == 0) break; // nothing alive, nothing left to start
+            n = min(best, T);
+            first = pool.ctr[stage + 1] - n; // take the newest n entries of the queue
+        }
+        __syncthreads(); // everybody has read the counters
+        if (tid == 0) {
+            pool.ctr[stage + 1] = first;
+            if (stage == S_BIRTH) pool.ctr[C_CURSOR] = cursor + n;
+            if (stage == S_T0) pool.ctr[C_TS] = firstTS;
+        }
+        const bool act = tid < n;
+        uint32_t entry = 0;
+        if (act) {
+            if (stage == S_T0 && tid >= n0) entry = pool.queue(S_TS)[firstTS + (tid - n0)];
+            else entry = pool.queue((int)stage)[first + tid];
+        }
+#ifdef THX_STAGE_PROFILE
+        profStage = stage;
+        profItems = n;
+#endif
+
+        switch (stage) {
+        case S_BIRTH: { // tracer.scene.forward.glsl:50-67
+            const uint32_t slot = entry;
+            if (act) {
+                Meta m{cursor + tid, 0u, 0u, 0.0f};
+                bindLane(L, m);
+                Ray ray = sampleRay(L, sceneMedium);
+                onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
+                m.dim = L.dim;
+                // (the host guarantees path_length >= 1 for this kernel)
+                m.flags = F_ALIVE | ((args.flags & THX_FLAG_DISABLE_DIRECT) ? 0u : F_ALLOW) | (1u << F_STEP_SHIFT);
+                storeRay(pool, slot, ray);
+                storeMeta(pool, slot, m);
+            }
+            pushTo(pool, S_A, act, slot);
+            break;
+        }
+        case S_A: { // trace() up to the ray query, scene.traverse.glsl:280-310
+            const uint32_t slot = entry;
+            int dest = 0; // 1 traversal, 2 propagate-only, 3 finished
+            if (act) {
+                Ray ray = loadRay(pool, slot);
+                Meta m = loadMeta(pool, slot);
+                bindLane(L, m);
+                L.cnt.add(ST_STEPS);
+                if (isRayBad(ray)) {
+                    endStep(L, ray, m, ERROR_CODE_RAY_BAD);
+                    dest = 3;
+                } else {
+                    f3 dir = normalize(ray.direction);
+                    float dist = sampleScatterLength(ray, prop, draw(L));
+                    float sampledDist = dist;
+                    bool mis_target = false;
+                    if constexpr (V::MIS) {
+                        GuideSample gs = evalTargetGuide(args.p.guide, ray.position, dir);
+                        mis_target = (m.flags & F_ALLOW) != 0u && gs.prob > 0.0f;
+                        if (mis_target) {
+                            mis_target = gs.dist > dist;
+                            dist = fmaxf(gs.dist, dist);
+                        }
+                    }
+                    m.flags = (m.flags & ~F_MIS_TARGET) | (mis_target ? F_MIS_TARGET : 0u);
+                    pool.sc[0 * P + slot] = make_float4(dist, sampledDist, 0.0f, 0.0f);
+                    dest = rootHit(L, ray.position, dir, dist) ? 1 : 2;
+                }
+                m.dim = L.dim;
+                storeMeta(pool, slot, m);
+            }
+            pushTo(pool, S_T0, dest == 1, slot);
+            pushTo(pool, S_BM, dest == 2, slot);
+            pushTo(pool, S_BIRTH, dest == 3, slot);
+            break;
+        }
+        case S_T0: { // closest-hit walks: primary rays (which 0; a surface hit is finished here,
+                     // scene.traverse.glsl:312-351) and shadow rays (which 1, 2; :185-214)
+            const uint32_t slot = entry & 0xFFFu, which = entry >> 12;
+            int dest = 0;
+            bool lastShadow = false;
+            if (act) {
+                float4 c0 = pool.st[0 * P + slot];
+                f3 dir;
+                float tmax, weight = 0.0f;
+                if (which == 0) {
+                    float4 c1 = pool.st[1 * P + slot];
+                    dir = normalize(f3{c1.x, c1.y, c1.z});
+                    tmax = pool.sc[0 * P + slot].x;
+                } else {
+                    float4 d = pool.sc[(which - 1u) * P + slot];
+                    dir = f3{d.x, d.y, d.z};
+                    weight = d.w;
+                    tmax = pool.st[4 * P + slot].w;
+                }
+                QueryHit h = rayQuery(L, f3{c0.x, c0.y, c0.z}, dir, tmax);
+                if (which == 0) {
+                    dest = h.valid ? postPrimary(L, pool, slot, h) : 4;
+                } else {
+                    if (h.valid) {
+                        Ray s = loadRay(pool, slot); // the photon itself is not modified
+                        Meta m = loadMeta(pool, slot);
+                        bindLane(L, m);
+                        scatterRayIS(L, s, s.medium, dir);
+                        SurfaceHit hit;
+                        if (processRayQuery(L, s.direction, s.medium, h, hit) >= 0) {
+                            s.lin_contrib *= weight;
+                            processShadowRay(L, s, hit);
+                        }
+                    }
+                    uint32_t old = atomicSub(pool.flagsWord(slot), F_PEND_ONE);
+                    lastShadow = ((old >> F_PEND_SHIFT) & 3u) == 1u;
+                }
+            }
+            pushTo(pool, S_BM, dest == 4, slot);
+            pushTo(pool, V::MIS ? S_M : S_C, dest == 1, slot);
+            pushTo(pool, S_A, dest == 2, slot);
+            pushTo(pool, S_BIRTH, dest == 3, slot);
+            pushTo(pool, S_C, lastShadow, slot);
+            break;
+        }
+        case S_BM: { // photons that travel their full sampled distance
+            const uint32_t slot = entry;
+            int dest = 0;
+            if (act) {
+                QueryHit none;
+                none.valid = false; none.instance = 0; none.prim = 0; none.t = 0; none.b1 = 0; none.b2 = 0;
+                dest = postPrimary(L, pool, slot, none);
+            }
+            pushTo(pool, V::MIS ? S_M : S_C, dest == 1, slot);
+            pushTo(pool, S_A, dest == 2, slot);
+            pushTo(pool, S_BIRTH, dest == 3, slot);
+            break;
+        }
+        case S_M: { // sampleTargetMIS set-up, scene.traverse.glsl:234-262
+            const uint32_t slot = entry;
+            bool t1 = false, t2 = false;
+            if (act) {
+                Ray ray = loadRay(pool, slot);
+                Meta m = loadMeta(pool, slot);
+                bindLane(L, m);
+                float pPP;
+                float u0 = draw(L);
+                float u1 = draw(L);
+                f3 dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
+                GuideSample ts = sampleTargetGuide(L, ray.position);
+                float pTT = ts.prob;
+                GuideSample ps = evalTargetGuide(args.p.guide, ray.position, dirPhase);
+                float pTP = ps.prob;
+                float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
+                float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
+                float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
+                pool.sc[0 * P + slot] = make_float4(dirPhase.x, dirPhase.y, dirPhase.z, wPhase);
+                pool.sc[1 * P + slot] = make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget);
+                t1 = rootHit(L, ray.position, dirPhase, ps.dist);
+                t2 = rootHit(L, ray.position, ts.dir, ts.dist);
+                m.distShadow = ps.dist; // == ts.dist: both are |center - observer| + radius
+                m.dim = L.dim;
+                m.flags = (m.flags & ~(3u << F_PEND_SHIFT)) | (((t1 ? 1u : 0u) + (t2 ? 1u : 0u)) << F_PEND_SHIFT);
+                storeMeta(pool, slot, m);
+            }
+            pushTo(pool, S_TS, t1, slot | (1u << 12));
+            pushTo(pool, S_TS, t2, slot | (2u << 12));
+            pushTo(pool, S_C, act && !t1 && !t2, slot);
+            break;
+        }
+        default: { // S_C: scatterRay, scene.traverse.glsl:391, and the end of the step
+            const uint32_t slot = entry;
+            int dest = 0;
+            if (act) {
+                Ray ray = loadRay(pool, slot);
+                Meta m = loadMeta(pool, slot);
+                bindLane(L, m);
+                float u0 = draw(L);
+                float u1 = draw(L);
+                scatterRay(L, ray, ray.medium, u0, u1);
+                storeRay(pool, slot, ray);
+                dest = endStep(L, ray, m, RESULT_CODE_RAY_SCATTERED) ? 2 : 3;
+                m.dim = L.dim;
+                storeMeta(pool, slot, m);
+            }
+            pushTo(pool, S_A, dest == 2, slot);
+            pushTo(pool, S_BIRTH, dest == 3, slot);
+            break;
+        }
+        }
+    }
+
+    // response.histogram.glsl:35-45 finalizeResponse
+    __syncthreads();
+    float* slab = args.slabs + (size_t)blockIdx.x * n_bins;
+    for (uint32_t i = tid; i < n_bins; i += T) slab[i] = hist[i];
+
+    if constexpr (V::STATS) {
+#pragma unroll
+        for (int k = 0; k < THX_N_STATS; ++k) {
+            unsigned long long v = L.cnt.v[k];
+#pragma unroll
+            for (int off = 32; off > 0; off >>= 1) v += __shfl_down(v, off, 64);
+            if (lane == 0 && v != 0) atomicAdd(&args.stats[k], v);
+        }
+    }
+}
+
+} // namespace thx

@@ -8,12 +8,13 @@ namespace thx {
 
 // compile-time specialisation of one kernel variant (the reference specialises
 // through GLSL macros, trace.py:660-666 / :1226-1235)
-template <bool POL_, bool MIS_, bool STATS_, bool TRACK_>
+template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, bool LDSBVH_ = false>
 struct Variant {
-    static constexpr bool POL = POL_;     // POLARIZATION
-    static constexpr bool MIS = MIS_;     // !DISABLE_MIS
-    static constexpr bool STATS = STATS_; // EventStatisticCallback + traversal counters
-    static constexpr bool TRACK = TRACK_; // per-event dump
+    static constexpr bool POL = POL_;       // POLARIZATION
+    static constexpr bool MIS = MIS_;       // !DISABLE_MIS
+    static constexpr bool STATS = STATS_;   // EventStatisticCallback + traversal counters
+    static constexpr bool TRACK = TRACK_;   // per-event dump
+    static constexpr bool LDSBVH = LDSBVH_; // BVH nodes staged in LDS (small scenes)
 };
 
 // ray.glsl:22-36 (+163-170 polarized part)
@@ -35,9 +36,17 @@ struct LaunchArgs {
     uint32_t photons_per_wave; // contiguous photon range owned by one wavefront
     uint32_t track_events;
     uint32_t stack_depth;      // LDS traversal stack entries per lane
+    uint32_t stack_wave_words; // LDS words of one wavefront's stack block (depth*64, or depth*32 for 16-bit entries)
+    uint32_t stack16;          // 1: stack entries are 16 bit (scene has < 8190 nodes/triangles)
+    uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active
+    uint32_t pool;             // staged kernel: photons held in LDS per workgroup
+    uint32_t shade_min;        // staged kernel: walk rounds start once no shading queue holds this many photons
+    uint32_t lds_nodes_word;   // LDSBVH variants: LDS word offset of the staged node array
+    uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
     unsigned long long* stats; // [THX_N_STATS]
     float* track;              // [batch][track_events][THX_TRACK_WORDS] or null
+    unsigned long long* prof;  // staged kernel, THX_STAGE_PROFILE builds: [3][16] cycles/rounds/items per stage
     SceneView scene;
 };
 
@@ -52,7 +61,7 @@ THX_DEV uint32_t* ldsWords() { return reinterpret_cast<uint32_t*>(thx_smem); }
 template <class V>
 struct Lane {
     const LaunchArgs* a;
-    uint32_t stackBase; // word index of this lane's stack slot 0; entry e at +e*64
+    uint32_t stackBase; // LDS word index of this wavefront's stack block; entry e of lane l at e*64 + l
     Counters<V::STATS> cnt;
     uint32_t idx;   // photon index == RNG stream
     uint32_t local; // index inside the batch
@@ -131,7 +140,7 @@ THX_DEV void response(Lane<V>& L, const HitItem& item) {
 // alignment (whose first row is (1,0,0,0), so S0 is the ray's S0).
 template <class V>
 THX_DEV HitItem createHit(const Ray& r) {
-    float contrib = r.lin_contrib * expf(r.log_contrib);
+    float contrib = r.lin_contrib * thx_exp(r.log_contrib);
     if constexpr (V::POL) contrib *= r.stokes.x;
     return HitItem{r.time, contrib};
 }
@@ -175,7 +184,7 @@ THX_DEV float sampleScatterLength(const Ray& r, const thx_propagate_params& p, f
     float dist = p.maxDist;
     float sampleCoef = p.scatterCoefficient >= 0.0f ? p.scatterCoefficient : r.constants.mu_s;
     bool canScatter = r.constants.mu_s > 0.0f;
-    if (canScatter && sampleCoef != 0.0f) dist = -logf(1.0f - u) / sampleCoef;
+    if (canScatter && sampleCoef != 0.0f) dist = -thx_log(1.0f - u) / sampleCoef;
     return dist;
 }
 // ray.propagate.glsl:70-80
@@ -519,6 +528,15 @@ THX_DEV float slabNode(const float4 a, const float4 b, f3 o, f3 inv, float tmax)
 constexpr uint32_t WALK_DONE = 0xFFFFFFFFu;     // low bits 7
 constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current instance
 
+// Node array of the walk: HBM/L2 (default) or the copy staged in LDS. A divergent
+// 16-B gather costs the L1 one cycle per lane and instruction (measured: ~250 cycles
+// per wave and node pair), an LDS gather about a tenth of that.
+template <class V>
+THX_DEV const float4* walkNodes(const Lane<V>& L) {
+    if constexpr (V::LDSBVH) return reinterpret_cast<const float4*>(ldsWords() + L.a->lds_nodes_word);
+    else return reinterpret_cast<const float4*>(L.a->scene.nodes);
+}
+
 // Closest-hit query: opaque, no culling, 0 < t < tmax, committed closest triangle
 // (what scene.traverse.glsl:312-323 / :198-205 ask of the driver). Two-level
 // BVH2 with 32-B nodes; the per-lane stack lives in LDS (lane-strided so a
@@ -527,15 +545,36 @@ constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current
 template <class V>
 THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
     const SceneView& sc = L.a->scene;
-    const float4* nodes = reinterpret_cast<const float4*>(sc.nodes);
+    const float4* nodes = walkNodes(L);
     const float4* tris = reinterpret_cast<const float4*>(sc.tris);
     QueryHit h;
     h.valid = false; h.instance = 0; h.prim = 0; h.t = tmax; h.b1 = 0.0f; h.b2 = 0.0f;
     L.cnt.add(ST_QUERIES);
 
     const uint32_t depth = L.a->stack_depth;
-    uint32_t* stack = ldsWords() + L.stackBase;
+    // lane-strided LDS stack: a push/pop of the whole wave touches consecutive banks.
+    // 16-bit entries when the scene is small enough (halves the LDS footprint).
+    // (Storing entry distances for pop-time culling was measured slower: -10 % node
+    // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
+    const bool s16 = L.a->stack16 != 0u;
+    uint32_t* const stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
+    uint16_t* const stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
     uint32_t sp = 0;
+    auto push = [&](uint32_t v) {
+        if (sp >= depth) return;
+        if (s16) stack16[sp * 64] = (uint16_t)v;
+        else stack32[sp * 64] = v;
+        ++sp;
+    };
+    auto pop = [&]() -> uint32_t {
+        if (sp == 0) return WALK_DONE;
+        --sp;
+        if (s16) {
+            uint32_t v = stack16[sp * 64];
+            return v == 0xFFFEu ? WALK_SENTINEL : v;
+        }
+        return stack32[sp * 64];
+    };
     // active ray: world space in the TLAS, object space inside an instance
     f3 ao = org;
     f3 ainv = f3{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
@@ -566,21 +605,21 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
             uint32_t mr = (__float_as_uint(r0.w) << 3) | __float_as_uint(r1.w);
             if (tl >= 0.0f && tr >= 0.0f) {
                 bool leftFirst = tl <= tr;
-                if (sp < depth) { stack[sp * 64] = leftFirst ? mr : ml; ++sp; }
+                push(leftFirst ? mr : ml);
                 cur = leftFirst ? ml : mr;
             } else if (tl >= 0.0f) {
                 cur = ml;
             } else if (tr >= 0.0f) {
                 cur = mr;
             } else {
-                cur = sp > 0 ? stack[(--sp) * 64] : WALK_DONE;
+                cur = pop();
             }
         }
         if (cur == WALK_DONE) break;
         if (cur == WALK_SENTINEL) { // back to world space
             inBlas = false;
             ao = org; ainv = winv;
-            cur = sp > 0 ? stack[(--sp) * 64] : WALK_DONE;
+            cur = pop();
             continue;
         }
         uint32_t first = cur >> 3, count = cur & 7u;
@@ -600,27 +639,34 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
             ainv = f3{1.0f / od.x, 1.0f / od.y, 1.0f / od.z};
             w = woopSetup(od);
             inBlas = true;
-            if (sp < depth) { stack[sp * 64] = WALK_SENTINEL; ++sp; }
+            push(WALK_SENTINEL);
             float4 n0 = nodes[2 * blasRoot], n1 = nodes[2 * blasRoot + 1];
             L.cnt.add(ST_NODES);
             if (slabNode(n0, n1, ao, ainv, h.t) >= 0.0f)
                 cur = (__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w);
             else
-                cur = stack[(--sp) * 64]; // pops the sentinel
+                cur = pop(); // pops the sentinel
             (void)count;
         } else {
-            for (uint32_t i = 0; i < count; ++i) {
-                const float4* tr = tris + 3 * (size_t)(first + i);
-                float4 a = tr[0], b = tr[1], c = tr[2];
-                L.cnt.add(ST_TRIS);
-                if (woopTri(w, ao, f3{a.x, a.y, a.z}, f3{b.x, b.y, b.z}, f3{c.x, c.y, c.z}, h.t,
-                            h.b1, h.b2)) {
-                    h.valid = true;
-                    h.instance = curInst;
-                    h.prim = __float_as_uint(a.w);
+            // leaves hold <= 4 triangles; fetch them in pairs before testing so that a
+            // leaf costs two memory round trips instead of four (tests stay in order)
+            const float4* tr = tris + 3 * (size_t)first;
+#pragma unroll
+            for (uint32_t i0 = 0; i0 < 4; i0 += 2) {
+                if (i0 >= count) break;
+                const bool two = i0 + 1 < count;
+                float4 a0 = tr[3 * i0], b0 = tr[3 * i0 + 1], c0 = tr[3 * i0 + 2];
+                float4 a1 = a0, b1 = b0, c1 = c0;
+                if (two) { a1 = tr[3 * i0 + 3]; b1 = tr[3 * i0 + 4]; c1 = tr[3 * i0 + 5]; }
+                L.cnt.add(ST_TRIS, two ? 2u : 1u);
+                if (woopTri(w, ao, f3{a0.x, a0.y, a0.z}, f3{b0.x, b0.y, b0.z}, f3{c0.x, c0.y, c0.z}, h.t, h.b1, h.b2)) {
+                    h.valid = true; h.instance = curInst; h.prim = __float_as_uint(a0.w);
+                }
+                if (two && woopTri(w, ao, f3{a1.x, a1.y, a1.z}, f3{b1.x, b1.y, b1.z}, f3{c1.x, c1.y, c1.z}, h.t, h.b1, h.b2)) {
+                    h.valid = true; h.instance = curInst; h.prim = __float_as_uint(a1.w);
                 }
             }
-            cur = sp > 0 ? stack[(--sp) * 64] : WALK_DONE;
+            cur = pop();
         }
     }
     if (h.valid) L.cnt.add(ST_HITS);
@@ -808,7 +854,7 @@ THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
     float cosTheta = 1.0f - cosMin * draw(L);
     float sinTheta = sqrtf(fmaxf(1.0f - cosTheta * cosTheta, 0.0f));
     float phi = TWO_PI * draw(L);
-    f3 local = f3{sinTheta * sinf(phi), sinTheta * cosf(phi), cosTheta};
+    f3 local = f3{sinTheta * thx_sin(phi), sinTheta * thx_cos(phi), cosTheta};
     GuideSample s;
     s.dir = mul(createLocalCOSY(viewDir), local);
     s.dist = d + g.radius;

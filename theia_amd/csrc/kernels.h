@@ -9,18 +9,23 @@ namespace thx {
 constexpr uint32_t kTraceBlock = 256;  // threads per tracing workgroup (4 wavefronts)
 constexpr uint32_t kStackDepth = 32;   // LDS traversal stack entries per lane
 
-// dynamic LDS bytes of a tracing workgroup
-inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block) {
+// dynamic LDS bytes of a tracing workgroup (lane kernel)
+inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block, uint32_t depth, bool stack16) {
     size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
-    size_t stack = kind == THX_TRACER_SCENE_FORWARD ? (size_t)(block / 64) * kStackDepth * 64 * 4 : 0;
+    size_t stack = kind == THX_TRACER_SCENE_FORWARD ? (size_t)(block / 64) * depth * 64 * (stack16 ? 2 : 4) : 0;
     return hist + stack;
 }
+// dynamic LDS bytes of the staged scene kernel (dev_staged.hpp: StagedLayout)
+size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, uint32_t ldsNodes);
+uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes);
+constexpr uint32_t kStagedBlock = 1024;
 
 // one function pair per compiled variant (trace_variant.hip, built once per
-// KIND x POL x MIS); `debug` selects the instrumented (statistics + track) kernel
-typedef hipError_t (*trace_launch_fn)(bool debug, const LaunchArgs& args, uint32_t grid,
+// KIND x POL x MIS); mode bit 0 selects the instrumented (statistics + track) kernel,
+// bit 1 the staged scene kernel
+typedef hipError_t (*trace_launch_fn)(uint32_t mode, const LaunchArgs& args, uint32_t grid,
                                       uint32_t block, size_t lds, hipStream_t stream);
-typedef int (*trace_occupancy_fn)(bool debug, uint32_t block, size_t lds);
+typedef int (*trace_occupancy_fn)(uint32_t mode, uint32_t block, size_t lds);
 
 struct TraceVariant {
     trace_launch_fn launch;

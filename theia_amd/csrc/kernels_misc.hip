@@ -3,13 +3,14 @@
 #include <cstring>
 
 #include "kernels.h"
+#include "dev_staged.hpp"
 
 namespace thx {
 
 #define THX_DECL(k, p, m)                                                                        \
-    hipError_t traceLaunch_##k##_##p##_##m(bool, const LaunchArgs&, uint32_t, uint32_t, size_t,  \
+    hipError_t traceLaunch_##k##_##p##_##m(uint32_t, const LaunchArgs&, uint32_t, uint32_t, size_t, \
                                            hipStream_t);                                         \
-    int traceOccupancy_##k##_##p##_##m(bool, uint32_t, size_t);
+    int traceOccupancy_##k##_##p##_##m(uint32_t, uint32_t, size_t);
 THX_DECL(0, 0, 0) THX_DECL(0, 0, 1) THX_DECL(0, 1, 0) THX_DECL(0, 1, 1)
 THX_DECL(1, 0, 0) THX_DECL(1, 0, 1) THX_DECL(1, 1, 0) THX_DECL(1, 1, 1)
 #undef THX_DECL
@@ -22,6 +23,14 @@ const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis) {
 #undef THX_ENT
     return table[(kind & 1u) * 4 + (pol ? 2 : 0) + (mis ? 1 : 0)];
 }
+
+size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, uint32_t ldsNodes) {
+    return polarized ? StagedLayout<true>::bytes(n_bins, stackBytesPerThread, pool, threads, ldsNodes) : StagedLayout<false>::bytes(n_bins, stackBytesPerThread, pool, threads, ldsNodes);
+}
+uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes) {
+    return polarized ? StagedLayout<true>::poolFor(n_bins, stackBytesPerThread, budget, threads, ldsNodes) : StagedLayout<false>::poolFor(n_bins, stackBytesPerThread, budget, threads, ldsNodes);
+}
+static_assert(kStagedBlock == kSchedThreads, "staged block size");
 
 // estimator.reduce.glsl:17-35: out[b] = norm * sum_h slab[h][b] with compensated
 // (Kahan) summation. The reference walks the slabs with one thread per bin; with
@@ -93,7 +102,7 @@ __global__ void __launch_bounds__(kTraceBlock) queryKernel(LaunchArgs args, cons
     uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     Lane<V> L;
     L.a = &args;
-    L.stackBase = (threadIdx.x >> 6) * args.stack_depth * 64u + (threadIdx.x & 63u);
+    L.stackBase = (threadIdx.x >> 6) * args.stack_wave_words;
     L.idx = 0; L.local = 0; L.dim = 0;
     if (i >= n) return;
     const float* r = rays7 + 7 * (size_t)i;
@@ -113,11 +122,13 @@ hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, f
     std::memset(&a, 0, sizeof(a));
     a.scene = scene;
     a.stack_depth = kStackDepth;
+    a.stack_wave_words = kStackDepth * 64;
+    a.stack16 = 0;
     a.n_bins = 0;
     uint32_t block = kTraceBlock;
     uint32_t grid = (n + block - 1) / block;
     if (grid == 0) return hipSuccess;
-    size_t lds = (size_t)(block / 64) * kStackDepth * 64 * 4;
+    size_t lds = traceLdsBytes(THX_TRACER_SCENE_FORWARD, 0, block, kStackDepth, false);
     hipLaunchKernelGGL(queryKernel, dim3(grid), dim3(block), lds, stream, a, rays7, n, out6);
     return hipGetLastError();
 }

@@ -11,15 +11,20 @@
 // LDS float atomics into one partial histogram per workgroup, flushed to a slab
 // and summed by reduceKernel (estimator.reduce.glsl).
 #include "kernels.h"
+#include "dev_staged.hpp"
 
 #ifndef THX_KIND
 #error "THX_KIND / THX_POL / THX_MIS must be defined"
+#endif
+// register budget: minimum wavefronts per SIMD the compiler must leave room for
+#ifndef THX_WAVES_PER_SIMD
+#define THX_WAVES_PER_SIMD 2
 #endif
 
 namespace thx {
 
 template <class V, int KIND>
-__global__ void __launch_bounds__(kTraceBlock) traceKernel(const LaunchArgs args) {
+__global__ void __launch_bounds__(kTraceBlock, THX_WAVES_PER_SIMD) traceKernel(const LaunchArgs args) {
     const uint32_t tid = threadIdx.x;
     const uint32_t lane = tid & 63u;
     const uint32_t wave = tid >> 6;
@@ -33,7 +38,7 @@ __global__ void __launch_bounds__(kTraceBlock) traceKernel(const LaunchArgs args
 
     Lane<V> L;
     L.a = &args;
-    L.stackBase = ((n_bins + 3u) & ~3u) + wave * args.stack_depth * 64u + lane;
+    L.stackBase = ((n_bins + 3u) & ~3u) + wave * args.stack_wave_words;
     L.cnt.clear();
     L.idx = 0; L.local = 0; L.dim = 0;
 
@@ -55,8 +60,11 @@ __global__ void __launch_bounds__(kTraceBlock) traceKernel(const LaunchArgs args
 
     while (true) {
         // refill dead lanes from the wave's photon range
-        const unsigned long long dead = __ballot(!active);
-        if (!active) {
+        // Refill only once the wave has thinned out (refill_below active lanes or fewer):
+        // lanes reborn together stay in lock-step (same step index => same code path),
+        // which costs fewer divergent instructions than topping up every iteration.
+        const unsigned long long dead = __popcll(__ballot(active)) <= args.refill_below ? __ballot(!active) : 0ull;
+        if (!active && dead != 0ull) {
             const uint32_t rank = __popcll(dead & ((1ull << lane) - 1ull));
             const uint32_t mine = cursor + rank;
             if (mine < end) {
@@ -94,13 +102,47 @@ __global__ void __launch_bounds__(kTraceBlock) traceKernel(const LaunchArgs args
 
 using Plain = Variant<THX_POL != 0, THX_MIS != 0, false, false>;
 using Debug = Variant<THX_POL != 0, THX_MIS != 0, true, true>;
+using PlainL = Variant<THX_POL != 0, THX_MIS != 0, false, false, true>; // BVH nodes staged in LDS
+using DebugL = Variant<THX_POL != 0, THX_MIS != 0, true, true, true>;
+
+#if THX_KIND == 1
+// staged (regrouped-in-LDS) form of the scene tracer, see dev_staged.hpp
+template <class V>
+__global__ void __launch_bounds__(kSchedThreads) sceneStagedKernel(const LaunchArgs args) {
+    sceneStagedBody<V>(args);
+}
+#endif
 
 #define THX_CAT_(a, b, c, d) a##b##_##c##_##d
 #define THX_CAT(a, b, c, d) THX_CAT_(a, b, c, d)
 #define THX_FN(prefix) THX_CAT(prefix, THX_KIND, THX_POL, THX_MIS)
 
-hipError_t THX_FN(traceLaunch_)(bool debug, const LaunchArgs& args, uint32_t grid, uint32_t block,
+// mode: bit 0 = instrumented (statistics + track), bit 1 = staged kernel (scene only),
+// bit 2 = BVH nodes staged in LDS (staged kernel only)
+hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t grid, uint32_t block,
                                 size_t lds, hipStream_t stream) {
+    const bool debug = mode & 1u;
+#if THX_KIND == 1
+    if (mode & 2u) {
+        // > 64 KB of dynamic LDS needs an explicit opt-in (once per kernel)
+        const void* fn[4] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainL>), reinterpret_cast<const void*>(sceneStagedKernel<DebugL>)};
+        static bool optedIn[4] = {false, false, false, false};
+        const uint32_t k = (debug ? 1u : 0u) | ((mode & 4u) ? 2u : 0u);
+        if (!optedIn[k]) {
+            hipError_t e = hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+            if (e != hipSuccess) return e;
+            optedIn[k] = true;
+        }
+        switch (k) {
+        case 0: hipLaunchKernelGGL((sceneStagedKernel<Plain>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 1: hipLaunchKernelGGL((sceneStagedKernel<Debug>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 2: hipLaunchKernelGGL((sceneStagedKernel<PlainL>), dim3(grid), dim3(block), lds, stream, args); break;
+        default: hipLaunchKernelGGL((sceneStagedKernel<DebugL>), dim3(grid), dim3(block), lds, stream, args); break;
+        }
+        return hipGetLastError();
+    }
+#endif
     if (debug)
         hipLaunchKernelGGL((traceKernel<Debug, THX_KIND>), dim3(grid), dim3(block), lds, stream, args);
     else
@@ -108,10 +150,24 @@ hipError_t THX_FN(traceLaunch_)(bool debug, const LaunchArgs& args, uint32_t gri
     return hipGetLastError();
 }
 
-int THX_FN(traceOccupancy_)(bool debug, uint32_t block, size_t lds) {
+int THX_FN(traceOccupancy_)(uint32_t mode, uint32_t block, size_t lds) {
     int n = 0;
-    hipError_t e = debug ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, traceKernel<Debug, THX_KIND>, (int)block, lds)
-                         : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, traceKernel<Plain, THX_KIND>, (int)block, lds);
+    const bool debug = mode & 1u;
+    hipError_t e;
+#if THX_KIND == 1
+    if (mode & 2u) {
+        const uint32_t k = (debug ? 1u : 0u) | ((mode & 4u) ? 2u : 0u);
+        switch (k) {
+        case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<Plain>, (int)block, lds); break;
+        case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<Debug>, (int)block, lds); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainL>, (int)block, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugL>, (int)block, lds); break;
+        }
+        return e == hipSuccess ? n : -1;
+    }
+#endif
+    e = debug ? hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, traceKernel<Debug, THX_KIND>, (int)block, lds)
+              : hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, traceKernel<Plain, THX_KIND>, (int)block, lds);
     return e == hipSuccess ? n : -1;
 }
 

@@ -1,0 +1,33 @@
+#!/bin/bash
+# PMC passes over the tracing kernel (separate passes; no trace domains besides kernel-trace).
+# usage: tools/prof_pmc.sh <outdir-under-gpurun_out> [bench args...]
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $OUT
+export TMPDIR=/tmp
+i=0
+for set in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+  "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_SCA" \
+  "SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INST_CYCLES_VMEM SQ_INSTS_BRANCH SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_BUSY_CYCLES" \
+  "FETCH_SIZE" "WRITE_SIZE" "TCC_HIT_sum TCC_MISS_sum" "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum" "GRBM_GUI_ACTIVE"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py --no-cpu-baseline --steps 3 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "traceKernel" not in k and "reduceKernel" not in k and "Staged" not in k: continue
+        short = "trace_debug" if "true, true>" in k else ("staged" if "Staged" in k else ("trace" if "traceKernel" in k else "reduce"))
+        agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/summary.txt", "w") as fh:
+    for k, d in agg.items():
+        fh.write(f"== {k}\n")
+        for c, v in sorted(d.items()):
+            fh.write(f"{c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
+print(open(out + "/summary.txt").read())
+PY

@@ -1,0 +1,27 @@
+#!/usr/bin/env python3
+"""Per-stage cycle shares of the staged scene kernel (needs a -DTHX_STAGE_PROFILE build)."""
+import ctypes as C, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+import scenarios as S
+from theia_amd import _backend, _capi
+n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
+which = sys.argv[2] if len(sys.argv) > 2 else "config2"
+make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus}[which]
+sc = make(batch=n)
+S.run_batches(sc, 2)
+be = _backend.get()
+out = np.zeros(48, np.uint64)
+_capi.check(be._lib.thx_tracer_read_stage_profile(C.c_void_p(sc.tracer.program.handle), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+S.run_batches(sc, 1)
+ms = sc.tracer.program.last_kernel_ms(0)
+_capi.check(be._lib.thx_tracer_read_stage_profile(C.c_void_p(sc.tracer.program.handle), out.ctypes.data_as(C.POINTER(C.c_uint64))))
+names = ["BIRTH", "A", "T0", "BM", "M", "TS", "C"]
+tot = out[:7].sum()
+info = sc.tracer.program.launch_info(n)
+print(which, "kernel ms", ms, info, "total cycles/WG", tot / info["grid"])
+for i, nm in enumerate(names):
+    cyc, rounds, items = int(out[i]), int(out[16 + i]), int(out[32 + i])
+    if rounds:
+        print(f"{nm:6s} share={cyc / tot:6.1%} rounds/WG={rounds / info['grid']:7.1f} items/round={items / rounds:7.1f} cycles/round={cyc / rounds:9.0f} cycles/item={cyc / max(items,1):8.1f}")
