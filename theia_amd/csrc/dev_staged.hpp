@@ -316,7 +316,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
         const uint32_t cT0 = pool.ctr[C_T0], cTS = pool.ctr[C_TS];
         uint32_t n, first, n0 = 0, firstTS = 0;
-        if (best < args.shade_min && cT0 + cTS > 0) { // walk round: primary rays first, then shadow rays
+        // walk when a full round of rays is waiting, or when no shading queue is worth a round
+        if ((cT0 + cTS >= T * args.walk_full || best < args.shade_min) && cT0 + cTS > 0) { // primary rays first, then shadow rays
             stage = S_T0;
             n0 = min(cT0, T);
             const uint32_t n1 = min(cTS, T - n0);

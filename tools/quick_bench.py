@@ -42,6 +42,13 @@ def run(name, make, batch, reps=5, **kw):
 
 if __name__ == "__main__":
     n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20
+    only = sys.argv[2] if len(sys.argv) > 2 else ""
+    if only == "config2":
+        run("config2_sphere", S.config2_sphere, n)
+        sys.exit(0)
+    if only == "config3":
+        run("config3_cube_torus_pol", S.config3_cube_torus, n)
+        sys.exit(0)
     print(_backend.get().device_name(), _backend.get().device_info())
     run("config1_volume", S.config1_volume, n)
     run("config1_volume_pol", S.config1_volume, n, polarized=True)
