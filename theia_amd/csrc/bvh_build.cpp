@@ -7,6 +7,7 @@
 
 #include <algorithm>
 #include <cmath>
+#include <cstdlib>
 #include <cstring>
 #include <limits>
 #include <stdexcept>
@@ -210,7 +211,9 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
             for (int k = 0; k < 3; ++k) p.cen[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
         }
         std::vector<BvhNode> local;
-        auto [root, depth] = buildTree(prims, local, 4, blasLimit);
+        uint32_t leafMax = 4; // the walk tests a leaf's triangles in two pairs
+        if (const char* e = std::getenv("THX_LEAF_MAX")) leafMax = std::min(4u, std::max(1u, (uint32_t)std::atoi(e)));
+        auto [root, depth] = buildTree(prims, local, leafMax, blasLimit);
         (void)root;
         deepestBlas = std::max(deepestBlas, depth);
         // relocate into the global arrays

@@ -150,8 +150,7 @@ THX_DEV bool rootHit(Lane<V>& L, f3 org, f3 dir, float tmax) {
     const SceneView& sc = L.a->scene;
     const float4* nodes = walkNodes(L);
     float4 n0 = nodes[2 * sc.tlasRoot], n1 = nodes[2 * sc.tlasRoot + 1];
-    f3 inv = f3{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-    bool hit = slabNode(n0, n1, org, inv, tmax) >= 0.0f;
+    bool hit = slabNode(n0, n1, slabRay(org, dir), tmax) >= 0.0f;
     if (!hit) { // account like rayQuery would have: one query, one node fetched
         L.cnt.add(ST_QUERIES);
         L.cnt.add(ST_NODES);
@@ -418,7 +417,18 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     weight = d.w;
                     tmax = pool.st[4 * P + slot].w;
                 }
+#ifdef THX_STAGE_PROFILE
+                const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
+#endif
                 QueryHit h = rayQuery(L, f3{c0.x, c0.y, c0.z}, dir, tmax);
+#ifdef THX_STAGE_PROFILE
+                // per wave: cycles until the first lane / the whole wave is through the walk
+                const unsigned long long wt1 = __builtin_amdgcn_s_memtime();
+                if ((tid & 63u) == 0u && args.prof) {
+                    atomicAdd(&args.prof[8], wt1 - wt0);
+                    atomicAdd(&args.prof[10], 1ull);
+                }
+#endif
                 if (which == 0) {
                     dest = h.valid ? postPrimary(L, pool, slot, h) : 4;
                 } else {
@@ -436,6 +446,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     uint32_t old = atomicSub(pool.flagsWord(slot), F_PEND_ONE);
                     lastShadow = ((old >> F_PEND_SHIFT) & 3u) == 1u;
                 }
+#ifdef THX_STAGE_PROFILE
+                if ((tid & 63u) == 0u && args.prof) atomicAdd(&args.prof[9], __builtin_amdgcn_s_memtime() - wt1);
+#endif
             }
             pushTo(pool, S_BM, dest == 4, slot);
             pushTo(pool, V::MIS ? S_M : S_C, dest == 1, slot);

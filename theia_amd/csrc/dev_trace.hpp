@@ -516,13 +516,33 @@ THX_DEV bool woopTri(const WoopRay& w, f3 org, f3 p0, f3 p1, f3 p2, float& t_io,
     return true;
 }
 
-// slab test against a 32-B node; returns entry distance or -1 for a miss
-THX_DEV float slabNode(const float4 a, const float4 b, f3 o, f3 inv, float tmax) {
-    float tx0 = (a.x - o.x) * inv.x, tx1 = (b.x - o.x) * inv.x;
-    float ty0 = (a.y - o.y) * inv.y, ty1 = (b.y - o.y) * inv.y;
-    float tz0 = (a.z - o.z) * inv.z, tz1 = (b.z - o.z) * inv.z;
-    float tn = fmaxf(fmaxf(fminf(tx0, tx1), fminf(ty0, ty1)), fmaxf(fminf(tz0, tz1), 0.0f));
-    float tf = fminf(fminf(fmaxf(tx0, tx1), fmaxf(ty0, ty1)), fminf(fmaxf(tz0, tz1), tmax));
+// Slab test against a 32-B node; returns the entry distance or -1 for a miss.
+// The ray is kept as (1/d, -o/d) so that a plane distance is one fma, x and y of a
+// corner in one v_pk_fma_f32 (the loaded float4 holds them in an aligned register
+// pair). The boxes are padded by the builder and the interval test carries a 4e-7
+// slack, so the rounding of this form cannot drop a box that holds a hit. A NaN
+// (0 * inf for an axis-parallel ray on a plane) drops out of v_min/v_max, i.e. that
+// axis does not cull: conservative.
+typedef float v2f __attribute__((ext_vector_type(2)));
+struct SlabRay {
+    v2f inv_xy, noi_xy; // 1/d and -(o/d), x and y
+    float inv_z, noi_z;
+};
+THX_DEV SlabRay slabRay(f3 o, f3 d) {
+    SlabRay r;
+    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    r.inv_xy = v2f{ix, iy};
+    r.noi_xy = v2f{-(o.x * ix), -(o.y * iy)};
+    r.inv_z = iz;
+    r.noi_z = -(o.z * iz);
+    return r;
+}
+THX_DEV float slabNode(const float4 a, const float4 b, const SlabRay& r, float tmax) {
+    const v2f t0 = __builtin_elementwise_fma(v2f{a.x, a.y}, r.inv_xy, r.noi_xy);
+    const v2f t1 = __builtin_elementwise_fma(v2f{b.x, b.y}, r.inv_xy, r.noi_xy);
+    const float tz0 = __builtin_fmaf(a.z, r.inv_z, r.noi_z), tz1 = __builtin_fmaf(b.z, r.inv_z, r.noi_z);
+    float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
     return tn <= tf * 1.0000004f ? tn : -1.0f;
 }
 
@@ -543,31 +563,49 @@ THX_DEV const float4* walkNodes(const Lane<V>& L) {
 // BVH2 with 32-B nodes; the per-lane stack lives in LDS (lane-strided so a
 // push/pop of the whole wave touches 64 consecutive banks). A node is fetched
 // exactly once, together with its sibling, when its parent is opened.
+//
+// Walker = the resumable state of one lane's query: begin() tests the TLAS root,
+// advance() opens inner nodes until the lane holds a leaf and then handles that
+// leaf (triangles, instance entry or instance exit). rayQuery() runs one ray per
+// lane to completion; walkQueue() (dev_staged.hpp) keeps the lanes of a wave fed
+// from a queue of rays.
 template <class V>
-THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
-    const SceneView& sc = L.a->scene;
-    const float4* nodes = walkNodes(L);
-    const float4* tris = reinterpret_cast<const float4*>(sc.tris);
+struct Walker {
+    Lane<V>& L;
+    const float4* nodes;
+    const float4* tris;
+    uint32_t depth;
+    bool s16;
+    uint32_t* stack32;
+    uint16_t* stack16;
+    uint32_t sp, cur, curInst;
+    bool inBlas;
+    f3 org, dir, ao;
+    SlabRay sr, wsr;
+    WoopRay w;
     QueryHit h;
-    h.valid = false; h.instance = 0; h.prim = 0; h.t = tmax; h.b1 = 0.0f; h.b2 = 0.0f;
-    L.cnt.add(ST_QUERIES);
 
-    const uint32_t depth = L.a->stack_depth;
-    // lane-strided LDS stack: a push/pop of the whole wave touches consecutive banks.
-    // 16-bit entries when the scene is small enough (halves the LDS footprint).
-    // (Storing entry distances for pop-time culling was measured slower: -10 % node
-    // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
-    const bool s16 = L.a->stack16 != 0u;
-    uint32_t* const stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
-    uint16_t* const stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
-    uint32_t sp = 0;
-    auto push = [&](uint32_t v) {
+    THX_DEV explicit Walker(Lane<V>& lane) : L(lane) {
+        nodes = walkNodes(L);
+        tris = reinterpret_cast<const float4*>(L.a->scene.tris);
+        depth = L.a->stack_depth;
+        // 16-bit entries when the scene is small enough (halves the LDS footprint).
+        // (Storing entry distances for pop-time culling was measured slower: -10 % node
+        // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
+        s16 = L.a->stack16 != 0u;
+        stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
+        stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
+        sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false;
+        w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
+        h.valid = false; h.instance = 0; h.prim = 0; h.t = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
+    }
+    THX_DEV void push(uint32_t v) {
         if (sp >= depth) return;
         if (s16) stack16[sp * 64] = (uint16_t)v;
         else stack32[sp * 64] = v;
         ++sp;
-    };
-    auto pop = [&]() -> uint32_t {
+    }
+    THX_DEV uint32_t pop() {
         if (sp == 0) return WALK_DONE;
         --sp;
         if (s16) {
@@ -575,33 +613,43 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
             return v == 0xFFFEu ? WALK_SENTINEL : v;
         }
         return stack32[sp * 64];
-    };
-    // active ray: world space in the TLAS, object space inside an instance
-    f3 ao = org;
-    f3 ainv = f3{1.0f / dir.x, 1.0f / dir.y, 1.0f / dir.z};
-    const f3 winv = ainv;
-    WoopRay w;
-    w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
-    bool inBlas = false;
-    uint32_t curInst = 0;
+    }
+    THX_DEV bool done() const { return cur == WALK_DONE; }
 
-    uint32_t cur;
-    {
+    THX_DEV void begin(f3 o, f3 d, float tmax) {
+        const SceneView& sc = L.a->scene;
+        org = o; dir = d;
+        h.valid = false; h.instance = 0; h.prim = 0; h.t = tmax; h.b1 = 0.0f; h.b2 = 0.0f;
+        L.cnt.add(ST_QUERIES);
+        sp = 0; inBlas = false; curInst = 0;
+        // active ray: world space in the TLAS, object space inside an instance
+        ao = org;
+        sr = slabRay(org, dir);
+        wsr = sr;
         float4 n0 = nodes[2 * sc.tlasRoot], n1 = nodes[2 * sc.tlasRoot + 1];
         L.cnt.add(ST_NODES);
-        cur = slabNode(n0, n1, ao, ainv, h.t) >= 0.0f
+        cur = slabNode(n0, n1, sr, h.t) >= 0.0f
                   ? ((__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w))
                   : WALK_DONE;
     }
-    while (cur != WALK_DONE) {
+
+    // one round: inner nodes down to a leaf, then that leaf. No-op for a finished lane.
+    THX_DEV void advance() {
+        const SceneView& sc = L.a->scene;
         // open inner nodes until this lane holds a leaf
         while ((cur & 7u) == 0u) {
             uint32_t left = cur >> 3;
             float4 l0 = nodes[2 * left], l1 = nodes[2 * left + 1];
             float4 r0 = nodes[2 * left + 2], r1 = nodes[2 * left + 3];
             L.cnt.add(ST_NODES, 2);
-            float tl = slabNode(l0, l1, ao, ainv, h.t);
-            float tr = slabNode(r0, r1, ao, ainv, h.t);
+#ifdef THX_EXTRA_LOADS // experiment: what do two more 16-B gathers per visit cost?
+            {
+                float4 x0 = nodes[2 * left + 0 + THX_EXTRA_LOADS], x1 = nodes[2 * left + 1 + THX_EXTRA_LOADS];
+                if (x0.x == 12345.678f || x1.x == 12345.678f) h.t = 0.0f;
+            }
+#endif
+            float tl = slabNode(l0, l1, sr, h.t);
+            float tr = slabNode(r0, r1, sr, h.t);
             uint32_t ml = (__float_as_uint(l0.w) << 3) | __float_as_uint(l1.w);
             uint32_t mr = (__float_as_uint(r0.w) << 3) | __float_as_uint(r1.w);
             if (tl >= 0.0f && tr >= 0.0f) {
@@ -616,12 +664,12 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
                 cur = pop();
             }
         }
-        if (cur == WALK_DONE) break;
+        if (cur == WALK_DONE) return;
         if (cur == WALK_SENTINEL) { // back to world space
             inBlas = false;
-            ao = org; ainv = winv;
+            ao = org; sr = wsr;
             cur = pop();
-            continue;
+            return;
         }
         uint32_t first = cur >> 3, count = cur & 7u;
         if (!inBlas) {
@@ -637,17 +685,16 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
             f3 od = f3{(m0.x * dir.x + m0.y * dir.y) + m0.z * dir.z,
                        (m1.x * dir.x + m1.y * dir.y) + m1.z * dir.z,
                        (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
-            ainv = f3{1.0f / od.x, 1.0f / od.y, 1.0f / od.z};
+            sr = slabRay(ao, od);
             w = woopSetup(od);
             inBlas = true;
             push(WALK_SENTINEL);
             float4 n0 = nodes[2 * blasRoot], n1 = nodes[2 * blasRoot + 1];
             L.cnt.add(ST_NODES);
-            if (slabNode(n0, n1, ao, ainv, h.t) >= 0.0f)
+            if (slabNode(n0, n1, sr, h.t) >= 0.0f)
                 cur = (__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w);
             else
                 cur = pop(); // pops the sentinel
-            (void)count;
         } else {
             // leaves hold <= 4 triangles; fetch them in pairs before testing so that a
             // leaf costs two memory round trips instead of four (tests stay in order)
@@ -670,8 +717,15 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
             cur = pop();
         }
     }
-    if (h.valid) L.cnt.add(ST_HITS);
-    return h;
+};
+
+template <class V>
+THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
+    Walker<V> wk(L);
+    wk.begin(org, dir, tmax);
+    while (!wk.done()) wk.advance();
+    if (wk.h.valid) L.cnt.add(ST_HITS);
+    return wk.h;
 }
 
 // scene.types.glsl:29-57 (what the path needs of it)

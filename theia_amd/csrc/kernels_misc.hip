@@ -1,5 +1,7 @@
 // Small kernels: histogram slab reduction, RNG probe, ray-query probe; plus the
 // table that maps (kind, polarized, mis) to the separately compiled variants.
+#include <algorithm>
+#include <cstdlib>
 #include <cstring>
 
 #include "kernels.h"
@@ -116,6 +118,58 @@ __global__ void __launch_bounds__(kTraceBlock) queryKernel(LaunchArgs args, cons
     o[5] = h.b2;
 }
 
+// Development variant: every wavefront owns a chunk of consecutive rays and a lane that
+// finishes its ray takes the next one of the chunk (refill when fewer than `thr` lanes
+// are busy) -- measures what ray-length divergence costs the plain one-ray-per-lane form.
+__global__ void __launch_bounds__(kTraceBlock) queryKernelPersistent(LaunchArgs args, const float* rays7,
+                                                                     uint32_t n, float* out6,
+                                                                     uint32_t chunk, uint32_t thr) {
+    using V = Variant<false, false, false, false>;
+    Lane<V> L;
+    L.a = &args;
+    L.stackBase = (threadIdx.x >> 6) * args.stack_wave_words;
+    L.idx = 0; L.local = 0; L.dim = 0;
+    const uint32_t wave = (blockIdx.x * blockDim.x + threadIdx.x) >> 6;
+    const uint32_t lane = threadIdx.x & 63u;
+    uint32_t next = wave * chunk;                 // wave-uniform
+    const uint32_t end = min(n, next + chunk);
+    Walker<V> wk(L);
+    uint32_t mine = 0xFFFFFFFFu;
+    for (;;) {
+        const bool idle = wk.done();
+        const uint64_t im = __ballot(idle);
+        if (next < end && im) {
+            const uint32_t rank = __popcll(im & ((1ull << lane) - 1ull));
+            const uint32_t cand = next + rank;
+            if (idle && mine != 0xFFFFFFFFu) {
+                float* o = out6 + 6 * (size_t)mine;
+                o[0] = wk.h.valid ? 1.0f : 0.0f; o[1] = (float)wk.h.instance; o[2] = (float)wk.h.prim;
+                o[3] = wk.h.t; o[4] = wk.h.b1; o[5] = wk.h.b2;
+                mine = 0xFFFFFFFFu;
+            }
+            if (idle && cand < end) {
+                const float* r = rays7 + 7 * (size_t)cand;
+                mine = cand;
+                wk.begin(f3{r[0], r[1], r[2]}, f3{r[3], r[4], r[5]}, r[6]);
+            }
+            next = min(end, next + (uint32_t)__popcll(im));
+        }
+        uint64_t act = __ballot(!wk.done());
+        if (!act) break;
+        const uint32_t need = next < end ? thr : 1u;
+        while ((uint32_t)__popcll(act) >= need) {
+            wk.advance();
+            act = __ballot(!wk.done());
+            if (!act) break;
+        }
+    }
+    if (mine != 0xFFFFFFFFu) {
+        float* o = out6 + 6 * (size_t)mine;
+        o[0] = wk.h.valid ? 1.0f : 0.0f; o[1] = (float)wk.h.instance; o[2] = (float)wk.h.prim;
+        o[3] = wk.h.t; o[4] = wk.h.b1; o[5] = wk.h.b2;
+    }
+}
+
 hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, float* out6,
                        hipStream_t stream) {
     LaunchArgs a;
@@ -129,6 +183,21 @@ hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, f
     uint32_t grid = (n + block - 1) / block;
     if (grid == 0) return hipSuccess;
     size_t lds = traceLdsBytes(THX_TRACER_SCENE_FORWARD, 0, block, kStackDepth, false);
+    if (const char* e = std::getenv("THX_QUERY_DEPTH")) { // development: smaller u16 stacks -> more waves per CU
+        uint32_t d = std::min(32, std::max(4, std::atoi(e)));
+        a.stack_depth = d;
+        a.stack16 = 1;
+        a.stack_wave_words = d * 32;
+        lds = (size_t)(block / 64) * d * 128;
+    }
+    if (const char* e = std::getenv("THX_QUERY_CHUNK")) {
+        uint32_t chunk = std::max(64, std::atoi(e)), thr = 48;
+        if (const char* t = std::getenv("THX_QUERY_THR")) thr = std::min(64, std::max(1, std::atoi(t)));
+        uint32_t waves = (n + chunk - 1) / chunk;
+        grid = (waves * 64 + block - 1) / block;
+        hipLaunchKernelGGL(queryKernelPersistent, dim3(grid), dim3(block), lds, stream, a, rays7, n, out6, chunk, thr);
+        return hipGetLastError();
+    }
     hipLaunchKernelGGL(queryKernel, dim3(grid), dim3(block), lds, stream, a, rays7, n, out6);
     return hipGetLastError();
 }

@@ -25,3 +25,7 @@ for i, nm in enumerate(names):
     cyc, rounds, items = int(out[i]), int(out[16 + i]), int(out[32 + i])
     if rounds:
         print(f"{nm:6s} share={cyc / tot:6.1%} rounds/WG={rounds / info['grid']:7.1f} items/round={items / rounds:7.1f} cycles/round={cyc / rounds:9.0f} cycles/item={cyc / max(items,1):8.1f}")
+
+if out[10]:
+    r = int(out[16 + 2])
+    print(f"T0 detail: waves/round={int(out[10]) / r:.1f} walk cycles/wave={int(out[8]) / int(out[10]):.0f} post cycles/wave={int(out[9]) / int(out[10]):.0f} round={int(out[2]) / r:.0f}")
