@@ -63,8 +63,7 @@ struct thx_tracer {
     uint32_t stackDepth = kStackDepth;
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
-    uint32_t shadeMin = 128;      // staged kernel: see LaunchArgs::shade_min (tuned on MI355X)
-    uint32_t walkFull = 1000;     // staged kernel: see LaunchArgs::walk_full
+    uint32_t takeMin = 1;         // staged kernel: see LaunchArgs::take_min (tuned on MI355X)
     uint32_t ldsNodes = 0;        // staged kernel: BVH nodes staged in LDS (0 = walk reads HBM/L2)
     uint32_t block = kTraceBlock;
     size_t lds = 0;
@@ -357,8 +356,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         t->ldsNodes = scene->info.n_nodes <= ldsNodeLimit ? scene->info.n_nodes : 0u;
         if (t->ldsNodes) t->mode |= 4u;
         t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, t->ldsNodes);
-        if (const char* env = std::getenv("THX_WALK_FULL")) t->walkFull = (uint32_t)std::max(1, std::atoi(env));
-        if (const char* env = std::getenv("THX_SHADE_MIN")) t->shadeMin = (uint32_t)std::max(1, std::atoi(env));
+        if (const char* env = std::getenv("THX_TAKE_MIN")) t->takeMin = (uint32_t)std::min(64, std::max(1, std::atoi(env)));
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(1024, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
     } else {
@@ -464,8 +462,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stack16 = t->stack16 ? 1u : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;
-    a.shade_min = t->shadeMin;
-    a.walk_full = t->walkFull;
+    a.take_min = t->takeMin;
     a.lds_nodes_count = t->ldsNodes;
     a.lds_nodes_word = (t->desc.n_bins + 3u) & ~3u;
     a.slabs = t->slabs[cfg];

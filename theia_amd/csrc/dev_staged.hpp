@@ -12,14 +12,18 @@
 //     BIRTH -> A (free path, guide) -> T0 (primary BVH walk + surface hit)
 //           -> BM (propagate, no hit) -> M (MIS sampling)
 //           -> TS (shadow-ray walk + detector response) -> C (scatter) -> A ...
-// Each round the workgroup runs the stage with the most waiting photons, on up to
-// blockDim.x of them, one photon per lane: wavefronts are dense, thin stages simply
-// wait until enough photons have piled up. Photons are independent and carry their own
-// RNG stream (= photon index) and dimension, so the order in which they advance
-// does not change any per-photon result; arithmetic, draw order and event order
-// are those of the lane kernel (the stage bodies call the same device functions).
-// Queue appends are wavefront-aggregated: one __ballot, a popcount prefix and one
-// LDS atomic per wavefront.
+// Every wavefront schedules itself: it claims up to 64 entries of the fullest queue
+// (one CAS on the queue head by lane 0), runs that stage on them, one photon per
+// lane, appends the photons to their next queues and looks for work again. There is
+// no workgroup barrier inside the loop, so BVH walks (gather/latency heavy) and the
+// shading stages (VALU heavy) of different wavefronts overlap on a SIMD and nobody
+// waits for the slowest wavefront of a round. Photons are independent and carry
+// their own RNG stream (= photon index) and dimension, so the order in which they
+// advance does not change any per-photon result; arithmetic, draw order and event
+// order are those of the lane kernel (the stage bodies call the same device
+// functions). Queues are rings of 16-bit entries in LDS with a cell hand-off
+// (EMPTY <-> entry) between the appending and the claiming wavefront; appends are
+// wavefront-aggregated: one __ballot, a popcount prefix and one LDS atomic.
 #pragma once
 #include "dev_trace.hpp"
 
@@ -28,10 +32,14 @@ namespace thx {
 constexpr uint32_t kSchedThreads = 1024; // upper bound of the workgroup size
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 
-// counters (LDS words)
-enum : int { C_CURSOR, C_FREE, C_A, C_T0, C_BM, C_M, C_TS, C_C, C_NUM = 16 };
-// stage ids == queue ids == counter ids - 1
+// stage ids == queue ids. The BIRTH queue is the free list of pool slots.
 enum : int { S_BIRTH = 0, S_A = 1, S_T0 = 2, S_BM = 3, S_M = 4, S_TS = 5, S_C = 6, S_NUM = 7 };
+// counters (LDS words): ring head (claimed up to) and tail (appended up to) per queue,
+// monotonic; then the photon cursor, the number of wavefronts inside a stage, the abort flag
+enum : int { C_HEAD = 0, C_TAIL = 8, C_CURSOR = 16, C_BUSY = 17, C_ABORT = 18, C_NUM = 32 };
+constexpr uint32_t Q_EMPTY = 0xFFFFu;  // ring cell without an entry (slot ids are < 4096 + which << 12)
+constexpr uint32_t kIdleSpinLimit = 1u << 18; // x s_sleep(8): ~50 ms without any work appearing -> abort
+constexpr uint32_t kCellSpinLimit = 1u << 22;
 
 // photon flags (meta.z)
 constexpr uint32_t F_ALIVE = 1u, F_ALLOW = 2u, F_MIS_TARGET = 4u;
@@ -42,11 +50,17 @@ template <bool POL>
 struct StagedLayout {
     static constexpr uint32_t NCH = POL ? 7u : 5u; // state chunks (float4) per photon
     static constexpr uint32_t NSC = 2u;            // scratch chunks per photon
-    // dynamic LDS: [hist][state+scratch (NCH+NSC)*P float4][stack depth*T u32]
-    //              [queues: 6 x P u16, TS-queue 2P u16][counters]
+    // ring capacity of a queue: power of two >= pool (the TS ring takes two of them)
+    static constexpr uint32_t qcap(uint32_t pool) {
+        uint32_t c = 64;
+        while (c < pool) c <<= 1;
+        return c;
+    }
+    // dynamic LDS: [hist][nodes][state+scratch (NCH+NSC)*P float4][stack depth*T]
+    //              [rings: 6 x qcap u16, TS ring 2 qcap u16][counters]
     static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, uint32_t ldsNodes = 0) {
         size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
-        return hist + (size_t)ldsNodes * 32 + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * pool * 2 + C_NUM * 4;
+        return hist + (size_t)ldsNodes * 32 + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool) * 2 + C_NUM * 4;
     }
     // largest pool (multiple of 64, <= 1024) that fits `budget` bytes of LDS
     static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes = 0) {
@@ -60,11 +74,12 @@ template <class V>
 struct Pool {
     float4* st;       // [NCH][P]
     float4* sc;       // [NSC][P]
-    uint16_t* q;      // queues
+    uint16_t* q;      // rings
     uint32_t* ctr;    // counters
-    uint32_t P;
-    // queue s holds slot ids; the TS queue (last) has room for 2P entries
-    THX_DEV uint16_t* queue(int s) const { return q + (size_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * P; }
+    uint32_t P, cap;  // pool size, ring capacity (power of two >= P)
+    // ring s holds slot ids; the TS ring (last) has room for 2 cap entries (two shadow rays per photon)
+    THX_DEV volatile uint16_t* queue(int s) const { return q + (size_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * cap; }
+    THX_DEV uint32_t mask(int s) const { return (s == S_TS ? 2u * cap : cap) - 1u; }
     THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[4 * P + slot]) + 2; }
 };
 
@@ -126,21 +141,27 @@ THX_DEV void bindLane(Lane<V>& L, const Meta& m) {
     L.dim = m.dim;
 }
 
-// wavefront-aggregated queue append; must be reached by all lanes of the wave
-THX_DEV uint32_t queuePush(uint32_t* counter, bool pred) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return 0;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)m) - 1;
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(counter, (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    return base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull));
-}
+// wavefront-aggregated ring append; must be reached by all lanes of the wave. Everything
+// the stage wrote for the photon (pool state, scratch, flags) is ordered before the entry
+// becomes visible: LDS operations of a wavefront execute in issue order, the fence keeps
+// the compiler from moving them.
 template <class V>
 THX_DEV void pushTo(const Pool<V>& p, int stage, bool pred, uint32_t entry) {
-    const uint32_t pos = queuePush(&p.ctr[stage + 1], pred);
-    if (pred) p.queue(stage)[pos] = (uint16_t)entry;
+    const unsigned long long m = __ballot(pred);
+    if (m == 0ull) return;
+    const uint32_t lane = threadIdx.x & 63u;
+    const int leader = __ffsll((long long)m) - 1;
+    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+    uint32_t base = 0;
+    if ((int)lane == leader) base = atomicAdd(&p.ctr[C_TAIL + stage], (uint32_t)__popcll(m));
+    base = __shfl(base, leader, 64);
+    if (pred) {
+        volatile uint16_t* cell = p.queue(stage) + ((base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & p.mask(stage));
+        // the claimer of the previous lap has normally long emptied the cell
+        for (uint32_t spin = 0; *cell != Q_EMPTY; ++spin)
+            if (spin > kCellSpinLimit) { p.ctr[C_ABORT] = 1u; break; }
+        *cell = (uint16_t)entry;
+    }
 }
 
 // TLAS root test done by the requesting stage, so rays that miss the whole scene
@@ -255,12 +276,12 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         for (uint32_t i = tid; i < args.lds_nodes_count * 2u; i += T) dst[i] = src[i];
     }
     pool.q = reinterpret_cast<uint16_t*>(ldsWords() + stackWord0 + args.stack_wave_words * (T >> 6));
-    pool.ctr = reinterpret_cast<uint32_t*>(pool.q + 8 * P);
+    pool.cap = Lay::qcap(P);
+    pool.ctr = reinterpret_cast<uint32_t*>(pool.q + 8 * pool.cap);
 
     // response.histogram.glsl:20-29 initResponse; every slot starts free
     for (uint32_t i = tid; i < n_bins; i += T) hist[i] = 0.0f;
-    for (uint32_t i = tid; i < P; i += T) pool.queue(S_BIRTH)[i] = (uint16_t)i;
-    if (tid < C_NUM) pool.ctr[tid] = 0;
+    for (uint32_t i = tid; i < 8 * pool.cap; i += T) pool.q[i] = (uint16_t)(i < P ? i : Q_EMPTY);
 
     Lane<V> L;
     L.a = &args;
@@ -274,82 +295,109 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const uint64_t b64 = per * blockIdx.x;
     const uint32_t begin = b64 < batch ? (uint32_t)b64 : batch;
     const uint32_t end = (b64 + per) < batch ? (uint32_t)(b64 + per) : batch;
+    if (tid < C_NUM) pool.ctr[tid] = tid == C_TAIL + S_BIRTH ? P : (tid == C_CURSOR ? begin : 0u);
     __syncthreads();
-    if (tid == 0) {
-        pool.ctr[C_CURSOR] = begin;
-        pool.ctr[C_FREE] = P;
-    }
 
     const thx_propagate_params& prop = args.p.scene.propagation;
     const uint64_t sceneMedium = (uint64_t)args.p.scene.sceneMedium[0] | ((uint64_t)args.p.scene.sceneMedium[1] << 32);
+    volatile uint32_t* const ctr = pool.ctr;
+    const uint32_t takeMin = min(max(args.take_min, 1u), 64u);
 
 #ifdef THX_STAGE_PROFILE
-    unsigned long long profT0 = 0;
-    uint32_t profStage = 15, profItems = 0;
+    unsigned long long profIdle0 = __builtin_amdgcn_s_memtime();
 #endif
+    uint32_t idleSpins = 0;
     while (true) {
-        __syncthreads(); // appends of the previous round are complete
-#ifdef THX_STAGE_PROFILE
-        if (tid == 0 && args.prof) {
-            unsigned long long now = __builtin_amdgcn_s_memtime();
-            if (profStage != 15) {
-                atomicAdd(&args.prof[profStage], now - profT0);
-                atomicAdd(&args.prof[16 + profStage], 1ull);
-                atomicAdd(&args.prof[32 + profStage], (unsigned long long)profItems);
-            }
-            profT0 = now;
-        }
-#endif
-        // ---- pick the next stage (workgroup-uniform decision): the shading stage with the
-        // most waiting photons; BVH walks only once every photon of the pool waits for one,
-        // so that a walk round has as many rays in flight as possible (it is latency bound)
-        const uint32_t cursor = pool.ctr[C_CURSOR];
-        uint32_t best = min(pool.ctr[C_FREE], end - cursor), stage = S_BIRTH;
-        {
-            const int shading[4] = {S_A, S_BM, S_M, S_C};
+        // ---- lane 0 looks for work: the fullest queue (both walk queues count as one)
+        // if it fills the wavefront; a thinner batch only when nothing fuller can show up
+        // (no wavefront is inside a stage) or it has at least `takeMin` entries.
+        // claim[0] = stage (S_NUM: nothing now, S_NUM + 1: leave), claim[1..4] = h0, n0, h1, n1
+        uint32_t cStage = S_NUM, cH0 = 0, cN0 = 0, cH1 = 0, cN1 = 0;
+        if (lane == 0) {
+            if (ctr[C_ABORT] != 0u) {
+                cStage = S_NUM + 1;
+            } else {
+                uint32_t cnt[S_NUM], head[S_NUM];
 #pragma unroll
-            for (int k = 0; k < 4; ++k) {
-                uint32_t c = pool.ctr[shading[k] + 1];
-                if (c > best) { best = c; stage = (uint32_t)shading[k]; }
+                for (int q = 0; q < S_NUM; ++q) {
+                    head[q] = ctr[C_HEAD + q];
+                    cnt[q] = ctr[C_TAIL + q] - head[q];
+                }
+                const uint32_t cursor = ctr[C_CURSOR];
+                const uint32_t freeSlots = cnt[S_BIRTH];
+                cnt[S_BIRTH] = min(freeSlots, cursor < end ? end - cursor : 0u);
+                if (cursor >= end && freeSlots == P) {
+                    cStage = S_NUM + 1; // every photon of the range is finished
+                } else {
+                    const uint32_t walk = cnt[S_T0] + cnt[S_TS];
+                    uint32_t best = walk, stage = S_T0;
+                    const int shading[5] = {S_A, S_BM, S_M, S_C, S_BIRTH};
+#pragma unroll
+                    for (int k = 0; k < 5; ++k)
+                        if (cnt[shading[k]] > best) { best = cnt[shading[k]]; stage = (uint32_t)shading[k]; }
+                    if (best >= 64u || (best > 0u && (best >= takeMin || ctr[C_BUSY] == 0u))) {
+                        if (stage == S_T0) {
+                            // primary rays first, then shadow rays (two rings, two claims)
+                            const uint32_t n0 = min(cnt[S_T0], 64u);
+                            if (n0 == 0u || atomicCAS(&pool.ctr[C_HEAD + S_T0], head[S_T0], head[S_T0] + n0) == head[S_T0]) {
+                                cN0 = n0; cH0 = head[S_T0];
+                                const uint32_t n1 = min(cnt[S_TS], 64u - n0);
+                                if (n1 > 0u && atomicCAS(&pool.ctr[C_HEAD + S_TS], head[S_TS], head[S_TS] + n1) == head[S_TS]) {
+                                    cN1 = n1; cH1 = head[S_TS];
+                                }
+                                if (cN0 + cN1 > 0u) cStage = S_T0;
+                            }
+                        } else {
+                            const uint32_t n0 = min(best, 64u);
+                            if (atomicCAS(&pool.ctr[C_HEAD + stage], head[stage], head[stage] + n0) == head[stage]) {
+                                cN0 = n0; cH0 = head[stage]; cStage = stage;
+                                // photon indices of a birth batch; beyond `end` the slot goes back
+                                if (stage == S_BIRTH) cH1 = atomicAdd(&pool.ctr[C_CURSOR], n0);
+                            }
+                        }
+                        if (cStage < (uint32_t)S_NUM) atomicAdd(&pool.ctr[C_BUSY], 1u);
+                    }
+                }
             }
         }
-        const uint32_t cT0 = pool.ctr[C_T0], cTS = pool.ctr[C_TS];
-        uint32_t n, first, n0 = 0, firstTS = 0;
-        // walk when a full round of rays is waiting, or when no shading queue is worth a round
-        if ((cT0 + cTS >= T * args.walk_full || best < args.shade_min) && cT0 + cTS > 0) { // primary rays first, then shadow rays
-            stage = S_T0;
-            n0 = min(cT0, T);
-            const uint32_t n1 = min(cTS, T - n0);
-            n = n0 + n1;
-            first = cT0 - n0;
-            firstTS = cTS - n1;
-        } else {
-            if (best == 0) break; // nothing alive, nothing left to start
-            n = min(best, T);
-            first = pool.ctr[stage + 1] - n; // take the newest n entries of the queue
+        const uint32_t stage = __builtin_amdgcn_readfirstlane(cStage);
+        if (stage == (uint32_t)S_NUM + 1u) break;
+        if (stage == (uint32_t)S_NUM) { // nothing to do right now
+            if (++idleSpins > kIdleSpinLimit) {
+                if (lane == 0) ctr[C_ABORT] = 1u;
+                break;
+            }
+            __builtin_amdgcn_s_sleep(8);
+            continue;
         }
-        __syncthreads(); // everybody has read the counters
-        if (tid == 0) {
-            pool.ctr[stage + 1] = first;
-            if (stage == S_BIRTH) pool.ctr[C_CURSOR] = cursor + n;
-            if (stage == S_T0) pool.ctr[C_TS] = firstTS;
-        }
-        const bool act = tid < n;
+        idleSpins = 0;
+        const uint32_t h0 = __builtin_amdgcn_readfirstlane(cH0), n0 = __builtin_amdgcn_readfirstlane(cN0);
+        const uint32_t h1 = __builtin_amdgcn_readfirstlane(cH1), n1 = __builtin_amdgcn_readfirstlane(cN1);
+        const uint32_t n = stage == (uint32_t)S_T0 ? n0 + n1 : n0;
+        bool act = lane < n;
         uint32_t entry = 0;
         if (act) {
-            if (stage == S_T0 && tid >= n0) entry = pool.queue(S_TS)[firstTS + (tid - n0)];
-            else entry = pool.queue((int)stage)[first + tid];
+            const int q = (stage == (uint32_t)S_T0 && lane >= n0) ? S_TS : (int)stage;
+            volatile uint16_t* cell = pool.queue(q) + ((q == S_TS && stage == (uint32_t)S_T0 ? h1 + (lane - n0) : h0 + lane) & pool.mask(q));
+            entry = *cell;
+            for (uint32_t spin = 0; entry == Q_EMPTY; ++spin) { // appended, not written yet
+                if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; entry = 0; act = false; break; }
+                entry = *cell;
+            }
+            *cell = (uint16_t)Q_EMPTY;
         }
+        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef THX_STAGE_PROFILE
-        profStage = stage;
-        profItems = n;
+        const unsigned long long profT0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && args.prof) atomicAdd(&args.prof[7], profT0 - profIdle0);
 #endif
 
         switch (stage) {
         case S_BIRTH: { // tracer.scene.forward.glsl:50-67
             const uint32_t slot = entry;
-            if (act) {
-                Meta m{cursor + tid, 0u, 0u, 0.0f};
+            const bool born = act && h1 + lane < end; // h1 = first photon index of this batch
+            if (born) {
+                Meta m{h1 + lane, 0u, 0u, 0.0f};
                 bindLane(L, m);
                 Ray ray = sampleRay(L, sceneMedium);
                 onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
@@ -359,7 +407,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 storeRay(pool, slot, ray);
                 storeMeta(pool, slot, m);
             }
-            pushTo(pool, S_A, act, slot);
+            pushTo(pool, S_A, born, slot);
+            pushTo(pool, S_BIRTH, act && !born, slot);
             break;
         }
         case S_A: { // trace() up to the ray query, scene.traverse.glsl:280-310
@@ -522,12 +571,23 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             break;
         }
         }
+        if (lane == 0) atomicSub(&pool.ctr[C_BUSY], 1u);
+#ifdef THX_STAGE_PROFILE
+        profIdle0 = __builtin_amdgcn_s_memtime();
+        if (lane == 0 && args.prof) {
+            atomicAdd(&args.prof[stage], profIdle0 - profT0);
+            atomicAdd(&args.prof[16 + stage], 1ull);
+            atomicAdd(&args.prof[32 + stage], (unsigned long long)n);
+        }
+#endif
     }
-
     // response.histogram.glsl:35-45 finalizeResponse
     __syncthreads();
+    // a tripped scheduler watchdog (a bug, never seen) poisons the light curve instead of
+    // returning a plausible partial one
+    const bool aborted = ctr[C_ABORT] != 0u;
     float* slab = args.slabs + (size_t)blockIdx.x * n_bins;
-    for (uint32_t i = tid; i < n_bins; i += T) slab[i] = hist[i];
+    for (uint32_t i = tid; i < n_bins; i += T) slab[i] = aborted ? __uint_as_float(0x7FC00000u) : hist[i];
 
     if constexpr (V::STATS) {
 #pragma unroll
