@@ -140,7 +140,7 @@ def config3_cube_torus(batch: int = 1_000_000, *, polarized: bool = True, stats:
                     response=response, rng=rng, guide=guide, tracer=tracer, callback=callback)
 
 
-def config5_suzanne_grid(batch: int = 1_000_000, *, polarized: bool = True, stats: bool = False, n_side: int = 10,
+def config5_suzanne_grid(batch: int = 1_000_000, *, polarized: bool = True, stats: bool = False, track: bool = False, n_side: int = 10,
                          maxPathLength: int = 20, key: int = 42) -> Scenario:
     """BASELINE config 5: suzanne x n_side^3 instances (BK7) + sphere detector."""
     water = WaterTestModel().createMedium(400.0 * u.nm, 800.0 * u.nm, name="water")
@@ -157,18 +157,22 @@ def config5_suzanne_grid(batch: int = 1_000_000, *, polarized: bool = True, stat
                 angle = gen.uniform(0.0, 360.0)
                 t = Transform.TRS(scale=1.0, rotate=(0.0, 0.0, 1.0, angle), translate=(ix * pitch, iy * pitch, iz * pitch))
                 instances.append(meshes.createInstance("suzanne", "glass", t))
+    # detector and light sit in the voids between the monkeys (cell centres of the grid):
+    # the detector in the central cell, the light one cell down the diagonal, so that the
+    # line of sight between them passes through the monkey at the shared grid point
     c = 0.5 * (n_side - 1) * pitch
-    det_pos = (c + 2.0, c + 2.0, c + 2.0)
+    det_pos = (c, c, c)
     instances.append(meshes.createInstance("sphere", "det", Transform.TRS(scale=1.0, translate=det_pos), detectorId=1))
     scene = Scene(instances, store.material, medium=store.media["water"])
     photons = UniformWavelengthSource(lambdaRange=(400.0 * u.nm, 800.0 * u.nm))
-    light = SphericalLightSource(position=(c - 2.0, c - 2.0, c - 2.0), timeRange=(0.0, 10.0) * u.ns, budget=1.0e5)
+    light = SphericalLightSource(position=(c - pitch, c - pitch, c - pitch), timeRange=(0.0, 10.0) * u.ns, budget=1.0e5)
     guide = SphereTargetGuide(position=det_pos, radius=1.0 * u.m)
     response = HistogramHitResponse(UniformValueResponse(), nBins=100, binSize=5.0 * u.ns)
     rng = PhiloxRNG(key=key)
     callback = EventStatisticCallback() if stats else EmptyEventCallback()
     tracer = SceneForwardTracer(batch, light, photons, response, rng, scene, maxPathLength=maxPathLength, targetId=1,
-                                targetGuide=guide, scatterCoefficient=0.05 / u.m, polarized=polarized, callback=callback)
+                                targetGuide=guide, scatterCoefficient=0.05 / u.m, polarized=polarized, callback=callback,
+                                trackEvents=track)
     rng.autoAdvance = tracer.nRNGSamples
     return Scenario(name="config5_suzanne_grid", store=store, meshes=meshes, scene=scene, light=light, photons=photons,
                     response=response, rng=rng, guide=guide, tracer=tracer, callback=callback)

@@ -165,6 +165,16 @@ def test_scene_tracer_parity_cube_torus(hip_backend):
     _compare(res, n)
 
 
+def test_scene_tracer_parity_suzanne_grid(hip_backend):
+    """BASELINE config 5 at reduced size: 4^3 instanced (non-manifold) suzannes of glass around a
+    detector sphere, polarized, path length 20 -- deep two-level walks, refraction chains, media
+    mismatches counted on both sides"""
+    n = 8000
+    res = _both(S.config5_suzanne_grid, batch=n, n_side=4, polarized=True, stats=True, track=True)
+    assert res[0][2][11] > 0  # the oracle sees media mismatches (suzanne's eyes are separate shells)
+    _compare(res, n, code_agree=0.99)
+
+
 def test_production_kernel_equals_instrumented(hip_backend):
     """the un-instrumented kernel (what bench.py times) produces the same light curve"""
     n = 50000

@@ -49,6 +49,9 @@ if __name__ == "__main__":
     if only == "config3":
         run("config3_cube_torus_pol", S.config3_cube_torus, n)
         sys.exit(0)
+    if only == "config5":
+        run("config5_suzanne_grid_pol", S.config5_suzanne_grid, n)
+        sys.exit(0)
     print(_backend.get().device_name(), _backend.get().device_info())
     run("config1_volume", S.config1_volume, n)
     run("config1_volume_pol", S.config1_volume, n, polarized=True)
