@@ -350,18 +350,28 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         size_t budget = (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor - 2048; // whole CU, one workgroup
         if (const char* env = std::getenv("THX_POOL_LDS_KB")) budget = (size_t)std::max(16, std::atoi(env)) * 1024;
         const uint32_t stackBytes = t->stackDepth * (t->stack16 ? 2u : 4u);
-        // stage the node array in LDS when it is small (<= 48 KB): LDS gathers are ~10x cheaper than L1 gathers
-        uint32_t ldsNodeLimit = 48 * 1024 / 32;
-        if (const char* env = std::getenv("THX_LDS_NODES")) ldsNodeLimit = (uint32_t)std::max(0, std::atoi(env));
-        t->ldsNodes = scene->info.n_nodes <= ldsNodeLimit ? scene->info.n_nodes : 0u;
-        if (t->ldsNodes) t->mode |= 4u;
-        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, t->ldsNodes);
+        // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %,
+        // nodes gathered from LDS instead of the vector cache 4.5 %. So the node array is
+        // staged in LDS only when that costs no pool slot (THX_LDS_NODES=<max nodes> forces it).
+        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0);
+        t->ldsNodes = 0;
+        const uint32_t withNodes = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, scene->info.n_nodes);
+        bool stage = withNodes == t->pool;
+        if (const char* env = std::getenv("THX_LDS_NODES")) stage = scene->info.n_nodes <= (uint32_t)std::max(0, std::atoi(env));
+        if (stage) {
+            t->ldsNodes = scene->info.n_nodes;
+            t->pool = withNodes;
+            t->mode |= 4u;
+        }
         if (const char* env = std::getenv("THX_TAKE_MIN")) t->takeMin = (uint32_t)std::min(64, std::max(1, std::atoi(env)));
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(1024, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
     } else {
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
     }
+    if (std::getenv("THX_VERBOSE"))
+        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u stack16=%d ldsNodes=%u takeMin=%u\n",
+                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, (int)t->stack16, t->ldsNodes, t->takeMin);
     int perCU = t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
     uint32_t mult = 1;

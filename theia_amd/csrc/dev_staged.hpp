@@ -62,10 +62,10 @@ struct StagedLayout {
         size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
         return hist + (size_t)ldsNodes * 32 + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool) * 2 + C_NUM * 4;
     }
-    // largest pool (multiple of 64, <= 1024) that fits `budget` bytes of LDS
+    // largest pool (multiple of 16, <= 1024) that fits `budget` bytes of LDS
     static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes = 0) {
         uint32_t p = 1024;
-        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, ldsNodes) > budget) p -= 64;
+        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, ldsNodes) > budget) p -= 16;
         return p;
     }
 };
