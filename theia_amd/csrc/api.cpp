@@ -353,7 +353,15 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %,
         // nodes gathered from LDS instead of the vector cache 4.5 %. So the node array is
         // staged in LDS only when that costs no pool slot (THX_LDS_NODES=<max nodes> forces it).
+        // Deep scenes (large per-thread stacks) leave a pool much smaller than the workgroup:
+        // batches run half empty then. Fewer wavefronts with fuller batches win while the pool
+        // holds less than 3/4 photon per thread (config 5: 1024 -> 768 threads, +9 %).
         t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0);
+        if (!std::getenv("THX_THREADS"))
+            while (t->block > 512 && 4u * t->pool < 3u * t->block) {
+                t->block -= 128;
+                t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0);
+            }
         t->ldsNodes = 0;
         const uint32_t withNodes = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, scene->info.n_nodes);
         bool stage = withNodes == t->pool;

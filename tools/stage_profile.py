@@ -8,7 +8,7 @@ import scenarios as S
 from theia_amd import _backend, _capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 which = sys.argv[2] if len(sys.argv) > 2 else "config2"
-make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus}[which]
+make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid}[which]
 sc = make(batch=n)
 S.run_batches(sc, 2)
 be = _backend.get()
@@ -18,7 +18,7 @@ S.run_batches(sc, 1)
 ms = sc.tracer.program.last_kernel_ms(0)
 _capi.check(be._lib.thx_tracer_read_stage_profile(C.c_void_p(sc.tracer.program.handle), out.ctypes.data_as(C.POINTER(C.c_uint64))))
 names = ["BIRTH", "A", "T0", "BM", "M", "TS", "C"]
-tot = out[:7].sum()
+tot = out[:8].sum()
 info = sc.tracer.program.launch_info(n)
 print(which, "kernel ms", ms, info, "total cycles/WG", tot / info["grid"])
 for i, nm in enumerate(names):
@@ -26,6 +26,7 @@ for i, nm in enumerate(names):
     if rounds:
         print(f"{nm:6s} share={cyc / tot:6.1%} rounds/WG={rounds / info['grid']:7.1f} items/round={items / rounds:7.1f} cycles/round={cyc / rounds:9.0f} cycles/item={cyc / max(items,1):8.1f}")
 
+print(f"idle share={int(out[7]) / tot:6.1%}")
 if out[10]:
     r = int(out[16 + 2])
     print(f"T0 detail: waves/round={int(out[10]) / r:.1f} walk cycles/wave={int(out[8]) / int(out[10]):.0f} post cycles/wave={int(out[9]) / int(out[10]):.0f} round={int(out[2]) / r:.0f}")
