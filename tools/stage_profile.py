@@ -26,7 +26,9 @@ for i, nm in enumerate(names):
     if rounds:
         print(f"{nm:6s} share={cyc / tot:6.1%} rounds/WG={rounds / info['grid']:7.1f} items/round={items / rounds:7.1f} cycles/round={cyc / rounds:9.0f} cycles/item={cyc / max(items,1):8.1f}")
 
-print(f"idle share={int(out[7]) / tot:6.1%}")
+claims = int(out[16:23].sum())
+print(f"idle share={int(out[7]) / tot:6.1%} idle cycles/claim={int(out[7]) / claims:.0f} empty polls/claim={int(out[11]) / claims:.2f}")
+print(f"per claim: failed looks {int(out[12]) / claims:.0f}  scan+claim {int(out[13]) / claims:.0f}  entries {int(out[14]) / claims:.0f} cycles")
 if out[10]:
     r = int(out[16 + 2])
     print(f"T0 detail: waves/round={int(out[10]) / r:.1f} walk cycles/wave={int(out[8]) / int(out[10]):.0f} post cycles/wave={int(out[9]) / int(out[10]):.0f} round={int(out[2]) / r:.0f}")
