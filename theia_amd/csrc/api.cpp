@@ -63,7 +63,6 @@ struct thx_tracer {
     uint32_t stackDepth = kStackDepth;
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
-    uint32_t takeMin = 1;         // staged kernel: see LaunchArgs::take_min (tuned on MI355X)
     uint32_t ldsNodes = 0;        // staged kernel: BVH nodes staged in LDS (0 = walk reads HBM/L2)
     uint32_t block = kTraceBlock;
     size_t lds = 0;
@@ -371,15 +370,14 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
             t->pool = withNodes;
             t->mode |= 4u;
         }
-        if (const char* env = std::getenv("THX_TAKE_MIN")) t->takeMin = (uint32_t)std::min(64, std::max(1, std::atoi(env)));
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(1024, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
     } else {
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
     }
     if (std::getenv("THX_VERBOSE"))
-        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u stack16=%d ldsNodes=%u takeMin=%u\n",
-                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, (int)t->stack16, t->ldsNodes, t->takeMin);
+        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u stack16=%d ldsNodes=%u\n",
+                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, (int)t->stack16, t->ldsNodes);
     int perCU = t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
     uint32_t mult = 1;
@@ -480,7 +478,6 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stack16 = t->stack16 ? 1u : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;
-    a.take_min = t->takeMin;
     a.lds_nodes_count = t->ldsNodes;
     a.lds_nodes_word = (t->desc.n_bins + 3u) & ~3u;
     a.slabs = t->slabs[cfg];

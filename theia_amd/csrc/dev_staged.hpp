@@ -34,15 +34,19 @@ constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 
 // stage ids == queue ids. The BIRTH queue is the free list of pool slots.
 enum : int { S_BIRTH = 0, S_A = 1, S_T0 = 2, S_BM = 3, S_M = 4, S_TS = 5, S_C = 6, S_NUM = 7 };
-// counters (LDS words): ring head (claimed up to) and tail (appended up to) per queue,
-// monotonic; then the photon cursor, the number of wavefronts inside a stage, the abort flag
+// counters (LDS words), laid out so that ONE 8-byte read per lane fetches everything the
+// scheduler looks at: pair q < 7 = {head, tail} of ring q (claimed up to / appended up to,
+// monotonic), pair 7 = {photon cursor, abort flag}
+enum : int { C_CURSOR = 14, C_ABORT = 15,
 #ifdef THX_STAGE_PROFILE
-// profile builds: 48 64-bit accumulators (cycles / batches / photons per stage) behind the counters
-enum : int { C_HEAD = 0, C_TAIL = 8, C_CURSOR = 16, C_BUSY = 17, C_ABORT = 18, C_PROF = 32, C_NUM = 32 + 96 };
+             C_PROF = 32, C_NUM = 32 + 96 // profile builds: 48 64-bit accumulators behind the counters
 #else
-enum : int { C_HEAD = 0, C_TAIL = 8, C_CURSOR = 16, C_BUSY = 17, C_ABORT = 18, C_NUM = 32 };
+             C_NUM = 32
 #endif
-constexpr uint32_t Q_EMPTY = 0xFFFFu;  // ring cell without an entry (slot ids are < 4096 + which << 12)
+};
+THX_DEV constexpr int cHead(int q) { return 2 * q; }
+THX_DEV constexpr int cTail(int q) { return 2 * q + 1; }
+constexpr uint32_t Q_EMPTY = 0xFFFFu;  // ring cell without an entry (entries: slot < 4096 | which << 12 | lap tag << 14)
 constexpr uint32_t kIdleSpinLimit = 1u << 20; // polls (~150 cycles each): ~70 ms without any work appearing -> abort
 constexpr uint32_t kCellSpinLimit = 1u << 22;
 
@@ -81,10 +85,13 @@ struct Pool {
     float4* sc;       // [NSC][P]
     uint16_t* q;      // rings
     uint32_t* ctr;    // counters
-    uint32_t P, cap;  // pool size, ring capacity (power of two >= P)
+    uint32_t P, cap, capShift; // pool size, ring capacity (power of two >= P) and its log2
     // ring s holds slot ids; the TS ring (last) has room for 2 cap entries (two shadow rays per photon)
     THX_DEV volatile uint16_t* queue(int s) const { return q + (size_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * cap; }
     THX_DEV uint32_t mask(int s) const { return (s == S_TS ? 2u * cap : cap) - 1u; }
+    // lap tag of ring position `pos` (bit 14 of the cell): a claimer never takes the entry of
+    // the previous lap for its own, however late that lap's claimer empties the cell
+    THX_DEV uint32_t lapTag(int s, uint32_t pos) const { return ((pos >> (s == S_TS ? capShift + 1u : capShift)) & 1u) << 14; }
     THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[4 * P + slot]) + 2; }
 };
 
@@ -144,29 +151,6 @@ THX_DEV void bindLane(Lane<V>& L, const Meta& m) {
     L.local = m.local;
     L.idx = L.a->p.photon_offset + m.local;
     L.dim = m.dim;
-}
-
-// wavefront-aggregated ring append; must be reached by all lanes of the wave. Everything
-// the stage wrote for the photon (pool state, scratch, flags) is ordered before the entry
-// becomes visible: LDS operations of a wavefront execute in issue order, the fence keeps
-// the compiler from moving them.
-template <class V>
-THX_DEV void pushTo(const Pool<V>& p, int stage, bool pred, uint32_t entry) {
-    const unsigned long long m = __ballot(pred);
-    if (m == 0ull) return;
-    const uint32_t lane = threadIdx.x & 63u;
-    const int leader = __ffsll((long long)m) - 1;
-    __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-    uint32_t base = 0;
-    if ((int)lane == leader) base = atomicAdd(&p.ctr[C_TAIL + stage], (uint32_t)__popcll(m));
-    base = __shfl(base, leader, 64);
-    if (pred) {
-        volatile uint16_t* cell = p.queue(stage) + ((base + (uint32_t)__popcll(m & ((1ull << lane) - 1ull))) & p.mask(stage));
-        // the claimer of the previous lap has normally long emptied the cell
-        for (uint32_t spin = 0; *cell != Q_EMPTY; ++spin)
-            if (spin > kCellSpinLimit) { p.ctr[C_ABORT] = 1u; break; }
-        *cell = (uint16_t)entry;
-    }
 }
 
 // TLAS root test done by the requesting stage, so rays that miss the whole scene
@@ -282,6 +266,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     }
     pool.q = reinterpret_cast<uint16_t*>(ldsWords() + stackWord0 + args.stack_wave_words * (T >> 6));
     pool.cap = Lay::qcap(P);
+    pool.capShift = 31u - (uint32_t)__builtin_clz(pool.cap);
     pool.ctr = reinterpret_cast<uint32_t*>(pool.q + 8 * pool.cap);
 
     // response.histogram.glsl:20-29 initResponse; every slot starts free
@@ -300,132 +285,191 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const uint64_t b64 = per * blockIdx.x;
     const uint32_t begin = b64 < batch ? (uint32_t)b64 : batch;
     const uint32_t end = (b64 + per) < batch ? (uint32_t)(b64 + per) : batch;
-    if (tid < C_NUM) pool.ctr[tid] = tid == C_TAIL + S_BIRTH ? P : (tid == C_CURSOR ? begin : 0u);
+    if (tid < C_NUM) pool.ctr[tid] = tid == (uint32_t)cTail(S_BIRTH) ? P : (tid == C_CURSOR ? begin : 0u);
     __syncthreads();
 
     const thx_propagate_params& prop = args.p.scene.propagation;
     const uint64_t sceneMedium = (uint64_t)args.p.scene.sceneMedium[0] | ((uint64_t)args.p.scene.sceneMedium[1] << 32);
     volatile uint32_t* const ctr = pool.ctr;
-    const uint32_t takeMin = min(max(args.take_min, 1u), 64u);
+    auto rl = [](uint32_t v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); };
+
+    // What a finished stage hands to the scheduler: every lane appends at most two entries,
+    // (dstA, entA) to any ring and (entB) to the TS ring (second shadow ray of the MIS stage).
+    int dstA = -1;
+    uint32_t entA = 0, entB = 0;
+    bool hasB = false;
+
+    // The scheduling code runs ~5 400 times per wavefront and launch between stages of a few
+    // thousand cycles, so its INSTRUCTION COUNT matters as much as its LDS round trips (a
+    // wavefront issues one instruction every ~10 cycles while three others keep the SIMD busy):
+    // appends are one LDS atomic per lane (same-address atomics serialise inside the LDS, one
+    // instruction for the wave), the fill levels are compared in lanes 0..7 with a 3-step DPP max.
+    // Lane-constant helpers of that comparison (lane q < 7 stands for ring q):
+    const uint32_t qLane = lane & 7u;
+    //   priority on ties: walk, A, BM, M, C, BIRTH;   0 = lane does not compete (TS, pair 7)
+    const uint32_t prioLane = (0x0123456u >> (4u * (qLane == (uint32_t)S_T0 ? 0u : qLane == (uint32_t)S_A ? 1u : qLane == (uint32_t)S_BM ? 2u
+                              : qLane == (uint32_t)S_M ? 3u : qLane == (uint32_t)S_C ? 4u : qLane == (uint32_t)S_BIRTH ? 5u : 6u))) & 7u;
+    const uint32_t keepMask = prioLane != 0u ? 0xFFFFFFFFu : 0u;
+    const uint32_t t0Mask = qLane == (uint32_t)S_T0 ? 0xFFFFFFFFu : 0u;
+    const bool birthLane = qLane == (uint32_t)S_BIRTH;
 
 #ifdef THX_STAGE_PROFILE
     unsigned long long profIdle0 = __builtin_amdgcn_s_memtime();
+    unsigned long long* const profLds = reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF);
 #endif
     uint32_t idleSpins = 0;
     while (true) {
-        // ---- look for work: the fullest queue (both walk queues count as one); a batch
-        // thinner than `takeMin` only when nothing fuller can show up (no wavefront is inside a
-        // stage). One LDS read fetches the whole counter block (lane k reads counter k), the
-        // decision runs on wave-uniform values (v_readlane -> scalar unit), lane 0 issues the
-        // claim. (Lane 0 reading the counters one by one: 4.2 ms per 10^7 photons instead of
-        // 3.65; comparing fill levels in eight lanes with a DPP max: 3.9 ms.)
-        // cStage: the claimed stage, S_NUM = nothing now, S_NUM + 1 = leave
-#ifdef THX_STAGE_PROFILE
-        const unsigned long long profTa = __builtin_amdgcn_s_memtime();
-#endif
-        uint32_t cStage = S_NUM, cH0 = 0, cN0 = 0, cH1 = 0, cN1 = 0;
-        {
-            const uint32_t cv = ctr[lane & 31u];
-            auto C = [&](int k) { return (uint32_t)__builtin_amdgcn_readlane((int)cv, k); };
-            uint32_t cnt[S_NUM], head[S_NUM];
-#pragma unroll
-            for (int q = 0; q < S_NUM; ++q) {
-                head[q] = C(C_HEAD + q);
-                cnt[q] = C(C_TAIL + q) - head[q];
+        // ===== LDS round trip 1: reserve a ring cell per entry of the finished stage and
+        // fetch the counter block (issued behind the atomics, so it sees them).
+        const bool pushA = dstA >= 0;
+        uint32_t posA = 0, posB = 0;
+        if (__ballot(pushA) != 0ull) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // stage data before the entries
+            if (pushA) posA = atomicAdd(&pool.ctr[cTail(dstA)], 1u);
+            if (__ballot(hasB) != 0ull)
+                if (hasB) posB = atomicAdd(&pool.ctr[cTail(S_TS)], 1u);
+        }
+        const unsigned long long hv = reinterpret_cast<volatile unsigned long long*>(pool.ctr)[qLane]; // {head, tail} / {cursor, abort}
+        const uint32_t hvx = (uint32_t)hv, hvy = (uint32_t)(hv >> 32);
+
+        // ring cells of this lane's entries
+        volatile uint16_t* cellA = nullptr;
+        volatile uint16_t* cellB = nullptr;
+        if (pushA) {
+            cellA = pool.queue(dstA) + (posA & pool.mask(dstA));
+            entA |= pool.lapTag(dstA, posA);
+        }
+        if (hasB) {
+            cellB = pool.queue(S_TS) + (posB & pool.mask(S_TS));
+            entB |= pool.lapTag(S_TS, posB);
+        }
+
+        // ---- pick the next batch: the fullest ring; both walk rings count as one
+        const uint32_t c = hvy - hvx;
+        const uint32_t cursor = rl(hvx, 7), abortFlag = rl(hvy, 7);
+        const uint32_t freeSlots = rl(c, S_BIRTH), cT0 = rl(c, S_T0), cTS = rl(c, S_TS);
+        const uint32_t remaining = cursor < end ? end - cursor : 0u;
+        uint32_t e = (c & keepMask) + (cTS & t0Mask);
+        e = min(e, birthLane ? remaining : 0xFFFFFFFFu);
+        // (letting shading stages go first while a walk batch would not fill the wavefront,
+        // or waiting for fuller batches, was measured slower: greedy wins)
+        uint32_t key = (e << 3) | prioLane;
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x111, 0xF, 0xF, false)); // row_shr:1
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x112, 0xF, 0xF, false)); // row_shr:2
+        key = max(key, (uint32_t)__builtin_amdgcn_update_dpp(0, (int)key, 0x114, 0xF, 0xF, false)); // row_shr:4
+        key = rl(key, 7);
+        const uint32_t best = key >> 3;
+        // cStage: S_NUM = nothing now, S_NUM + 1 = leave (aborted, or every photon is finished)
+        uint32_t cStage = S_NUM, pick = S_NUM;
+        if (abortFlag != 0u || (cursor >= end && freeSlots == P)) cStage = S_NUM + 1;
+        else if (best != 0u) pick = (((uint32_t)S_BIRTH << 4) | ((uint32_t)S_C << 8) | ((uint32_t)S_M << 12) | ((uint32_t)S_BM << 16) |
+                                    ((uint32_t)S_A << 20) | ((uint32_t)S_T0 << 24)) >> ((key & 7u) * 4u) & 15u;
+        // claim parameters: lane 0 claims ring qa (n0 entries from ha), lane 1 ring TS for a walk
+        uint32_t qa = 0, ha = 0, n0 = 0, hb = 0, n1 = 0;
+        if (pick == (uint32_t)S_T0) {
+            qa = S_T0; ha = rl(hvx, S_T0); n0 = min(cT0, 64u);
+            hb = rl(hvx, S_TS); n1 = min(cTS, 64u - n0);
+        } else if (pick < (uint32_t)S_NUM) {
+            qa = pick; ha = rl(hvx, pick); n0 = min(best, 64u);
+        }
+
+        // ===== LDS round trip 2: are my ring cells empty (they are, unless the claimer of the
+        // previous lap is ~10^4 cycles late), the claim itself (CAS on the ring head), and,
+        // speculatively, the entries the claim would give this wavefront.
+        uint32_t chkA = Q_EMPTY, chkB = Q_EMPTY, casOld = 0, spec = Q_EMPTY;
+        if (cellA) chkA = *cellA;
+        if (cellB) chkB = *cellB;
+        if (lane == 0 && n0 > 0u) casOld = atomicCAS(&pool.ctr[cHead((int)qa)], ha, ha + n0);
+        if (lane == 1 && n1 > 0u) casOld = atomicCAS(&pool.ctr[cHead(S_TS)], hb, hb + n1);
+        volatile uint16_t* claimCell = nullptr;
+        uint32_t wantTag = 0;
+        if (lane < n0) {
+            claimCell = pool.queue((int)qa) + ((ha + lane) & pool.mask((int)qa));
+            wantTag = pool.lapTag((int)qa, ha + lane);
+        } else if (lane < n0 + n1) {
+            claimCell = pool.queue(S_TS) + ((hb + (lane - n0)) & pool.mask(S_TS));
+            wantTag = pool.lapTag(S_TS, hb + (lane - n0));
+        }
+        if (claimCell) spec = *claimCell;
+
+        // ---- publish the entries of the finished stage
+        if (cellA) {
+            for (uint32_t spin = 0; chkA != Q_EMPTY; ++spin) {
+                if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; break; }
+                chkA = *cellA;
             }
-            const uint32_t cursor = C(C_CURSOR);
-            const uint32_t freeSlots = cnt[S_BIRTH];
-            cnt[S_BIRTH] = min(freeSlots, cursor < end ? end - cursor : 0u);
-            if (C(C_ABORT) != 0u || (cursor >= end && freeSlots == P)) {
-                cStage = S_NUM + 1; // aborted, or every photon of the range is finished
-            } else {
-                const uint32_t walk = cnt[S_T0] + cnt[S_TS];
-                uint32_t best = walk, pick = S_T0;
-                const int shading[5] = {S_A, S_BM, S_M, S_C, S_BIRTH};
-#pragma unroll
-                for (int k = 0; k < 5; ++k)
-                    if (cnt[shading[k]] > best) { best = cnt[shading[k]]; pick = (uint32_t)shading[k]; }
-                if (best >= 64u || (best > 0u && (best >= takeMin || C(C_BUSY) == 0u))) {
-                    if (pick == (uint32_t)S_T0) {
-                        // primary rays first, then shadow rays (two rings, two claims)
-                        const uint32_t n0 = min(cnt[S_T0], 64u);
-                        const uint32_t n1 = min(cnt[S_TS], 64u - n0);
-                        uint32_t ok0 = 1u, ok1 = 0u;
-                        if (lane == 0) {
-                            if (n0 > 0u) ok0 = atomicCAS(&pool.ctr[C_HEAD + S_T0], head[S_T0], head[S_T0] + n0) == head[S_T0];
-                            if (ok0 && n1 > 0u) ok1 = atomicCAS(&pool.ctr[C_HEAD + S_TS], head[S_TS], head[S_TS] + n1) == head[S_TS];
-                        }
-                        ok0 = __builtin_amdgcn_readfirstlane(ok0);
-                        ok1 = __builtin_amdgcn_readfirstlane(ok1);
-                        if (ok0) { cN0 = n0; cH0 = head[S_T0]; }
-                        if (ok1) { cN1 = n1; cH1 = head[S_TS]; }
-                        if (cN0 + cN1 > 0u) cStage = S_T0;
-                    } else {
-                        const uint32_t n0 = min(best, 64u);
-                        uint32_t ok = 0u, first = 0u;
-                        if (lane == 0) {
-                            ok = atomicCAS(&pool.ctr[C_HEAD + pick], head[pick], head[pick] + n0) == head[pick];
-                            // photon indices of a birth batch; beyond `end` the slot goes back
-                            if (ok && pick == (uint32_t)S_BIRTH) first = atomicAdd(&pool.ctr[C_CURSOR], n0);
-                        }
-                        if (__builtin_amdgcn_readfirstlane(ok)) {
-                            cN0 = n0; cH0 = head[pick]; cStage = pick;
-                            cH1 = __builtin_amdgcn_readfirstlane(first);
-                        }
-                    }
-                    if (cStage < (uint32_t)S_NUM && lane == 0) atomicAdd(&pool.ctr[C_BUSY], 1u);
-                }
+            *cellA = (uint16_t)entA;
+        }
+        if (cellB) {
+            for (uint32_t spin = 0; chkB != Q_EMPTY; ++spin) {
+                if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; break; }
+                chkB = *cellB;
             }
+            *cellB = (uint16_t)entB;
+        }
+        dstA = -1; hasB = false;
+
+        // ---- outcome of the claim
+        const bool ok0 = n0 > 0u && rl(casOld, 0) == ha;
+        const bool ok1 = n1 > 0u && rl(casOld, 1) == hb;
+        if (cStage != (uint32_t)S_NUM + 1u && (ok0 || ok1)) {
+            cStage = pick;
         }
         const uint32_t stage = cStage;
 #ifdef THX_STAGE_PROFILE
         const unsigned long long profTb = __builtin_amdgcn_s_memtime();
 #endif
         if (stage == (uint32_t)S_NUM + 1u) break;
-        if (stage == (uint32_t)S_NUM) { // nothing to do right now
+        if (stage == (uint32_t)S_NUM) { // nothing to do right now (or another wavefront was faster)
 #ifdef THX_STAGE_PROFILE
-            if (lane == 0) atomicAdd(&reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF)[11], 1ull);
+            if (lane == 0) atomicAdd(&profLds[11], 1ull);
 #endif
             if (++idleSpins > kIdleSpinLimit) {
                 if (lane == 0) ctr[C_ABORT] = 1u;
                 break;
             }
-            __builtin_amdgcn_s_sleep(1);
+            if (best == 0u) __builtin_amdgcn_s_sleep(1);
             continue;
         }
         idleSpins = 0;
-        const uint32_t h0 = cH0, n0 = cN0, h1 = cH1, n1 = cN1;
-        const uint32_t n = stage == (uint32_t)S_T0 ? n0 + n1 : n0;
-        bool act = lane < n;
-        uint32_t entry = 0;
+        // lanes [0, n0) hold ring qa's entries (if that claim succeeded), lanes [n0, n0 + n1) the
+        // shadow rays; a walk batch may consist of the second part only
+        bool act = (lane < n0 && ok0) || (lane >= n0 && lane < n0 + n1 && ok1);
+        uint32_t entry = spec;
         if (act) {
-            const int q = (stage == (uint32_t)S_T0 && lane >= n0) ? S_TS : (int)stage;
-            volatile uint16_t* cell = pool.queue(q) + ((q == S_TS && stage == (uint32_t)S_T0 ? h1 + (lane - n0) : h0 + lane) & pool.mask(q));
-            entry = *cell;
-            for (uint32_t spin = 0; entry == Q_EMPTY; ++spin) { // appended, not written yet
+            // reserved but not written yet: the cell is empty (or, after a very late claimer of
+            // the previous lap, still holds that lap's entry: wrong tag)
+            for (uint32_t spin = 0; (entry & 0xC000u) != wantTag; ++spin) {
                 if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; entry = 0; act = false; break; }
-                entry = *cell;
+                entry = *claimCell;
             }
-            *cell = (uint16_t)Q_EMPTY;
+            *claimCell = (uint16_t)Q_EMPTY;
+            entry &= 0x3FFFu;
+        } else {
+            entry = 0;
+        }
+        const uint32_t n = (ok0 ? n0 : 0u) + (ok1 ? n1 : 0u);
+        // photon indices of a birth batch; beyond `end` the slot goes back to the free ring
+        uint32_t birthFirst = 0;
+        if (stage == (uint32_t)S_BIRTH) {
+            if (lane == 0) birthFirst = atomicAdd(&pool.ctr[C_CURSOR], n0);
+            birthFirst = __builtin_amdgcn_readfirstlane(birthFirst);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef THX_STAGE_PROFILE
         const unsigned long long profT0 = __builtin_amdgcn_s_memtime();
-        unsigned long long* const profLds = reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF);
         if (lane == 0) {
             atomicAdd(&profLds[7], profT0 - profIdle0);
-            atomicAdd(&profLds[12], profTa - profIdle0); // failed looks before this one
-            atomicAdd(&profLds[13], profTb - profTa);    // scan + claim
-            atomicAdd(&profLds[14], profT0 - profTb);    // entries
+            atomicAdd(&profLds[14], profT0 - profTb); // entries
         }
 #endif
 
         switch (stage) {
         case S_BIRTH: { // tracer.scene.forward.glsl:50-67
             const uint32_t slot = entry;
-            const bool born = act && h1 + lane < end; // h1 = first photon index of this batch
+            const bool born = act && birthFirst + lane < end;
             if (born) {
-                Meta m{h1 + lane, 0u, 0u, 0.0f};
+                Meta m{birthFirst + lane, 0u, 0u, 0.0f};
                 bindLane(L, m);
                 Ray ray = sampleRay(L, sceneMedium);
                 onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
@@ -435,8 +479,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 storeRay(pool, slot, ray);
                 storeMeta(pool, slot, m);
             }
-            pushTo(pool, S_A, born, slot);
-            pushTo(pool, S_BIRTH, act && !born, slot);
+            entA = slot;
+            if (born) dstA = S_A;
+            else if (act) dstA = S_BIRTH;
             break;
         }
         case S_A: { // trace() up to the ray query, scene.traverse.glsl:280-310
@@ -470,9 +515,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 m.dim = L.dim;
                 storeMeta(pool, slot, m);
             }
-            pushTo(pool, S_T0, dest == 1, slot);
-            pushTo(pool, S_BM, dest == 2, slot);
-            pushTo(pool, S_BIRTH, dest == 3, slot);
+            entA = slot;
+            dstA = dest == 1 ? S_T0 : (dest == 2 ? S_BM : (dest == 3 ? S_BIRTH : -1));
             break;
         }
         case S_T0: { // closest-hit walks: primary rays (which 0; a surface hit is finished here,
@@ -527,11 +571,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 if ((tid & 63u) == 0u) atomicAdd(&profLds[9], __builtin_amdgcn_s_memtime() - wt1);
 #endif
             }
-            pushTo(pool, S_BM, dest == 4, slot);
-            pushTo(pool, V::MIS ? S_M : S_C, dest == 1, slot);
-            pushTo(pool, S_A, dest == 2, slot);
-            pushTo(pool, S_BIRTH, dest == 3, slot);
-            pushTo(pool, S_C, lastShadow, slot);
+            entA = slot;
+            dstA = dest == 4 ? S_BM : (dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : (dest == 3 ? S_BIRTH : (lastShadow ? S_C : -1))));
             break;
         }
         case S_BM: { // photons that travel their full sampled distance
@@ -542,9 +583,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 none.valid = false; none.instance = 0; none.prim = 0; none.t = 0; none.b1 = 0; none.b2 = 0;
                 dest = postPrimary(L, pool, slot, none);
             }
-            pushTo(pool, V::MIS ? S_M : S_C, dest == 1, slot);
-            pushTo(pool, S_A, dest == 2, slot);
-            pushTo(pool, S_BIRTH, dest == 3, slot);
+            entA = slot;
+            dstA = dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : (dest == 3 ? S_BIRTH : -1));
             break;
         }
         case S_M: { // sampleTargetMIS set-up, scene.traverse.glsl:234-262
@@ -574,9 +614,14 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 m.flags = (m.flags & ~(3u << F_PEND_SHIFT)) | (((t1 ? 1u : 0u) + (t2 ? 1u : 0u)) << F_PEND_SHIFT);
                 storeMeta(pool, slot, m);
             }
-            pushTo(pool, S_TS, t1, slot | (1u << 12));
-            pushTo(pool, S_TS, t2, slot | (2u << 12));
-            pushTo(pool, S_C, act && !t1 && !t2, slot);
+            if (t1) {
+                dstA = S_TS; entA = slot | (1u << 12);
+                hasB = t2; entB = slot | (2u << 12);
+            } else if (t2) {
+                dstA = S_TS; entA = slot | (2u << 12);
+            } else if (act) {
+                dstA = S_C; entA = slot;
+            }
             break;
         }
         default: { // S_C: scatterRay, scene.traverse.glsl:391, and the end of the step
@@ -594,12 +639,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 m.dim = L.dim;
                 storeMeta(pool, slot, m);
             }
-            pushTo(pool, S_A, dest == 2, slot);
-            pushTo(pool, S_BIRTH, dest == 3, slot);
+            entA = slot;
+            dstA = dest == 2 ? S_A : (dest == 3 ? S_BIRTH : -1);
             break;
         }
         }
-        if (lane == 0) atomicSub(&pool.ctr[C_BUSY], 1u);
 #ifdef THX_STAGE_PROFILE
         profIdle0 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {

@@ -40,7 +40,6 @@ struct LaunchArgs {
     uint32_t stack16;          // 1: stack entries are 16 bit (scene has < 8190 nodes/triangles)
     uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active
     uint32_t pool;             // staged kernel: photons held in LDS per workgroup
-    uint32_t take_min;         // staged kernel: a wavefront takes a batch thinner than this only when no other wavefront is inside a stage
     uint32_t lds_nodes_word;   // LDSBVH variants: LDS word offset of the staged node array
     uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
