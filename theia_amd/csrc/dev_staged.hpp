@@ -428,7 +428,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 if (lane == 0) ctr[C_ABORT] = 1u;
                 break;
             }
-            if (best == 0u) __builtin_amdgcn_s_sleep(1);
+            if (best == 0u) __builtin_amdgcn_s_sleep(4);
             continue;
         }
         idleSpins = 0;
@@ -464,59 +464,36 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
 #endif
 
+        bool doA = false; // lanes that run the A part after the stage body
+        Ray rayA;
+        Meta mA{0u, 0u, 0u, 0.0f};
+        uint32_t slotA = 0;
         switch (stage) {
-        case S_BIRTH: { // tracer.scene.forward.glsl:50-67
-            const uint32_t slot = entry;
+        case S_BIRTH: { // tracer.scene.forward.glsl:50-67; goes straight on into the A part
+            slotA = entry;
             const bool born = act && birthFirst + lane < end;
             if (born) {
-                Meta m{birthFirst + lane, 0u, 0u, 0.0f};
-                bindLane(L, m);
-                Ray ray = sampleRay(L, sceneMedium);
-                onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
-                m.dim = L.dim;
+                mA = Meta{birthFirst + lane, 0u, 0u, 0.0f};
+                bindLane(L, mA);
+                rayA = sampleRay(L, sceneMedium);
+                onEvent(L, rayA, RESULT_CODE_RAY_CREATED, 0);
+                mA.dim = L.dim;
                 // (the host guarantees path_length >= 1 for this kernel)
-                m.flags = F_ALIVE | ((args.flags & THX_FLAG_DISABLE_DIRECT) ? 0u : F_ALLOW) | (1u << F_STEP_SHIFT);
-                storeRay(pool, slot, ray);
-                storeMeta(pool, slot, m);
+                mA.flags = F_ALIVE | ((args.flags & THX_FLAG_DISABLE_DIRECT) ? 0u : F_ALLOW) | (1u << F_STEP_SHIFT);
+                storeRay(pool, slotA, rayA);
+                doA = true;
             }
-            entA = slot;
-            if (born) dstA = S_A;
-            else if (act) dstA = S_BIRTH;
+            entA = slotA;
+            if (act && !born) dstA = S_BIRTH; // beyond the photon range: the slot goes back
             break;
         }
-        case S_A: { // trace() up to the ray query, scene.traverse.glsl:280-310
-            const uint32_t slot = entry;
-            int dest = 0; // 1 traversal, 2 propagate-only, 3 finished
+        case S_A: { // photons that start their next step after a surface interaction
+            slotA = entry;
             if (act) {
-                Ray ray = loadRay(pool, slot);
-                Meta m = loadMeta(pool, slot);
-                bindLane(L, m);
-                L.cnt.add(ST_STEPS);
-                if (isRayBad(ray)) {
-                    endStep(L, ray, m, ERROR_CODE_RAY_BAD);
-                    dest = 3;
-                } else {
-                    f3 dir = normalize(ray.direction);
-                    float dist = sampleScatterLength(ray, prop, draw(L));
-                    float sampledDist = dist;
-                    bool mis_target = false;
-                    if constexpr (V::MIS) {
-                        GuideSample gs = evalTargetGuide(args.p.guide, ray.position, dir);
-                        mis_target = (m.flags & F_ALLOW) != 0u && gs.prob > 0.0f;
-                        if (mis_target) {
-                            mis_target = gs.dist > dist;
-                            dist = fmaxf(gs.dist, dist);
-                        }
-                    }
-                    m.flags = (m.flags & ~F_MIS_TARGET) | (mis_target ? F_MIS_TARGET : 0u);
-                    pool.sc[0 * P + slot] = make_float4(dist, sampledDist, 0.0f, 0.0f);
-                    dest = rootHit(L, ray.position, dir, dist) ? 1 : 2;
-                }
-                m.dim = L.dim;
-                storeMeta(pool, slot, m);
+                rayA = loadRay(pool, slotA);
+                mA = loadMeta(pool, slotA);
+                doA = true;
             }
-            entA = slot;
-            dstA = dest == 1 ? S_T0 : (dest == 2 ? S_BM : (dest == 3 ? S_BIRTH : -1));
             break;
         }
         case S_T0: { // closest-hit walks: primary rays (which 0; a surface hit is finished here,
@@ -624,25 +601,61 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             }
             break;
         }
-        default: { // S_C: scatterRay, scene.traverse.glsl:391, and the end of the step
-            const uint32_t slot = entry;
-            int dest = 0;
+        default: { // S_C: scatterRay, scene.traverse.glsl:391, the end of the step and, for
+                   // the photons that go on, the A part of the next one
+            slotA = entry;
             if (act) {
-                Ray ray = loadRay(pool, slot);
-                Meta m = loadMeta(pool, slot);
-                bindLane(L, m);
+                rayA = loadRay(pool, slotA);
+                mA = loadMeta(pool, slotA);
+                bindLane(L, mA);
                 float u0 = draw(L);
                 float u1 = draw(L);
-                scatterRay(L, ray, ray.medium, u0, u1);
-                storeRay(pool, slot, ray);
-                dest = endStep(L, ray, m, RESULT_CODE_RAY_SCATTERED) ? 2 : 3;
-                m.dim = L.dim;
-                storeMeta(pool, slot, m);
+                scatterRay(L, rayA, rayA.medium, u0, u1);
+                storeRay(pool, slotA, rayA);
+                doA = endStep(L, rayA, mA, RESULT_CODE_RAY_SCATTERED);
+                mA.dim = L.dim;
+                if (!doA) {
+                    storeMeta(pool, slotA, mA);
+                    dstA = S_BIRTH;
+                }
             }
-            entA = slot;
-            dstA = dest == 2 ? S_A : (dest == 3 ? S_BIRTH : -1);
+            entA = slotA;
             break;
         }
+        }
+
+        // ---- A part: trace() up to the ray query, scene.traverse.glsl:280-310. Entered from
+        // the A ring, and directly (photon still in registers) after a birth or a scatter.
+        if (__ballot(doA) != 0ull) {
+            int dest = 0; // 1 traversal, 2 propagate-only, 3 finished
+            if (doA) {
+                bindLane(L, mA);
+                L.cnt.add(ST_STEPS);
+                if (isRayBad(rayA)) {
+                    endStep(L, rayA, mA, ERROR_CODE_RAY_BAD);
+                    dest = 3;
+                } else {
+                    f3 dir = normalize(rayA.direction);
+                    float dist = sampleScatterLength(rayA, prop, draw(L));
+                    float sampledDist = dist;
+                    bool mis_target = false;
+                    if constexpr (V::MIS) {
+                        GuideSample gs = evalTargetGuide(args.p.guide, rayA.position, dir);
+                        mis_target = (mA.flags & F_ALLOW) != 0u && gs.prob > 0.0f;
+                        if (mis_target) {
+                            mis_target = gs.dist > dist;
+                            dist = fmaxf(gs.dist, dist);
+                        }
+                    }
+                    mA.flags = (mA.flags & ~F_MIS_TARGET) | (mis_target ? F_MIS_TARGET : 0u);
+                    pool.sc[0 * P + slotA] = make_float4(dist, sampledDist, 0.0f, 0.0f);
+                    dest = rootHit(L, rayA.position, dir, dist) ? 1 : 2;
+                }
+                mA.dim = L.dim;
+                storeMeta(pool, slotA, mA);
+                entA = slotA;
+                dstA = dest == 1 ? S_T0 : (dest == 2 ? S_BM : S_BIRTH);
+            }
         }
 #ifdef THX_STAGE_PROFILE
         profIdle0 = __builtin_amdgcn_s_memtime();
