@@ -464,7 +464,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
 #endif
 
-        bool doA = false; // lanes that run the A part after the stage body
+        bool doA = false, doBM = false, doM = false; // lanes that run the A / BM / M part after the stage body
         Ray rayA;
         Meta mA{0u, 0u, 0u, 0.0f};
         uint32_t slotA = 0;
@@ -552,55 +552,14 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             dstA = dest == 4 ? S_BM : (dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : (dest == 3 ? S_BIRTH : (lastShadow ? S_C : -1))));
             break;
         }
-        case S_BM: { // photons that travel their full sampled distance
-            const uint32_t slot = entry;
-            int dest = 0;
-            if (act) {
-                QueryHit none;
-                none.valid = false; none.instance = 0; none.prim = 0; none.t = 0; none.b1 = 0; none.b2 = 0;
-                dest = postPrimary(L, pool, slot, none);
-            }
-            entA = slot;
-            dstA = dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : (dest == 3 ? S_BIRTH : -1));
+        case S_BM: // primary rays whose walk found nothing: BM part below
+            slotA = entry;
+            doBM = act;
             break;
-        }
-        case S_M: { // sampleTargetMIS set-up, scene.traverse.glsl:234-262
-            const uint32_t slot = entry;
-            bool t1 = false, t2 = false;
-            if (act) {
-                Ray ray = loadRay(pool, slot);
-                Meta m = loadMeta(pool, slot);
-                bindLane(L, m);
-                float pPP;
-                float u0 = draw(L);
-                float u1 = draw(L);
-                f3 dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
-                GuideSample ts = sampleTargetGuide(L, ray.position);
-                float pTT = ts.prob;
-                GuideSample ps = evalTargetGuide(args.p.guide, ray.position, dirPhase);
-                float pTP = ps.prob;
-                float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
-                float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
-                float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
-                pool.sc[0 * P + slot] = make_float4(dirPhase.x, dirPhase.y, dirPhase.z, wPhase);
-                pool.sc[1 * P + slot] = make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget);
-                t1 = rootHit(L, ray.position, dirPhase, ps.dist);
-                t2 = rootHit(L, ray.position, ts.dir, ts.dist);
-                m.distShadow = ps.dist; // == ts.dist: both are |center - observer| + radius
-                m.dim = L.dim;
-                m.flags = (m.flags & ~(3u << F_PEND_SHIFT)) | (((t1 ? 1u : 0u) + (t2 ? 1u : 0u)) << F_PEND_SHIFT);
-                storeMeta(pool, slot, m);
-            }
-            if (t1) {
-                dstA = S_TS; entA = slot | (1u << 12);
-                hasB = t2; entB = slot | (2u << 12);
-            } else if (t2) {
-                dstA = S_TS; entA = slot | (2u << 12);
-            } else if (act) {
-                dstA = S_C; entA = slot;
-            }
+        case S_M: // photons that scatter after a surface-free walk: M part below
+            slotA = entry;
+            doM = act;
             break;
-        }
         default: { // S_C: scatterRay, scene.traverse.glsl:391, the end of the step and, for
                    // the photons that go on, the A part of the next one
             slotA = entry;
@@ -654,7 +613,61 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 mA.dim = L.dim;
                 storeMeta(pool, slotA, mA);
                 entA = slotA;
+                // (running the BM and M parts right here for the photons that miss the scene's
+                // bounding box was measured slower on configs 2 and 5: those parts then run with
+                // the lanes the walk-bound photons leave empty)
                 dstA = dest == 1 ? S_T0 : (dest == 2 ? S_BM : S_BIRTH);
+            }
+        }
+
+        // ---- BM part: the photon travels its full sampled distance (trace() after a ray query
+        // without a hit, scene.traverse.glsl:324-351)
+        if (__ballot(doBM) != 0ull) {
+            if (doBM) {
+                QueryHit none;
+                none.valid = false; none.instance = 0; none.prim = 0; none.t = 0; none.b1 = 0; none.b2 = 0;
+                const int dest = postPrimary(L, pool, slotA, none);
+                entA = slotA;
+                // (going straight on into the M part was measured slower as well)
+                dstA = dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : S_BIRTH);
+            }
+        }
+
+        // ---- M part: sampleTargetMIS set-up, scene.traverse.glsl:234-262
+        if (__ballot(doM) != 0ull) {
+            const uint32_t slot = slotA;
+            bool t1 = false, t2 = false;
+            if (doM) {
+                Ray ray = loadRay(pool, slot);
+                Meta m = loadMeta(pool, slot);
+                bindLane(L, m);
+                float pPP;
+                float u0 = draw(L);
+                float u1 = draw(L);
+                f3 dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
+                GuideSample ts = sampleTargetGuide(L, ray.position);
+                float pTT = ts.prob;
+                GuideSample ps = evalTargetGuide(args.p.guide, ray.position, dirPhase);
+                float pTP = ps.prob;
+                float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
+                float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
+                float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
+                pool.sc[0 * P + slot] = make_float4(dirPhase.x, dirPhase.y, dirPhase.z, wPhase);
+                pool.sc[1 * P + slot] = make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget);
+                t1 = rootHit(L, ray.position, dirPhase, ps.dist);
+                t2 = rootHit(L, ray.position, ts.dir, ts.dist);
+                m.distShadow = ps.dist; // == ts.dist: both are |center - observer| + radius
+                m.dim = L.dim;
+                m.flags = (m.flags & ~(3u << F_PEND_SHIFT)) | (((t1 ? 1u : 0u) + (t2 ? 1u : 0u)) << F_PEND_SHIFT);
+                storeMeta(pool, slot, m);
+            }
+            if (t1) {
+                dstA = S_TS; entA = slot | (1u << 12);
+                hasB = t2; entB = slot | (2u << 12);
+            } else if (t2) {
+                dstA = S_TS; entA = slot | (2u << 12);
+            } else if (doM) {
+                dstA = S_C; entA = slot;
             }
         }
 #ifdef THX_STAGE_PROFILE
