@@ -49,6 +49,9 @@ THX_DEV constexpr int cTail(int q) { return 2 * q + 1; }
 constexpr uint32_t Q_EMPTY = 0xFFFFu;  // ring cell without an entry (entries: slot < 4096 | which << 12 | lap tag << 14)
 constexpr uint32_t kIdleSpinLimit = 1u << 20; // polls (~150 cycles each): ~70 ms without any work appearing -> abort
 constexpr uint32_t kCellSpinLimit = 1u << 22;
+#ifndef THX_IDLE_SLEEP
+#define THX_IDLE_SLEEP 4 // x64 cycles between two looks of a wavefront that found no work (VALU is ~97 % busy: polling costs)
+#endif
 
 // photon flags (meta.z)
 constexpr uint32_t F_ALIVE = 1u, F_ALLOW = 2u, F_MIS_TARGET = 4u;
@@ -428,7 +431,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 if (lane == 0) ctr[C_ABORT] = 1u;
                 break;
             }
-            if (best == 0u) __builtin_amdgcn_s_sleep(4);
+            if (best == 0u) __builtin_amdgcn_s_sleep(THX_IDLE_SLEEP);
             continue;
         }
         idleSpins = 0;

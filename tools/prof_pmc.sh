@@ -22,7 +22,11 @@ for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
     for r in csv.DictReader(open(f)):
         k = r.get("Kernel_Name", "")
         if "traceKernel" not in k and "reduceKernel" not in k and "Staged" not in k: continue
-        short = "trace_debug" if "true, true>" in k else ("staged" if "Staged" in k else ("trace" if "traceKernel" in k else "reduce"))
+        import re
+        m = re.search(r"Variant<([^>]*)>", k)
+        a = [x.strip() for x in m.group(1).split(",")] if m else []
+        dbg = len(a) > 2 and a[2] == "true"  # STATS
+        short = ("staged" if "Staged" in k else ("trace" if "traceKernel" in k else "reduce")) + ("_debug" if dbg else "")
         agg[short][r["Counter_Name"]].append(float(r["Counter_Value"]))
 with open(out + "/summary.txt", "w") as fh:
     for k, d in agg.items():
