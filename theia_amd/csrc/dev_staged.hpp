@@ -12,18 +12,19 @@
 //     BIRTH -> A (free path, guide) -> T0 (primary BVH walk + surface hit)
 //           -> BM (propagate, no hit) -> M (MIS sampling)
 //           -> TS (shadow-ray walk + detector response) -> C (scatter) -> A ...
-// Every wavefront schedules itself: it claims up to 64 entries of the fullest queue
-// (one CAS on the queue head by lane 0), runs that stage on them, one photon per
-// lane, appends the photons to their next queues and looks for work again. There is
+// Every wavefront schedules itself: it claims up to 64 entries of the fullest ring
+// (one CAS on the ring head by lane 0), runs that stage on them, one photon per
+// lane, appends the photons to their next rings and looks for work again. There is
 // no workgroup barrier inside the loop, so BVH walks (gather/latency heavy) and the
 // shading stages (VALU heavy) of different wavefronts overlap on a SIMD and nobody
 // waits for the slowest wavefront of a round. Photons are independent and carry
 // their own RNG stream (= photon index) and dimension, so the order in which they
 // advance does not change any per-photon result; arithmetic, draw order and event
 // order are those of the lane kernel (the stage bodies call the same device
-// functions). Queues are rings of 16-bit entries in LDS with a cell hand-off
-// (EMPTY <-> entry) between the appending and the claiming wavefront; appends are
-// wavefront-aggregated: one __ballot, a popcount prefix and one LDS atomic.
+// functions). Rings hold 16-bit entries in LDS with a cell hand-off (EMPTY <-> entry
+// with a lap tag) between the appending and the claiming wavefront; an append is one
+// LDS atomic per lane on the ring tail. DESIGN.md section 3.1 has the measurements
+// behind every choice made here.
 #pragma once
 #include "dev_trace.hpp"
 
