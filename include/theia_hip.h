@@ -151,10 +151,22 @@ typedef struct {
     uint32_t flags;       /* THX_FLAG_* */
     uint32_t path_length; /* PATH_LENGTH macro */
     uint32_t block_size;  /* reference BLOCK_SIZE; accepted for API parity */
-    uint32_t n_bins;      /* N_BINS macro */
+    uint32_t n_bins;      /* N_BINS macro (histogram response) */
     uint32_t capacity;    /* max batch size */
-    uint32_t reserved[6];
+    uint32_t response_kind; /* THX_RESPONSE_* */
+    uint32_t hit_capacity;  /* HIT_QUEUE_SIZE macro (record response), response.py:261-266 */
+    uint32_t hit_polarized; /* HIT_QUEUE_POLARIZED macro */
+    uint32_t reserved[3];
 } thx_tracer_desc;
+
+/* which `response(HitItem)` the tracer is built with:
+ * HISTOGRAM = HistogramHitResponse(UniformValueResponse()) (response.histogram.glsl),
+ * RECORD    = HitRecorder (response.record.glsl): hits appended to a queue with the layout
+ *             of shader/response.queue.glsl:6-33 -- uint32 count, then one float column of
+ *             hit_capacity entries each for posX posY posZ dirX dirY dirZ nrmX nrmY nrmZ
+ *             [stokesI stokesQ stokesU stokesV polX polY polZ] wavelength time contrib and
+ *             an int32 column objectId. Runs on the instrumented kernel variants. */
+enum { THX_RESPONSE_HISTOGRAM = 0, THX_RESPONSE_RECORD = 1 };
 
 /* vertices [n][6] f32 = position + normal (shader/scene.types.glsl:6-9),
  * indices [m][3] u32 (:12-14) -- what hp.Mesh holds (scene.py:425-431) */
@@ -227,6 +239,13 @@ int thx_tracer_reset_stats(thx_tracer* tracer);
 /* development aid (library built with -DTHX_STAGE_PROFILE): per-stage cycles [0..15],
  * rounds [16..31], photons [32..47] of the staged scene kernel since the last call */
 int thx_tracer_read_stage_profile(thx_tracer* tracer, uint64_t* out48);
+/* HitRecorder queue (replaces hephaistos IOQueue(mode="retrieve") of response.py:219,
+ * 268-274): size in bytes of a queue, copy of the device queue to `out` (at most `nbytes`;
+ * synchronises), optionally followed by resetting its counter for the next batch. The counter
+ * keeps counting past a full queue; entries beyond hit_capacity are dropped. */
+size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized);
+int thx_tracer_read_hits(thx_tracer* tracer, void* out, size_t nbytes, int clear);
+int thx_tracer_hits_device_ptr(thx_tracer* tracer, uint64_t* dev_addr);
 /* parity probe: per-event dump of the last run, [batch][path_length+3][THX_TRACK_WORDS] */
 int thx_tracer_read_track(thx_tracer* tracer, float* out, size_t n_floats);
 /* launch geometry chosen by the library: workgroups, threads per workgroup,

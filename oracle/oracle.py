@@ -203,6 +203,15 @@ class Scene:
             pass
 
 
+def set_hit_queue(queue: np.ndarray | None, capacity: int, polarized: bool) -> None:
+    """HitRecorder response: the next traces append their hits to `queue` (uint32 array:
+    count + columns, shader/response.queue.glsl layout) instead of binning; None switches back."""
+    fn = lib().orc_set_hit_queue
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    fn.restype = None
+    fn(queue.ctypes.data if queue is not None else None, int(capacity), int(bool(polarized)))
+
+
 def trace_volume(common: Common, trace: VolumeTraceParams, target: TargetParams, *, threads: int = 0, track: bool = False):
     hist = np.zeros(common.n_bins, dtype=np.float32)
     stats = np.zeros(N_STATS, dtype=np.uint64)

@@ -582,8 +582,45 @@ typedef struct {
     int objectId;
 } HitItem;
 
+/* response.record.glsl:23-26 + SAVE_HIT of response.queue.glsl: the queue the next traces
+ * record into instead of binning (NULL: histogram response). Layout: uint32 count, then one
+ * column of `capacity` floats per field. */
+static uint32_t* g_hit_queue = NULL;
+static uint32_t g_hit_capacity = 0;
+static int g_hit_polarized = 0;
+void orc_set_hit_queue(uint32_t* queue, uint32_t capacity, int polarized) {
+    g_hit_queue = queue; g_hit_capacity = capacity; g_hit_polarized = polarized;
+}
+
+static void recordHit(Ctx* x, const HitItem* it) {
+    uint32_t id;
+    x->cnt.stats[ST_RESPONSES]++;
+#pragma omp atomic capture
+    id = g_hit_queue[0]++;
+    if (id >= g_hit_capacity) return;
+    float* col = (float*)(g_hit_queue + 1) + id;
+    const uint32_t cap = g_hit_capacity;
+#define PUT(v) do { *col = (v); col += cap; } while (0)
+    PUT(it->position.x); PUT(it->position.y); PUT(it->position.z);
+    PUT(it->direction.x); PUT(it->direction.y); PUT(it->direction.z);
+    PUT(it->normal.x); PUT(it->normal.y); PUT(it->normal.z);
+    if (g_hit_polarized) {
+        if (x->polarized) {
+            PUT(it->stokes.x); PUT(it->stokes.y); PUT(it->stokes.z); PUT(it->stokes.w);
+            PUT(it->polRef.x); PUT(it->polRef.y); PUT(it->polRef.z);
+        } else { /* response.queue.glsl:106-112 */
+            PUT(1.0f); PUT(0.0f); PUT(0.0f); PUT(0.0f);
+            PUT(0.0f); PUT(0.0f); PUT(0.0f);
+        }
+    }
+    PUT(it->wavelength); PUT(it->time); PUT(it->contrib);
+#undef PUT
+    *(int32_t*)col = it->objectId;
+}
+
 /* response.histogram.glsl:59-68 with response.uniform.glsl:4-6 */
 static void response(Ctx* x, const HitItem* item) {
+    if (g_hit_queue) { recordHit(x, item); return; }
     float value = item->contrib;
     float f = floorf((item->time - x->c->response.t0) / x->c->response.binSize);
     x->cnt.stats[ST_RESPONSES]++;

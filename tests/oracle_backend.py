@@ -33,6 +33,7 @@ class _Tracer:
         self.out = [np.zeros(spec.n_bins, np.float32) for _ in range(2)]
         self.stats = np.zeros(orc.N_STATS, np.uint64)
         self.track = None
+        self.hits = None  # HitRecorder queue: uint32 count + columns
 
 
 class OracleBackend:
@@ -124,6 +125,22 @@ class OracleBackend:
         _copy(c.wavelength, params.wavelength)
         _copy(c.response, params.response)
         want_track = bool(spec.flags & capi.FLAG_TRACK)
+        record = getattr(spec, "response_kind", 0) == capi.RESPONSE_RECORD
+        if record:
+            if t.hits is None:
+                ncol = 20 if spec.hit_polarized else 13
+                t.hits = np.zeros(1 + ncol * spec.hit_capacity, dtype=np.uint32)
+            orc.set_hit_queue(t.hits, spec.hit_capacity, spec.hit_polarized)
+        try:
+            hist, stats, track = self._trace(spec, t, c, params, want_track)
+        finally:
+            if record:
+                orc.set_hit_queue(None, 0, False)
+        t.raw[cfg] = hist
+        t.stats += stats
+        t.track = track
+
+    def _trace(self, spec, t, c, params, want_track):
         if spec.kind == capi.TRACER_VOLUME_FORWARD:
             tp, tg = orc.VolumeTraceParams(), orc.TargetParams()
             _copy(tp, params.volume)
@@ -135,9 +152,15 @@ class OracleBackend:
             _copy(g, params.guide)
             guide = None if (spec.flags & capi.FLAG_DISABLE_MIS) else g
             hist, stats, track = orc.trace_scene(c, tp, guide, t.scene, threads=self.threads, track=want_track)
-        t.raw[cfg] = hist
-        t.stats += stats
-        t.track = track
+        return hist, stats, track
+
+    def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True) -> None:
+        t = self._tracers[tracer]
+        raw = t.hits.view(np.uint8)
+        n = min(out.nbytes, raw.nbytes)
+        out.reshape(-1).view(np.uint8)[:n] = raw[:n]
+        if clear:
+            t.hits[0] = 0
 
     def tracer_reduce(self, tracer: int, cfg: int, norm: float, d_out: int = 0, stream: int = 0) -> None:
         t = self._tracers[tracer]

@@ -28,6 +28,9 @@ class TracerSpec:
     block_size: int
     n_bins: int
     capacity: int
+    response_kind: int = 0   # capi.RESPONSE_*
+    hit_capacity: int = 0    # HitRecorder queue size
+    hit_polarized: bool = False
 
 
 class HipBackend:
@@ -127,7 +130,8 @@ class HipBackend:
 
     # -- tracer ------------------------------------------------------------
     def tracer_create(self, spec: TracerSpec, scene: int | None) -> int:
-        desc = capi.TracerDesc(spec.kind, spec.flags, spec.path_length, spec.block_size, spec.n_bins, spec.capacity)
+        desc = capi.TracerDesc(spec.kind, spec.flags, spec.path_length, spec.block_size, spec.n_bins, spec.capacity,
+                               spec.response_kind, spec.hit_capacity, int(spec.hit_polarized))
         handle = C.c_void_p()
         capi.check(self._lib.thx_tracer_create(self._ctx, C.byref(desc), C.c_void_p(scene) if scene else None, C.byref(handle)))
         return handle.value
@@ -163,6 +167,10 @@ class HipBackend:
         out = np.empty((int(batch), int(events), capi.TRACK_WORDS), dtype=np.float32)
         capi.check(self._lib.thx_tracer_read_track(C.c_void_p(tracer), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
+
+    def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True) -> None:
+        """copies the HitRecorder queue into `out` (uint8) and resets its counter"""
+        capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
 
     def tracer_launch_info(self, tracer: int, batch: int) -> dict:
         g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()

@@ -25,6 +25,8 @@ __all__ = [
 
 TRACER_VOLUME_FORWARD = 0
 TRACER_SCENE_FORWARD = 1
+RESPONSE_HISTOGRAM = 0
+RESPONSE_RECORD = 1
 FLAG_POLARIZED = 1 << 0
 FLAG_DISABLE_DIRECT = 1 << 1
 FLAG_DISABLE_MIS = 1 << 2
@@ -113,7 +115,8 @@ class RunParams(_Packed):
 class TracerDesc(Structure):
     _fields_ = [
         ("kind", c_uint32), ("flags", c_uint32), ("path_length", c_uint32), ("block_size", c_uint32),
-        ("n_bins", c_uint32), ("capacity", c_uint32), ("reserved", c_uint32 * 6),
+        ("n_bins", c_uint32), ("capacity", c_uint32), ("response_kind", c_uint32), ("hit_capacity", c_uint32),
+        ("hit_polarized", c_uint32), ("reserved", c_uint32 * 3),
     ]
 
 
@@ -160,6 +163,9 @@ _PROTOS = {
     "thx_tracer_reset_stats": (c_int, [c_void_p]),
     "thx_tracer_read_stage_profile": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_read_track": (c_int, [c_void_p, POINTER(c_float), c_size_t]),
+    "thx_hit_queue_bytes": (c_size_t, [c_uint32, c_uint32]),
+    "thx_tracer_read_hits": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
+    "thx_tracer_hits_device_ptr": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "thx_tracer_last_kernel_ms": (c_int, [c_void_p, c_uint32, POINTER(c_float)]),
     "thx_tracer_kernel_times": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_uint32)]),

@@ -74,6 +74,7 @@ struct thx_tracer {
     unsigned long long* stats = nullptr;
     unsigned long long* prof = nullptr;
     float* track = nullptr;
+    uint32_t* hits = nullptr;     // HitRecorder queue (count + SoA columns) or null
     uint32_t trackEvents = 0;
     uint32_t lastBatch = 0;
     // ring of HIP event pairs bracketing the tracing kernel on its launch stream
@@ -316,7 +317,10 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
     if (desc->kind == THX_TRACER_SCENE_FORWARD && !scene)
         return fail(THX_ERR_INVALID, "scene tracer needs a scene");
-    if (desc->n_bins == 0 || desc->n_bins > 8192)
+    const bool record = desc->response_kind == THX_RESPONSE_RECORD;
+    if (desc->response_kind > THX_RESPONSE_RECORD) return fail(THX_ERR_INVALID, "unknown response kind");
+    if (record && desc->hit_capacity == 0) return fail(THX_ERR_INVALID, "cannot create a hit queue of size 0 (response.py:266-267)");
+    if (!record && (desc->n_bins == 0 || desc->n_bins > 8192))
         return fail(THX_ERR_INVALID, "n_bins must be in [1, 8192] (LDS histogram, response.py:1098)");
     if (desc->capacity == 0) return fail(THX_ERR_INVALID, "capacity must be positive");
     THX_HIP(hipSetDevice(ctx->device));
@@ -325,10 +329,13 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     t->ctx = ctx;
     t->scene = scene;
     t->desc = *desc;
+    if (record) t->desc.n_bins = 1; // the kernels keep their (unused) one-bin histogram
+    desc = &t->desc;
     const bool pol = (desc->flags & THX_FLAG_POLARIZED) != 0;
     const bool mis = (desc->flags & THX_FLAG_DISABLE_MIS) == 0;
     t->variant = traceVariant(desc->kind, pol, mis);
-    t->debug = (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK)) != 0;
+    // the record response is compiled into the instrumented variants only
+    t->debug = record || (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK)) != 0;
     t->block = kTraceBlock;
     if (scene) {
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
@@ -406,6 +413,11 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         e = hipMalloc((void**)&t->track, nb);
         if (e == hipSuccess) e = hipMemset(t->track, 0, nb);
     }
+    if (e == hipSuccess && record) {
+        const size_t nb = thx_hit_queue_bytes(desc->hit_capacity, desc->hit_polarized);
+        e = hipMalloc((void**)&t->hits, nb);
+        if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
+    }
     if (e != hipSuccess) { thx_tracer_destroy(t); return hipFail(e, "thx_tracer_create"); }
     *out = t;
     return THX_OK;
@@ -426,6 +438,7 @@ int thx_tracer_destroy(thx_tracer* t) {
     if (t->stats) hipFree(t->stats);
     if (t->prof) hipFree(t->prof);
     if (t->track) hipFree(t->track);
+    if (t->hits) hipFree(t->hits);
     delete t;
     return THX_OK;
 }
@@ -483,6 +496,9 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.slabs = t->slabs[cfg];
     a.stats = t->stats;
     a.prof = t->prof;
+    a.hits = t->hits;
+    a.hit_capacity = t->desc.hit_capacity;
+    a.hit_polarized = t->desc.hit_polarized;
     a.track = t->track;
     if (t->scene) a.scene = t->scene->view;
     uint32_t grid, ppw;
@@ -548,6 +564,28 @@ int thx_tracer_reset_stats(thx_tracer* t) {
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS));
+    return THX_OK;
+}
+
+size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized) {
+    const size_t columns = hit_polarized ? 20 : 13; // response.queue.glsl:6-33
+    return 4 + columns * 4 * (size_t)hit_capacity;
+}
+
+int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
+    if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    if (!t->hits) return fail(THX_ERR_INVALID, "tracer was not created with the record response");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    const size_t total = thx_hit_queue_bytes(t->desc.hit_capacity, t->desc.hit_polarized);
+    THX_HIP(hipMemcpy(out, t->hits, std::min(nbytes, total), hipMemcpyDeviceToHost));
+    if (clear) THX_HIP(hipMemset(t->hits, 0, 4));
+    return THX_OK;
+}
+
+int thx_tracer_hits_device_ptr(thx_tracer* t, uint64_t* dev_addr) {
+    if (!t || !dev_addr) return fail(THX_ERR_INVALID, "null argument");
+    *dev_addr = (uint64_t)(uintptr_t)t->hits;
     return THX_OK;
 }
 

@@ -43,6 +43,9 @@ struct LaunchArgs {
     uint32_t lds_nodes_word;   // LDSBVH variants: LDS word offset of the staged node array
     uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
+    uint32_t* hits;            // HitRecorder queue (response.queue.glsl layout) or null: histogram response
+    uint32_t hit_capacity;     // entries per SoA column of the queue
+    uint32_t hit_polarized;    // queue has the stokes / polRef columns
     unsigned long long* stats; // [THX_N_STATS]
     float* track;              // [batch][track_events][THX_TRACK_WORDS] or null
     unsigned long long* prof;  // staged kernel, THX_STAGE_PROFILE builds: [3][16] cycles/rounds/items per stage
@@ -121,6 +124,14 @@ struct HitItem {
     float time, contrib;
 };
 
+// where a hit happened, in the object space of what was hit (ray.response.glsl createHit
+// arguments). Only the HitRecorder response reads it.
+struct HitFrame {
+    f3 objPos, objNrm;
+    m3 worldToObj;
+    int objectId;
+};
+
 // response.histogram.glsl:59-68 + response.uniform.glsl:4-6. The bin update is an
 // LDS float atomic (ds_add_f32), the partial histogram is flushed per workgroup.
 template <class V>
@@ -134,6 +145,30 @@ THX_DEV void response(Lane<V>& L, const HitItem& item) {
     }
 }
 
+// response.record.glsl:23-26 with SAVE_HIT of response.queue.glsl: one global atomic on the
+// queue counter, then one store per column (structure of arrays, `capacity` entries each).
+// A full queue drops the hit but keeps counting, like the reference's unchecked store would
+// overrun; the host clamps the count it reports to the capacity.
+template <class V>
+THX_DEV void recordHit(Lane<V>& L, f3 pos, f3 dir, f3 nrm, f4 stokes, f3 polRef, float wavelength,
+                       float time, float contrib, int objectId) {
+    L.cnt.add(ST_RESPONSES);
+    const uint32_t cap = L.a->hit_capacity;
+    const uint32_t id = atomicAdd(L.a->hits, 1u);
+    if (id >= cap) return;
+    float* col = reinterpret_cast<float*>(L.a->hits + 1) + id;
+    auto put = [&](float v) { *col = v; col += cap; };
+    put(pos.x); put(pos.y); put(pos.z);
+    put(dir.x); put(dir.y); put(dir.z);
+    put(nrm.x); put(nrm.y); put(nrm.z);
+    if (L.a->hit_polarized) { // HIT_QUEUE_POLARIZED; an unpolarized tracer stores (1,0,0,0), 0
+        put(stokes.x); put(stokes.y); put(stokes.z); put(stokes.w);
+        put(polRef.x); put(polRef.y); put(polRef.z);
+    }
+    put(wavelength); put(time); put(contrib);
+    *reinterpret_cast<int*>(col) = objectId;
+}
+
 // ray.response.glsl:18-56 / :63-84. Only time and contribution feed the
 // histogram response; the polarized contribution picks up S0 after the frame
 // alignment (whose first row is (1,0,0,0), so S0 is the ray's S0).
@@ -142,6 +177,36 @@ THX_DEV HitItem createHit(const Ray& r) {
     float contrib = r.lin_contrib * thx_exp(r.log_contrib);
     if constexpr (V::POL) contrib *= r.stokes.x;
     return HitItem{r.time, contrib};
+}
+
+// createHit + `if (item.contrib > 0.0) response(item)` of the reference's createResponse
+// functions. The HitRecorder response exists in the instrumented kernel variants only
+// (the host selects them for a recording tracer), so the histogram path of the production
+// kernels carries none of it.
+template <class V>
+THX_DEV void respond(Lane<V>& L, const Ray& r, const HitFrame& fr) {
+    if constexpr (V::STATS) {
+        if (L.a->hits != nullptr) {
+            float contrib = r.lin_contrib * thx_exp(r.log_contrib);
+            f3 objHitDir = normalize(mul(fr.worldToObj, r.direction));
+            f4 stokes{1.0f, 0.0f, 0.0f, 0.0f};
+            f3 hitPolRef{0.0f, 0.0f, 0.0f};
+            if constexpr (V::POL) {
+                hitPolRef = perpendicularTo(objHitDir, fr.objNrm);
+                f3 objPolRef = normalize(mul(fr.worldToObj, r.polRef));
+                float c, s;
+                alignPolRef(objHitDir, objPolRef, hitPolRef, c, s);
+                f4 st = rotApply(c, s, r.stokes);
+                contrib *= st.x;
+                stokes = f4{st.x / st.x, st.y / st.x, st.z / st.x, st.w / st.x};
+            }
+            if (contrib > 0.0f)
+                recordHit(L, fr.objPos, objHitDir, fr.objNrm, stokes, hitPolRef, r.wavelength, r.time, contrib, fr.objectId);
+            return;
+        }
+    }
+    HitItem item = createHit<V>(r);
+    if (item.contrib > 0.0f) response(L, item);
 }
 
 // ----------------------------------------------------------- ray.scatter.glsl
@@ -276,6 +341,12 @@ struct TargetSample {
     float dist, prob;
     bool valid;
 };
+// target.sphere.glsl:36-41, 68-73: on the sphere target the object-space position and normal
+// are the world normal, world->object is the uniform scale 1/radius
+THX_DEV HitFrame targetFrame(const thx_run_params& p, const TargetSample& hit) {
+    const float ir = p.target.invRad;
+    return HitFrame{hit.normal, hit.normal, m3{f3{ir, 0.0f, 0.0f}, f3{0.0f, ir, 0.0f}, f3{0.0f, 0.0f, ir}}, p.volume.objectId};
+}
 
 // math.sphere.glsl:14-39 (nearest root)
 THX_DEV float intersectSphereNear(f3 center, float radius, f3 origin, f3 direction) {
@@ -351,8 +422,7 @@ THX_DEV void volCreateResponse(Lane<V>& L, Ray ray, const TargetSample& hit, f3 
     int code = propagateRayToHit<V>(ray, hit.position, hit.normal, L.a->p.volume.propagation);
     if (code < 0) return;
     ray.lin_contrib *= weight;
-    HitItem item = createHit<V>(ray);
-    if (item.contrib > 0.0f) response(L, item);
+    respond(L, ray, targetFrame(L.a->p, hit));
 }
 
 // tracer.volume.forward.glsl:103-114
@@ -401,8 +471,7 @@ THX_DEV int volTrace(Lane<V>& L, Ray& ray, uint64_t med, bool allowResponse) {
     if (result < 0) return result;
     if (hitValid && allowResponse) {
         alignRayToHit<V>(ray, hit.normal);
-        HitItem item = createHit<V>(ray);
-        if (item.contrib > 0.0f) response(L, item);
+        respond(L, ray, targetFrame(L.a->p, hit));
         return RESULT_CODE_RAY_DETECTED;
     } else if (hitValid) {
         return RESULT_CODE_RAY_ABSORBED;
@@ -733,6 +802,8 @@ struct SurfaceHit {
     uint32_t flags;
     uint64_t mat_inside, mat_outside;
     f3 worldPos, rayNrm;
+    f3 objPos, objNrm; // read by the HitRecorder response only
+    m3 worldToObj;
 };
 
 // scene.intersect.glsl:23-99. `rayDir` is ray.state.direction (not normalised).
@@ -744,6 +815,8 @@ THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const Que
     hit.inward = false; hit.customId = 0; hit.flags = 0;
     hit.mat_inside = 0; hit.mat_outside = 0;
     hit.worldPos = f3{0, 0, 0}; hit.rayNrm = f3{0, 0, 0};
+    hit.objPos = f3{0, 0, 0}; hit.objNrm = f3{0, 0, 0};
+    hit.worldToObj = m3{f3{0, 0, 0}, f3{0, 0, 0}, f3{0, 0, 0}};
     if (!hit.valid) return RESULT_CODE_RAY_MISSED;
     const InstanceRecord* inst = sc.instances + q.instance;
     const GeometryGLSL geom = sc.geometries[inst->geometry];
@@ -770,6 +843,7 @@ THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const Que
     m3 worldToObj{f3{W[0], W[4], W[8]}, f3{W[1], W[5], W[9]}, f3{W[2], W[6], W[10]}};
     f3 objDir = normalize(mul(worldToObj, rayDir));
     hit.inward = dot(objDir, objNrm) <= 0.0f;
+    hit.objPos = objPos; hit.objNrm = objNrm; hit.worldToObj = worldToObj;
 
     uint32_t flagsIn = 0, flagsOut = 0;
     hit.mat_inside = 0; hit.mat_outside = 0;
@@ -931,12 +1005,13 @@ template <class V>
 THX_DEV void sceneCreateResponse(Lane<V>& L, Ray ray, const SurfaceHit& hit,
                                  const Reflectance& surface, bool absorb) {
     if (!absorb) {
-        // HIT_USE_TRANSMITTED_DIR only changes the recorded direction, which the
-        // histogram response does not read; the transmission factor applies either way
+        // the transmission factor applies either way; HIT_USE_TRANSMITTED_DIR selects the
+        // direction a recorded hit carries (scene.traverse.glsl:42-56)
+        const f3 dir = ray.direction;
         transmitRay<V, false>(L, ray, hit, surface);
+        if (!(L.a->flags & THX_FLAG_HIT_USE_TRANSMITTED)) ray.direction = dir;
     }
-    HitItem item = createHit<V>(ray);
-    if (item.contrib > 0.0f) response(L, item);
+    respond(L, ray, HitFrame{hit.objPos, hit.objNrm, hit.worldToObj, hit.customId});
 }
 
 // scene.traverse.glsl:160-180 (ray by value; `hit` already checked for validity)

@@ -10,11 +10,11 @@ from __future__ import annotations
 import numpy as np
 
 from .. import _backend
-from . import glsl, pipeline  # noqa: F401
+from . import glsl, pipeline, queue  # noqa: F401
 
 __all__ = [
     "Mesh", "getCurrentDevice", "isRaytracingSupported", "isRaytracingEnabled", "enableRaytracing",
-    "suitableDeviceAvailable", "destroyResources", "selectDevice", "enumerateDevices", "glsl", "pipeline",
+    "suitableDeviceAvailable", "destroyResources", "selectDevice", "enumerateDevices", "glsl", "pipeline", "queue",
 ]
 
 

@@ -9,15 +9,50 @@ a slab; the reducer Kahan-sums the slabs and applies the normalisation.
 """
 from __future__ import annotations
 
-from ctypes import Structure, c_float
+from ctypes import Structure, c_float, c_int32
 from dataclasses import dataclass
+from warnings import warn
 
 import numpy as np
 
 from . import units as u
 from .hp.pipeline import SourceCodeMixin
+from .hp.queue import IOQueue
 
-__all__ = ["TraceConfig", "HitResponse", "EmptyResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse"]
+__all__ = ["HitItem", "PolarizedHitItem", "TraceConfig", "HitResponse", "EmptyResponse", "HitRecorder", "ValueResponse",
+           "UniformValueResponse", "HistogramHitResponse"]
+
+
+class HitItem(Structure):
+    """One hit in the object space of the detector it happened on (response.py:27-70,
+    shader/response.common.glsl:4-19)."""
+
+    _fields_ = [
+        ("position", c_float * 3),
+        ("direction", c_float * 3),
+        ("normal", c_float * 3),
+        ("wavelength", c_float),
+        ("time", c_float),
+        ("contrib", c_float),
+        ("objectId", c_int32),
+    ]
+
+
+class PolarizedHitItem(Structure):
+    """`HitItem` with the (normalised) Stokes vector and its reference direction
+    (response.py:73-92)."""
+
+    _fields_ = [
+        ("position", c_float * 3),
+        ("direction", c_float * 3),
+        ("normal", c_float * 3),
+        ("stokes", c_float * 4),
+        ("polarizationRef", c_float * 3),
+        ("wavelength", c_float),
+        ("time", c_float),
+        ("contrib", c_float),
+        ("objectId", c_int32),
+    ]
 
 
 @dataclass
@@ -58,6 +93,73 @@ class EmptyResponse(HitResponse):
 
     def __init__(self) -> None:
         super().__init__()
+
+
+class HitRecorder(HitResponse):
+    """
+    Records hits onto a queue that is retrieved after every batch (response.py:191-275,
+    shader/response.record.glsl). `capacity <= 0`: sized by the tracer
+    (`maxHitsPerThread * capacity`). `polarized`: the queue has the Stokes / reference columns
+    (an unpolarized tracer then stores (1, 0, 0, 0) and a null reference).
+
+    `recorder.queue.view(i)` is the queue of the most recent batch run with pipeline config
+    `i`: `.count`, `view["position"]`, ... (`theia_amd.hp.queue.QueueView`). On the device the
+    queue lives in the tracer; the append is one global atomic per hit plus one store per column.
+    """
+
+    name = "Hit Recorder"
+
+    def __init__(self, *, capacity: int = 0, polarized: bool = False) -> None:
+        super().__init__()
+        self._capacity = capacity
+        self._polarized = polarized
+        self._queue = IOQueue(PolarizedHitItem if polarized else HitItem, mode="retrieve")
+        self._program = None
+        if capacity > 0:
+            self._queue.initialize(capacity)
+
+    def prepare(self, config: TraceConfig) -> None:
+        maxHits = config.maxHitsPerThread * config.capacity
+        if self.queue.initialized and maxHits > self.capacity:
+            warn(f"tracer reported maxHits: {maxHits}, but response was initialized with capacity: {self.capacity}")
+        elif not self.queue.initialized:
+            self._capacity = max(self._capacity, maxHits)  # worst case over all tracers
+
+    def updateConfig(self, config: TraceConfig) -> None:
+        maxHits = config.batchSize * config.maxHitsPerThread
+        if not self.queue.initialized:
+            self._capacity = max(maxHits, self._capacity)
+        elif maxHits > self.capacity:
+            warn(f"tracer reported maxHits: {maxHits}, but response was initialized with capacity: {self.capacity}")
+
+    @property
+    def capacity(self) -> int:
+        """maximum number of hits kept per batch"""
+        return self._capacity
+
+    @property
+    def polarized(self) -> bool:
+        return self._polarized
+
+    @property
+    def queue(self) -> IOQueue:
+        return self._queue
+
+    def _bindParams(self, program, i: int) -> None:
+        if not self.queue.initialized:
+            if self.capacity <= 0:
+                raise RuntimeError(f"Cannot create a queue of size {self.capacity}")
+            self.queue.initialize(self.capacity)
+        super()._bindParams(program, i)
+        self._program = program
+
+    def run(self, i: int):
+        def retrieve() -> None:
+            if self._program is None:
+                raise RuntimeError("HitRecorder is not bound to a tracer")
+            self._program.read_hits(self.queue.buffer(i), clear=True)
+
+        return [retrieve]
 
 
 class ValueResponse(SourceCodeMixin):

@@ -25,7 +25,7 @@ from .hp.glsl import buffer_reference, vec3
 from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .light import ConstWavelengthSource, LightSource, SphericalLightSource, UniformWavelengthSource, WavelengthSource
 from .random import RNG, PhiloxRNG
-from .response import HistogramHitResponse, HitResponse, TraceConfig
+from .response import HistogramHitResponse, HitRecorder, HitResponse, TraceConfig
 from .scene import RectBBox, Scene
 from .target import SphereTarget, SphereTargetGuide, Target, TargetGuide
 
@@ -159,6 +159,9 @@ class _Program:
 
     def hist_ptr(self, cfg: int) -> int:
         return self.backend.tracer_hist_ptr(self.handle, cfg)
+
+    def read_hits(self, out: np.ndarray, clear: bool = True) -> None:
+        self.backend.tracer_read_hits(self.handle, out, clear)
 
     def read_stats(self) -> np.ndarray:
         return self.backend.tracer_read_stats(self.handle)
@@ -319,9 +322,16 @@ class Tracer(PipelineStage):
             P.wavelength.p0, P.wavelength.p1, P.wavelength.p2 = w.lambdaRange.x, w.lambdaRange.y, w._contrib
         else:
             P.wavelength.p0 = w.wavelength
-        rp = response._getParamsBlock("ResponseParams", i)
-        P.response.t0, P.response.binSize = rp.t0, rp.binSize
+        if isinstance(response, HistogramHitResponse):
+            rp = response._getParamsBlock("ResponseParams", i)
+            P.response.t0, P.response.binSize = rp.t0, rp.binSize
         return P
+
+    def _responseSpec(self, response) -> tuple:
+        """(n_bins, capacity, response_kind, hit_capacity, hit_polarized) of the TracerSpec"""
+        if isinstance(response, HitRecorder):
+            return (1, self.capacity, capi.RESPONSE_RECORD, response.capacity, response.polarized)
+        return (response.nBins, self.capacity, capi.RESPONSE_HISTOGRAM, 0, False)
 
     @staticmethod
     def _fillPropagation(dst, block, lower: str, upper: str) -> None:
@@ -339,8 +349,8 @@ class Tracer(PipelineStage):
             raise _unsupported("light source", source, "SphericalLightSource")
         if not isinstance(wavelength, (ConstWavelengthSource, UniformWavelengthSource)):
             raise _unsupported("wavelength source", wavelength, "ConstWavelengthSource, UniformWavelengthSource")
-        if not isinstance(response, HistogramHitResponse):
-            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse())")
+        if not isinstance(response, (HistogramHitResponse, HitRecorder)):
+            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder")
         if not isinstance(rng, PhiloxRNG):
             raise _unsupported("random number generator", rng, "PhiloxRNG")
         if not isinstance(callback, (EmptyEventCallback, EventStatisticCallback)):
@@ -411,7 +421,7 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if trackEvents else 0
         self._code = b"" if code is None else code
-        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, response.nBins, self.capacity), None)
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response)), None)
 
     callback = property(lambda self: self._callback, doc="callback called for each tracing event")
     code = property(lambda self: self._code, doc="kept for API parity; kernels are precompiled")
@@ -526,7 +536,7 @@ class SceneForwardTracer(Tracer):
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if trackEvents else 0
         self._code = b"" if code is None else code
-        self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, response.nBins, self.capacity), scene)
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response)), scene)
 
     callback = property(lambda self: self._callback)
     code = property(lambda self: self._code)
