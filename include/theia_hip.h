@@ -47,12 +47,17 @@ typedef struct {
     uint32_t offset[4];
 } thx_philox_params;
 
-/* src/theia/light.py:1132-1139; shader/lightsource.spherical.glsl:7-14 */
+/* SphericalLightSource: src/theia/light.py:1132-1139; shader/lightsource.spherical.glsl:7-14.
+ * PencilLightSource (THX_FLAG_LIGHT_PENCIL): light.py:1065-1073; shader/lightsource.pencil.glsl:4-16
+ * -- contribFwd carries its budget, direction / stokes / polRef are read by it only */
 typedef struct {
     float position[3];
     float contribFwd;
     float contribBwd;
     float t_min, t_max;
+    float direction[3];
+    float stokes[4];
+    float polRef[3];
 } thx_light_params;
 
 /* src/theia/light.py:272-273 (const) / :308-312 (uniform) */
@@ -136,7 +141,8 @@ enum {
     THX_FLAG_HIT_USE_TRANSMITTED   = 1u << 5,
     THX_FLAG_WAVELENGTH_UNIFORM    = 1u << 6, /* UniformWavelengthSource, else Const */
     THX_FLAG_STATISTICS            = 1u << 8, /* EventStatisticCallback + traversal counters */
-    THX_FLAG_TRACK                 = 1u << 9  /* per-event state dump (parity probe) */
+    THX_FLAG_TRACK                 = 1u << 9, /* per-event state dump (parity probe, TrackRecordCallback) */
+    THX_FLAG_LIGHT_PENCIL          = 1u << 10 /* PencilLightSource, else SphericalLightSource */
 };
 
 /* number of u64 counters returned by thx_tracer_read_stats: 12 event counters

@@ -23,6 +23,7 @@ FLAG_DISABLE_TRANSMISSION = 1 << 3
 FLAG_DISABLE_VOLUME_BORDER = 1 << 4
 FLAG_HIT_USE_TRANSMITTED = 1 << 5
 FLAG_WAVELENGTH_UNIFORM = 1 << 6
+FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_BRUTE_FORCE = 1 << 7
 TRACK_WORDS = 12
 N_STATS = 20
@@ -37,7 +38,8 @@ class PhiloxParams(_P):
 
 
 class LightParams(_P):
-    _fields_ = [("position", C.c_float * 3), ("contribFwd", C.c_float), ("contribBwd", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float)]
+    _fields_ = [("position", C.c_float * 3), ("contribFwd", C.c_float), ("contribBwd", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float),
+                ("direction", C.c_float * 3), ("stokes", C.c_float * 4), ("polRef", C.c_float * 3)]
 
 
 class WavelengthParams(_P):

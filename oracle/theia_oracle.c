@@ -712,6 +712,25 @@ static Ray sampleRay(Ctx* x, uint64_t medium, uint32_t idx, uint32_t* dim) {
         wcontrib = 1.0f;
     }
     MediumConstants constants = lookUpMedium(medium, wavelength, &x->cnt);
+    if (c->flags & ORC_FLAG_LIGHT_PENCIL) { /* lightsource.pencil.glsl:18-35 */
+        float v = rnd(x, idx, dim);
+        Ray r;
+        memset(&r, 0, sizeof(r));
+        r.position = V3(c->light.position[0], c->light.position[1], c->light.position[2]);
+        r.direction = V3(c->light.direction[0], c->light.direction[1], c->light.direction[2]);
+        r.medium = medium;
+        r.wavelength = wavelength;
+        r.time = f_mix(c->light.t_min, c->light.t_max, v);
+        r.lin_contrib = wcontrib * c->light.contribFwd;
+        r.log_contrib = 0.0f;
+        r.constants = constants;
+        if (x->polarized) { /* lightsource.common.glsl:88-112 */
+            r.stokes.x = c->light.stokes[0]; r.stokes.y = c->light.stokes[1];
+            r.stokes.z = c->light.stokes[2]; r.stokes.w = c->light.stokes[3];
+            r.polRef = V3(c->light.polRef[0], c->light.polRef[1], c->light.polRef[2]);
+        }
+        return r;
+    }
     /* sampleLight */
     float u0 = rnd(x, idx, dim);
     float u1 = rnd(x, idx, dim);

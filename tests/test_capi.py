@@ -29,7 +29,8 @@ def test_library_exports_every_declared_symbol():
 
 def test_parameter_block_layouts():
     # scalar layout sizes of the reference UBOs
-    assert C.sizeof(capi.PhiloxParams) == 24 and C.sizeof(capi.LightParams) == 28
+    # the light block is the spherical source's UBO (28 B) followed by what only the pencil source reads
+    assert C.sizeof(capi.PhiloxParams) == 24 and C.sizeof(capi.LightParams) == 28 + 40 and capi.LightParams.direction.offset == 28
     assert C.sizeof(capi.TargetParams) == 36 and C.sizeof(capi.GuideParams) == 20
     assert C.sizeof(capi.PropagateParams) == 36
     assert C.sizeof(capi.VolumeTraceParams) == 48 and C.sizeof(capi.SceneTraceParams) == 48
@@ -42,12 +43,13 @@ def test_parameter_block_layouts():
                  (capi.WavelengthParams, orc.WavelengthParams)]:
         assert C.sizeof(a) == C.sizeof(b)
     # host stage blocks == C ABI blocks
-    from theia_amd.light import SphericalLightSource
+    from theia_amd.light import PencilLightSource, SphericalLightSource
     from theia_amd.random import PhiloxRNG
     from theia_amd.target import SphereTarget, SphereTargetGuide
     from theia_amd.trace import SceneForwardTracer, VolumeForwardTracer
 
-    assert C.sizeof(SphericalLightSource.LightParams) == C.sizeof(capi.LightParams)
+    assert C.sizeof(SphericalLightSource.LightParams) == capi.LightParams.direction.offset
+    assert C.sizeof(PencilLightSource.LightParams) == 64  # light.py:1065-1073
     assert C.sizeof(PhiloxRNG.PhiloxParams) == C.sizeof(capi.PhiloxParams)
     assert C.sizeof(SphereTarget.TargetParams) == C.sizeof(capi.TargetParams)
     assert C.sizeof(SphereTargetGuide.TargetGuideParams) == C.sizeof(capi.GuideParams)

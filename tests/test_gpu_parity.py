@@ -86,6 +86,52 @@ def test_ray_query_matches_brute_force(hip, mesh, scale):
     hip.scene_destroy(hs)
 
 
+@pytest.mark.parametrize("mesh,scale", [("sphere", 5.0), ("cube", 0.5), ("torus", 1.0)])
+def test_ray_query_axis_parallel_rays(hip, mesh, scale):
+    """rays with exactly zero direction components (1/d = inf) and rays through the centre of the
+    cube's faces (the shared diagonal of two triangles): the slab test must not cull the boxes the
+    origin lies in, the watertight triangle test must not leak. A laser along +x is the reference's
+    own beam-splitter test (tests/test_trace.py:1234-1239)."""
+    from theia_amd.scene import Transform
+
+    m = S.bundled_mesh(mesh)
+    meshes = [(m.vertices, m.indices)]
+    # axis-aligned instance so that object-space rays stay axis parallel, plus a rotated one
+    inst = [(0, Transform.TRS(scale=scale, translate=(0.25, -0.5, 0.125)).numpy(), 3, 0),
+            (0, Transform.TRS(scale=scale, rotate=(0.0, 0.0, 1.0, 45.0), translate=(4.0 * scale, 0.0, 0.0)).numpy(), 4, 0)]
+    hs = hip.scene_create(meshes, inst)
+    ob = OracleBackend(brute_force=True)
+    os_ = ob.scene_create(meshes, inst)
+    rng = np.random.default_rng(11)
+    n = 3000
+    o = (rng.uniform(-1.5, 1.5, size=(n, 3)) * scale + np.array([0.25, -0.5, 0.125])).astype(np.float32)
+    d = np.zeros((n, 3), np.float32)
+    axis = rng.integers(0, 3, n)
+    d[np.arange(n), axis] = rng.choice([-1.0, 1.0], n)
+    two = rng.random(n) < 0.3  # a third of the rays: one zero component only
+    d[two, (axis[two] + 1) % 3] = rng.normal(size=two.sum())
+    d /= np.linalg.norm(d, axis=1, keepdims=True)
+    # rays through the instance centre along the axes (cube: the face diagonals), exact zeros in o
+    c = np.array([0.25, -0.5, 0.125], np.float32)
+    for k in range(3):
+        for sgn in (-1.0, 1.0):
+            oo = c.copy(); oo[k] -= sgn * 3.0 * scale
+            dd = np.zeros(3, np.float32); dd[k] = sgn
+            o = np.vstack([o, oo]); d = np.vstack([d, dd])
+    o = np.vstack([o, [[-20.0, 0.0, 0.0]]]).astype(np.float32); d = np.vstack([d, [[1.0, 0.0, 0.0]]]).astype(np.float32)
+    got = hip.scene_query(hs, o, d, 1e4)
+    want = ob.scene_query(os_, o, d, 1e4)
+    assert np.array_equal(got[:, 0], want[:, 0])  # hit / miss
+    hit = want[:, 0] > 0
+    assert hit.sum() > 300
+    assert np.array_equal(got[hit, 1], want[hit, 1])  # instance
+    assert np.array_equal(got[hit, 3], want[hit, 3])  # t bitwise; on a shared edge either triangle is a valid answer
+    same_prim = got[hit, 2] == want[hit, 2]
+    assert same_prim.mean() > 0.95
+    assert np.array_equal(got[hit][same_prim][:, 4:].view(np.uint32), want[hit][same_prim][:, 4:].view(np.uint32))
+    hip.scene_destroy(hs)
+
+
 def _both(make, **kw):
     """runs the scenario on the oracle and on the GPU; returns (scenario, hist, stats, track) pairs"""
     out = []

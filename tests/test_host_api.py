@@ -9,7 +9,7 @@ import theia_amd.units as u
 from theia_amd.hp import pipeline as pl
 from theia_amd.light import ConstWavelengthSource, SphericalLightSource, UniformWavelengthSource
 from theia_amd.random import PhiloxRNG
-from theia_amd.response import EmptyResponse, HistogramHitResponse, UniformValueResponse, ValueResponse
+from theia_amd.response import EmptyResponse, HistogramHitResponse, HitResponse, UniformValueResponse, ValueResponse
 from theia_amd.scene import RectBBox, Transform
 from theia_amd.target import SphereTarget, SphereTargetGuide
 from theia_amd.trace import EventStatisticCallback, SceneForwardTracer, VolumeForwardTracer
@@ -95,8 +95,12 @@ def test_unsupported_components_raise_clearly(oracle_backend):
 
     with pytest.raises(NotImplementedError, match="UniformValueResponse"):
         HistogramHitResponse(MyValue())
+    class MyResponse(HitResponse):
+        pass
+
     with pytest.raises(NotImplementedError, match="HistogramHitResponse"):
-        VolumeForwardTracer(10, sc.light, sc.target, sc.wavelength, EmptyResponse(), sc.rng, medium=0)
+        VolumeForwardTracer(10, sc.light, sc.target, sc.wavelength, MyResponse(), sc.rng, medium=0)
+    VolumeForwardTracer(10, sc.light, sc.target, sc.wavelength, EmptyResponse(), sc.rng, medium=0)  # response.empty.glsl
     with pytest.raises(NotImplementedError, match="SphereTarget"):
         VolumeForwardTracer(10, sc.light, SphereTargetGuide(), sc.wavelength, sc.response, sc.rng, medium=0)
     with pytest.raises(NotImplementedError):

@@ -239,6 +239,100 @@ def test_SceneForwardTracer(backend, polarized, disableDirect, disableVolumeBord
         assert np.abs(np.abs((polRef_exp * polRef).sum(-1))[mask] - 1.0).max() < 1e-6
 
 
+def test_volumeBorder(backend):
+    """/root/reference/tests/test_trace.py:1122-1193: a laser from vacuum into a glass cube marked
+    as volume border: no refraction, ray parameters updated (group index)."""
+    if not hp.isRaytracingEnabled():
+        pytest.skip("ray tracing is not supported")
+
+    N = 32 * 256
+    LAMBDA = 500.0 * u.nm
+
+    model = theia.material.BK7Model()
+    glass = model.createMedium()
+    mat = theia.material.Material("mat", glass, None, flags=("V", "B"))
+    matStore = theia.material.MaterialStore([mat])
+    store = theia.scene.MeshStore({"cube": S.bundled_mesh("cube")})  # reference: assets/cube.ply
+    trafo = Transform.TRS(scale=50.0, translate=(75.0, 0.0, 0.0))
+    cube = store.createInstance("cube", "mat", trafo)
+    scene = theia.scene.Scene([cube], matStore.material)
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource(lambdaRange=(LAMBDA, LAMBDA))  # const lambda
+    source = theia.light.PencilLightSource(
+        position=(0.0, 0.0, 0.0),
+        # important: hit cube not straight on but in angle to test for no refraction
+        direction=(0.8, 0.36, 0.48),
+        timeRange=(0.0, 0.0),  # const time
+        budget=1.0,
+    )
+    estimator = theia.response.EmptyResponse()
+    tracker = theia.trace.TrackRecordCallback(N, 4)
+    tracer = theia.trace.SceneForwardTracer(N, source, photons, estimator, rng, callback=tracker, scene=scene, targetId=1,
+                                            maxPathLength=2)
+    pl.runPipeline(tracer.collectStages())
+
+    track, lengths, codes = tracker.result(0)
+    # check for no refraction (straight line)
+    assert lengths.min() >= 2
+    d1 = track[:, 1, :3] - track[:, 0, :3]
+    l1 = np.sqrt(np.square(d1).sum(-1))
+    d2 = track[:, 2, :3] - track[:, 1, :3]
+    l2 = np.sqrt(np.square(d2).sum(-1))
+    cos_theta = np.multiply(d1, d2).sum(-1) / (l1 * l2)
+    assert cos_theta.min() >= 1.0 - 1e-5
+    # check ray slowed down
+    t1 = track[:, 1, 3] - track[:, 0, 3]
+    t2 = track[:, 2, 3] - track[:, 1, 3]
+    n1 = theia.material.speed_of_light / (l1 / t1)
+    n2 = theia.material.speed_of_light / (l2 / t2)
+    n2_exp = theia.material.speed_of_light / model.group_velocity(LAMBDA)
+    assert np.abs(n1 - 1.0).max() < 5e-5
+    assert np.abs(n2 - n2_exp).max() < 5e-5
+
+
+@pytest.mark.parametrize("flag,reflectance,err", [("T", 0.0, 0.0), ("R", 1.0, 0.0), ("TR", 0.0516, 0.005)])
+def test_tracer_reflection(backend, flag, reflectance, err):
+    """/root/reference/tests/test_trace.py:1196-1277: laser -> 45 deg BK7 beam splitter -> one detector
+    behind it (transmitted), one below (reflected); Fresnel reflectance 0.0516 +- 0.005."""
+    if not hp.isRaytracingEnabled():
+        pytest.skip("ray tracing is not supported")
+
+    N = 32 * 256
+
+    glass = theia.material.BK7Model().createMedium()
+    # only enable transmission on rays going outwards the splitter
+    mat = theia.material.Material("mat", glass, None, flags=(flag, "T"))
+    det = theia.material.Material("det", glass, None, flags="DB")
+    matStore = theia.material.MaterialStore([mat, det])
+    store = theia.scene.MeshStore({"cube": S.bundled_mesh("cube")})  # reference: assets/cube.ply
+    splitter_trans = Transform.TRS(scale=(0.1, 5.0, 5.0), rotate=(0.0, 0.0, 1.0, 45.0), translate=(0.141, 0.0, 0.0))
+    splitter = store.createInstance("cube", "mat", splitter_trans)
+    ref_trans = Transform.TRS(scale=(50.0, 0.5, 50.0), translate=(0.0, -50.0, 0.0))
+    ref_det = store.createInstance("cube", "det", ref_trans, detectorId=1)
+    trans_trans = Transform.TRS(scale=(0.5, 50.0, 50.0), translate=(50.0, 0.0, 0.0))
+    trans_det = store.createInstance("cube", "det", trans_trans, detectorId=2)
+    scene = theia.scene.Scene([splitter, trans_det, ref_det], matStore.material)
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource(lambdaRange=(500.0, 500.0) * u.nm)  # const lambda
+    source = theia.light.PencilLightSource(position=(-20.0, 0.0, 0.0) * u.m, direction=(1.0, 0.0, 0.0),
+                                           timeRange=(0.0, 0.0), budget=1.0)
+    recorder = theia.response.HitRecorder()
+    tracer = theia.trace.SceneForwardTracer(N, source, photons, recorder, rng, scene=scene, targetId=1, maxPathLength=4)
+    pipeline = pl.Pipeline(tracer.collectStages())
+    pipeline.run(0)
+    hits_ref = recorder.queue.view(0)
+    # run for second detector
+    tracer.setParam("targetId", 2)
+    pipeline.run(1)
+    hits_trans = recorder.queue.view(1)
+
+    assert hits_ref.count + hits_trans.count == N
+    reflectance_sim = hits_ref.count / N
+    assert np.abs(reflectance_sim - reflectance) <= err
+
+
 def _hits_table(view) -> np.ndarray:
     """one row per hit: time, contrib, wavelength, position, direction, normal[, stokes, polRef]"""
     h = view[: view.count]

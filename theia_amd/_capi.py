@@ -20,7 +20,7 @@ __all__ = [
     "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
     "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
-    "FLAG_STATISTICS", "FLAG_TRACK", "EXPORTED_SYMBOLS",
+    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "EXPORTED_SYMBOLS",
 ]
 
 TRACER_VOLUME_FORWARD = 0
@@ -36,6 +36,7 @@ FLAG_HIT_USE_TRANSMITTED = 1 << 5
 FLAG_WAVELENGTH_UNIFORM = 1 << 6
 FLAG_STATISTICS = 1 << 8
 FLAG_TRACK = 1 << 9
+FLAG_LIGHT_PENCIL = 1 << 10
 N_STATS = 20
 TRACK_WORDS = 12
 STAT_NAMES = (
@@ -66,7 +67,8 @@ class PhiloxParams(_Packed):
 
 
 class LightParams(_Packed):
-    _fields_ = [("position", c_float * 3), ("contribFwd", c_float), ("contribBwd", c_float), ("t_min", c_float), ("t_max", c_float)]
+    _fields_ = [("position", c_float * 3), ("contribFwd", c_float), ("contribBwd", c_float), ("t_min", c_float), ("t_max", c_float),
+                ("direction", c_float * 3), ("stokes", c_float * 4), ("polRef", c_float * 3)]
 
 
 class WavelengthParams(_Packed):

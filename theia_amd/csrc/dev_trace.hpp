@@ -313,6 +313,25 @@ THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
         wcontrib = 1.0f;
     }
     MediumConstants constants = lookUpMedium(medium, wavelength, L.cnt);
+    if (L.a->flags & THX_FLAG_LIGHT_PENCIL) { // lightsource.pencil.glsl:18-35
+        float v = draw(L);
+        Ray r;
+        r.position = ld3(P.light.position);
+        r.direction = ld3(P.light.direction);
+        r.medium = medium;
+        r.wavelength = wavelength;
+        r.time = mixf(P.light.t_min, P.light.t_max, v);
+        r.lin_contrib = wcontrib * P.light.contribFwd;
+        r.log_contrib = 0.0f;
+        r.constants = constants;
+        r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
+        r.polRef = f3{0.0f, 0.0f, 0.0f};
+        if constexpr (V::POL) { // lightsource.common.glsl:88-112 (polarized source ray)
+            r.stokes = f4{P.light.stokes[0], P.light.stokes[1], P.light.stokes[2], P.light.stokes[3]};
+            r.polRef = ld3(P.light.polRef);
+        }
+        return r;
+    }
     float u0 = draw(L);
     float u1 = draw(L);
     f3 rayDir = sphericalToCartessian(TWO_PI * u0, 2.0f * u1 - 1.0f);
@@ -587,17 +606,22 @@ THX_DEV bool woopTri(const WoopRay& w, f3 org, f3 p0, f3 p1, f3 p2, float& t_io,
 // The ray is kept as (1/d, -o/d) so that a plane distance is one fma, x and y of a
 // corner in one v_pk_fma_f32 (the loaded float4 holds them in an aligned register
 // pair). The boxes are padded by the builder and the interval test carries a 4e-7
-// slack, so the rounding of this form cannot drop a box that holds a hit. A NaN
-// (0 * inf for an axis-parallel ray on a plane) drops out of v_min/v_max, i.e. that
-// axis does not cull: conservative.
+// slack, so the rounding of this form cannot drop a box that holds a hit.
+// 1/d is clamped to +-1e30: with an infinite reciprocal (axis-parallel ray, d = 0) the
+// far plane of a slab the origin lies in would come out as inf - inf = NaN, v_max would
+// return the near plane's -inf for it and the box would be culled. With 1e30 both planes
+// stay finite (|plane| * 1e30 < FLT_MAX for coordinates below 1e8 m) and keep their signs:
+// the padding of the boxes (2e-6 relative) is far above the 6e-8 relative rounding of the
+// product.
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct SlabRay {
     v2f inv_xy, noi_xy; // 1/d and -(o/d), x and y
     float inv_z, noi_z;
 };
+THX_DEV float slabInv(float d) { return fminf(fmaxf(1.0f / d, -1.0e30f), 1.0e30f); }
 THX_DEV SlabRay slabRay(f3 o, f3 d) {
     SlabRay r;
-    const float ix = 1.0f / d.x, iy = 1.0f / d.y, iz = 1.0f / d.z;
+    const float ix = slabInv(d.x), iy = slabInv(d.y), iz = slabInv(d.z);
     r.inv_xy = v2f{ix, iy};
     r.noi_xy = v2f{-(o.x * ix), -(o.y * iy)};
     r.inv_z = iz;

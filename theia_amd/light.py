@@ -11,10 +11,11 @@ from ctypes import Structure, c_float
 import numpy as np
 
 from . import units as u
-from .hp.glsl import vec2, vec3
+from .hp.glsl import vec2, vec3, vec4
 from .hp.pipeline import SourceCodeMixin
 
-__all__ = ["WavelengthSource", "ConstWavelengthSource", "UniformWavelengthSource", "LightSource", "SphericalLightSource"]
+__all__ = ["WavelengthSource", "ConstWavelengthSource", "UniformWavelengthSource", "LightSource", "SphericalLightSource",
+           "PencilLightSource"]
 
 
 class WavelengthSource(SourceCodeMixin):
@@ -131,3 +132,23 @@ class SphericalLightSource(LightSource):
         self.setParam("_contribFwd", self.budget)
         # backward mode integrates over the sphere of directions
         self.setParam("_contribBwd", self.budget / (4.0 * np.pi))
+
+
+class PencilLightSource(LightSource):
+    """Pencil beam: every photon starts at `position` along `direction` at a time drawn from
+    `timeRange`; `budget` is shared by the sampled photons. Polarized tracers take the beam's
+    `stokes` vector and `polarizationRef` (unit, perpendicular to `direction`). 1 draw.
+    Reference: light.py:1024-1110, shader/lightsource.pencil.glsl."""
+
+    name = "Pencil Light Source"
+
+    class LightParams(Structure):
+        _fields_ = [("position", vec3), ("direction", vec3), ("budget", c_float), ("timeRange", vec2), ("stokes", vec4),
+                    ("polarizationRef", vec3)]
+
+    def __init__(self, *, position=(0.0, 0.0, 0.0), direction=(0.0, 0.0, 1.0), timeRange=(0.0, 100.0) * u.ns,
+                 budget: float = 1.0, stokes=(1.0, 0.0, 0.0, 0.0), polarizationRef=(0.0, 1.0, 0.0)) -> None:
+        super().__init__(supportForward=True, supportBackward=False, nRNGForward=1, nRNGBackward=0,
+                         params={"LightParams": PencilLightSource.LightParams})
+        self.setParams(position=position, direction=direction, timeRange=timeRange, budget=budget, stokes=stokes,
+                       polarizationRef=polarizationRef)

@@ -89,7 +89,10 @@ class HitResponse(SourceCodeMixin):
 
 
 class EmptyResponse(HitResponse):
-    """Ignores all hits. Not executable on the HIP backend (no kernel variant)."""
+    """Ignores all hits (response.empty.glsl). Runs as a one-bin histogram nobody reads."""
+
+    def run(self, i: int):
+        return []
 
     def __init__(self) -> None:
         super().__init__()

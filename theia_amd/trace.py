@@ -23,15 +23,16 @@ from . import _capi as capi
 from . import units as u
 from .hp.glsl import buffer_reference, vec3
 from .hp.pipeline import PipelineStage, SourceCodeMixin
-from .light import ConstWavelengthSource, LightSource, SphericalLightSource, UniformWavelengthSource, WavelengthSource
+from .light import (ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
+                    WavelengthSource)
 from .random import RNG, PhiloxRNG
-from .response import HistogramHitResponse, HitRecorder, HitResponse, TraceConfig
+from .response import EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, TraceConfig
 from .scene import RectBBox, Scene
 from .target import SphereTarget, SphereTargetGuide, Target, TargetGuide
 
 __all__ = [
     "EmptyEventCallback", "EventResultCode", "EventStatisticCallback", "SceneForwardTracer", "Tracer",
-    "TraceEventCallback", "VolumeForwardTracer",
+    "TraceEventCallback", "TrackRecordCallback", "VolumeForwardTracer",
 ]
 
 
@@ -100,6 +101,64 @@ for _k, _n in enumerate(EventStatisticCallback._FIELDS):
     setattr(EventStatisticCallback, _n, _stat_property(_k, f"number of '{_n}' events"))
 
 
+class TrackRecordCallback(TraceEventCallback):
+    """
+    Records the position and time of every event of the first `capacity` photons, up to
+    `length` points per photon (reference: trace.py:189-299, shader/callback.track.glsl).
+    `result(i)` -> `(tracks[capacity, length, 4] = x, y, z, t; lengths; codes)`: the index of a
+    photon's last event and its result code; points beyond a track's length hold garbage, as
+    in the reference. Selects the instrumented kernel variant with the per-event state dump
+    (`THX_FLAG_TRACK`); `polarized=True` (Stokes vector and reference per point) is not built.
+    """
+
+    name = "Track Recorder"
+
+    def __init__(self, capacity: int, length: int, *, polarized: bool = False, retrieve: bool = True) -> None:
+        super().__init__()
+        if polarized:
+            raise NotImplementedError("TrackRecordCallback(polarized=True) has no kernel variant on the HIP backend")
+        self._capacity, self._length, self._polarized, self._retrieve = capacity, length, polarized, retrieve
+        self._program = None
+        self._batch = [0, 0]
+        self._result = [None, None]
+
+    capacity = property(lambda self: self._capacity, doc="number of rays that can be recorded")
+    length = property(lambda self: self._length, doc="max number of points per track")
+    polarized = property(lambda self: self._polarized)
+    retrieve = property(lambda self: self._retrieve)
+
+    def _bindParams(self, program, i: int) -> None:
+        self._program = program
+
+    def run(self, i: int):
+        def fetch() -> None:
+            if self._program is None:
+                raise RuntimeError("TrackRecordCallback is not bound to a tracer")
+            dump = self._program.read_track(self._program.last_batch)  # [photon][event][12]
+            n = min(self._capacity, dump.shape[0])
+            ev = dump.shape[1]
+            code = dump[:n, :, 0].astype(np.int32)
+            # a photon's events are consecutive from index 0 and end with its first negative code;
+            # MAX_ITER does not progress the track (callback.track.glsl:29-30)
+            stop = np.argmax(code < 0, axis=1)
+            last = np.where(code[np.arange(n), stop] == int(EventResultCode.MAX_ITER), stop - 1, stop)
+            tracks = np.zeros((self._capacity, self._length, 4), dtype=np.float32)
+            m = min(ev, self._length)
+            tracks[:n, :m, :3] = dump[:n, :m, 1:4]
+            tracks[:n, :m, 3] = dump[:n, :m, 7]
+            lengths = np.zeros(self._capacity, dtype=np.uint32)
+            codes = np.zeros(self._capacity, dtype=np.int32)
+            lengths[:n] = last
+            codes[:n] = code[np.arange(n), last]
+            self._result[i] = (tracks, lengths, codes)
+
+        return [fetch] if self._retrieve else []
+
+    def result(self, i: int):
+        """tracks, lengths and last result codes of the most recent batch run with config `i`"""
+        return self._result[i]
+
+
 class EventResultCode(IntEnum):
     """Result codes passed to event callbacks; negative codes stop the photon
     (shader/result.glsl:10-28)."""
@@ -131,6 +190,7 @@ class _Program:
         self._scene = scene
         self._handle = None
         self._be = None
+        self.last_batch = 0
 
     @property
     def created(self) -> bool:
@@ -149,6 +209,7 @@ class _Program:
         return self._be
 
     def run(self, cfg: int, params: capi.RunParams) -> None:
+        self.last_batch = int(params.dispatch.batchSize)
         self.backend.tracer_run(self.handle, cfg, params)
 
     def reduce(self, cfg: int, norm: float, d_out: int = 0) -> None:
@@ -315,8 +376,16 @@ class Tracer(PipelineStage):
             P.philox.offset[k] = r.offset.word[k]
         l = source._getParamsBlock("LightParams", i)
         P.light.position[0], P.light.position[1], P.light.position[2] = l.position.x, l.position.y, l.position.z
-        P.light.contribFwd, P.light.contribBwd = l._contribFwd, l._contribBwd
         P.light.t_min, P.light.t_max = l.timeRange.x, l.timeRange.y
+        if isinstance(source, PencilLightSource):
+            P.light.contribFwd, P.light.contribBwd = l.budget, 0.0
+            for k, c in enumerate("xyz"):
+                P.light.direction[k] = getattr(l.direction, c)
+                P.light.polRef[k] = getattr(l.polarizationRef, c)
+            for k, c in enumerate("xyzw"):
+                P.light.stokes[k] = getattr(l.stokes, c)
+        else:
+            P.light.contribFwd, P.light.contribBwd = l._contribFwd, l._contribBwd
         w = wavelength._getParamsBlock("WavelengthParams", i)
         if isinstance(wavelength, UniformWavelengthSource):
             P.wavelength.p0, P.wavelength.p1, P.wavelength.p2 = w.lambdaRange.x, w.lambdaRange.y, w._contrib
@@ -331,6 +400,8 @@ class Tracer(PipelineStage):
         """(n_bins, capacity, response_kind, hit_capacity, hit_polarized) of the TracerSpec"""
         if isinstance(response, HitRecorder):
             return (1, self.capacity, capi.RESPONSE_RECORD, response.capacity, response.polarized)
+        if isinstance(response, EmptyResponse):  # response.empty.glsl: hits are dropped (a one-bin histogram nobody reads)
+            return (1, self.capacity, capi.RESPONSE_HISTOGRAM, 0, False)
         return (response.nBins, self.capacity, capi.RESPONSE_HISTOGRAM, 0, False)
 
     @staticmethod
@@ -345,16 +416,16 @@ class Tracer(PipelineStage):
 
     @staticmethod
     def _checkComponents(source, wavelength, response, rng, callback) -> None:
-        if not isinstance(source, SphericalLightSource):
-            raise _unsupported("light source", source, "SphericalLightSource")
+        if not isinstance(source, (SphericalLightSource, PencilLightSource)):
+            raise _unsupported("light source", source, "SphericalLightSource, PencilLightSource")
         if not isinstance(wavelength, (ConstWavelengthSource, UniformWavelengthSource)):
             raise _unsupported("wavelength source", wavelength, "ConstWavelengthSource, UniformWavelengthSource")
-        if not isinstance(response, (HistogramHitResponse, HitRecorder)):
-            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder")
+        if not isinstance(response, (HistogramHitResponse, HitRecorder, EmptyResponse)):
+            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder, EmptyResponse")
         if not isinstance(rng, PhiloxRNG):
             raise _unsupported("random number generator", rng, "PhiloxRNG")
-        if not isinstance(callback, (EmptyEventCallback, EventStatisticCallback)):
-            raise _unsupported("event callback", callback, "EmptyEventCallback, EventStatisticCallback")
+        if not isinstance(callback, (EmptyEventCallback, EventStatisticCallback, TrackRecordCallback)):
+            raise _unsupported("event callback", callback, "EmptyEventCallback, EventStatisticCallback, TrackRecordCallback")
 
 
 class VolumeForwardTracer(Tracer):
@@ -419,7 +490,8 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_DISABLE_MIS if disableTargetSampling else 0
         flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
-        flags |= capi.FLAG_TRACK if trackEvents else 0
+        flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
+        flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response)), None)
 
@@ -534,7 +606,8 @@ class SceneForwardTracer(Tracer):
         flags |= capi.FLAG_HIT_USE_TRANSMITTED if useRefractedHitDir else 0
         flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
-        flags |= capi.FLAG_TRACK if trackEvents else 0
+        flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
+        flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response)), scene)
 
