@@ -577,8 +577,21 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
     if (!t->hits) return fail(THX_ERR_INVALID, "tracer was not created with the record response");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
-    const size_t total = thx_hit_queue_bytes(t->desc.hit_capacity, t->desc.hit_polarized);
-    THX_HIP(hipMemcpy(out, t->hits, std::min(nbytes, total), hipMemcpyDeviceToHost));
+    // the counter first, then of every column only the entries that were appended (a queue is
+    // sized for the worst case, maxHitsPerThread * batch: reading it whole would move ~10x more)
+    const size_t cap = t->desc.hit_capacity, columns = t->desc.hit_polarized ? 20 : 13;
+    if (nbytes < 4) return fail(THX_ERR_INVALID, "output buffer too small");
+    uint32_t count = 0;
+    THX_HIP(hipMemcpy(&count, t->hits, 4, hipMemcpyDeviceToHost));
+    std::memcpy(out, &count, 4);
+    const size_t n = std::min<size_t>(count, cap);
+    for (size_t c = 0; c < columns && n > 0; ++c) {
+        const size_t off = 4 + c * cap * 4;
+        if (off >= nbytes) break;
+        const size_t bytes = std::min(n * 4, nbytes - off);
+        THX_HIP(hipMemcpyAsync((char*)out + off, (const char*)t->hits + off, bytes, hipMemcpyDeviceToHost, t->ctx->stream));
+    }
+    THX_HIP(hipStreamSynchronize(t->ctx->stream));
     if (clear) THX_HIP(hipMemset(t->hits, 0, 4));
     return THX_OK;
 }

@@ -16,7 +16,7 @@ from ctypes import Structure
 
 import numpy as np
 
-__all__ = ["QueueView", "IOQueue", "queueSize", "as_queue"]
+__all__ = ["QueueView", "IOQueue", "queueSize", "as_queue", "dumpQueue"]
 
 
 def _columns(item: type[Structure]) -> list[tuple[str, np.dtype, int, int]]:
@@ -107,6 +107,12 @@ class QueueView:
 
 def as_queue(data: np.ndarray, item: type[Structure], *, capacity: int, skipCounter: bool = False) -> QueueView:
     return QueueView(np.asarray(data).view(np.uint8).reshape(-1), item, capacity, skipCounter=skipCounter)
+
+
+def dumpQueue(view: QueueView) -> dict[str, np.ndarray]:
+    """copies of the valid items of a queue, one array per field (hephaistos.queue.dumpQueue)"""
+    n = view.count if view.hasCounter else len(view)
+    return {name: np.array(view[name][:n]) for name in view.fields}
 
 
 class IOQueue:
