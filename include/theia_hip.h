@@ -142,7 +142,9 @@ enum {
     THX_FLAG_WAVELENGTH_UNIFORM    = 1u << 6, /* UniformWavelengthSource, else Const */
     THX_FLAG_STATISTICS            = 1u << 8, /* EventStatisticCallback + traversal counters */
     THX_FLAG_TRACK                 = 1u << 9, /* per-event state dump (parity probe, TrackRecordCallback) */
-    THX_FLAG_LIGHT_PENCIL          = 1u << 10 /* PencilLightSource, else SphericalLightSource */
+    THX_FLAG_LIGHT_PENCIL          = 1u << 10, /* PencilLightSource, else SphericalLightSource */
+    THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;
+                                                  thx_target_params.hemisphereProb then holds its `prob` = 1/area */
 };
 
 /* number of u64 counters returned by thx_tracer_read_stats: 12 event counters

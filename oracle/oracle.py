@@ -24,6 +24,7 @@ FLAG_DISABLE_VOLUME_BORDER = 1 << 4
 FLAG_HIT_USE_TRANSMITTED = 1 << 5
 FLAG_WAVELENGTH_UNIFORM = 1 << 6
 FLAG_LIGHT_PENCIL = 1 << 10
+FLAG_TARGET_INNER = 1 << 11
 FLAG_BRUTE_FORCE = 1 << 7
 TRACK_WORDS = 12
 N_STATS = 20

@@ -798,8 +798,46 @@ static TargetSample targetMiss(void) { /* target.common.glsl:79-91 */
     return s;
 }
 
+/* math.sphere.glsl:14-39, farthest root (.y) */
+static float intersectSphereFar(vec3 center, float radius, vec3 origin, vec3 direction) {
+    vec3 f = v_sub(origin, center);
+    float b2 = v_dot(f, direction);
+    float r2 = radius * radius;
+    vec3 fd = v_sub(f, v_scale(direction, b2));
+    float discr = r2 - v_dot(fd, fd);
+    float ry = INFINITY;
+    if (discr >= 0.0f) {
+        float cc = v_dot(f, f) - r2;
+        float q = -b2 - signBit(b2) * sqrtf(discr);
+        float rx = cc / q;
+        ry = q;
+        if (rx > ry) ry = rx;
+    }
+    return ry;
+}
+
+static int g_target_inner = 0; /* set per trace from ORC_FLAG_TARGET_INNER */
+
+/* target.sphere.inner.glsl:36-57 */
+static TargetSample intersectTargetInner(const orc_target_params* tp, vec3 observer, vec3 direction) {
+    vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
+    float t = intersectSphereFar(center, tp->radius, observer, direction);
+    int hit = (t > 0.0f) && !isinf(t);
+    TargetSample s;
+    memset(&s, 0, sizeof(s));
+    vec3 pos = v_add(observer, v_scale(direction, t));
+    vec3 nrm = v_normalize(v_sub(center, pos));
+    s.position = pos; s.normal = nrm; s.dist = t;
+    s.objPosition = v_scale(nrm, -1.0f); s.objNormal = nrm;
+    s.prob = tp->hemisphereProb; s.valid = hit;
+    s.offset = V3(tp->invPos[0], tp->invPos[1], tp->invPos[2]);
+    s.invRad = tp->invRad;
+    return s;
+}
+
 /* target.sphere.glsl:45-78 */
 static TargetSample intersectTarget(const orc_target_params* tp, vec3 observer, vec3 direction) {
+    if (g_target_inner) return intersectTargetInner(tp, observer, direction);
     vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
     float t = intersectSphereNear(center, tp->radius, observer, direction);
     int hit = (t > 0.0f) && !isinf(t);
@@ -824,6 +862,20 @@ static TargetSample intersectTarget(const orc_target_params* tp, vec3 observer, 
 static TargetSample sampleTarget(Ctx* x, const orc_target_params* tp, vec3 observer, uint32_t idx,
                                  uint32_t* dim) {
     vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
+    if (g_target_inner) { /* target.sphere.inner.glsl:18-34: uniform over the sphere */
+        float v0 = rnd(x, idx, dim);
+        float v1 = rnd(x, idx, dim);
+        vec3 normal = sphericalToCartessian(TWO_PI_F * v0, 2.0f * v1 - 1.0f); /* util.sample.glsl:84-88 */
+        vec3 pos = v_add(v_scale(normal, tp->radius), center);
+        TargetSample s;
+        memset(&s, 0, sizeof(s));
+        s.position = pos; s.normal = v_scale(normal, -1.0f); s.dist = v_distance(observer, pos);
+        s.objPosition = normal; s.objNormal = v_scale(normal, -1.0f);
+        s.prob = tp->hemisphereProb; s.valid = 1;
+        s.offset = V3(tp->invPos[0], tp->invPos[1], tp->invPos[2]);
+        s.invRad = tp->invRad;
+        return s;
+    }
     vec3 dir = v_normalize(v_sub(observer, center));
     float d = v_distance(observer, center);
     float cosOpening = tp->radius / d;
@@ -937,7 +989,8 @@ static void vol_traceMain(Ctx* x, const orc_volume_trace_params* tp, const orc_t
     onEvent(x, &ray, RESULT_CODE_RAY_CREATED, local_idx, 0, dim);
     /* target.sphere.glsl:80-83 */
     vec3 center = V3(tg->position[0], tg->position[1], tg->position[2]);
-    if (v_distance(ray.position, center) <= tg->radius) {
+    /* isOccludedByTarget: target.sphere.glsl:80-83 (inside) / target.sphere.inner.glsl:59-61 (outside) */
+    if (g_target_inner ? (v_distance(ray.position, center) >= tg->radius) : (v_distance(ray.position, center) <= tg->radius)) {
         onEvent(x, &ray, ERROR_CODE_TRACE_ABORT, local_idx, 0, dim);
         return;
     }
@@ -1744,6 +1797,7 @@ int orc_trace_volume(const orc_common* c, const orc_volume_trace_params* t,
     x.c = c;
     x.polarized = (c->flags & ORC_FLAG_POLARIZED) != 0;
     x.use_global_medium = 1;
+    g_target_inner = (c->flags & ORC_FLAG_TARGET_INNER) != 0;
     x.global_medium = (uint64_t)t->medium[0] | ((uint64_t)t->medium[1] << 32);
     x.prop = t->propagation;
     VolArgs a = {t, target};

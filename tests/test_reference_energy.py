@@ -4,8 +4,9 @@ sample sizes, on the HIP kernels (`-m gpu` only: 84 M / 200 M / 21 M photons per
 seconds on an MI355X and hours on the CPU oracle, whose reduced-size versions are in
 tests/test_oracle_tracers.py). Bodies as in /root/reference/tests/test_trace_energy.py:
 `test_SceneForwardTracer_GroundTruth` (:58-176, HitRecorder + scheduler + dumpQueue),
-`test_SceneForwardTracer_Crosscheck` (:187-337, target-guide MIS against plain path tracing)
-and `test_SceneForwardTracer_MultiMedia` (:479-568, nested media with refraction, 0.61 %).
+`test_SceneForwardTracer_Crosscheck` (:187-337, target-guide MIS against plain path tracing),
+`test_SceneForwardTracer_MultiMedia` (:479-568, nested media with refraction, 0.61 %) and
+`test_VolumeForwardTracer` (:815-938, light inside an InnerSphereTarget, tolerances 2.8e-4 ... 1.2e-2).
 Only the mesh source differs (bundled sphere.stl fixture).
 """
 import numpy as np
@@ -24,7 +25,7 @@ import theia.trace
 import theia.units as u
 from hephaistos.queue import dumpQueue
 from theia.scene import Transform
-from theia.target import SphereTargetGuide
+from theia.target import InnerSphereTarget, SphereTargetGuide
 
 pytestmark = pytest.mark.gpu
 
@@ -272,3 +273,85 @@ def test_SceneForwardTracer_MultiMedia(polarized: bool):
     estimate = hist.sum()
 
     assert abs(estimate / budget - 1.0) < 0.0061
+
+
+@pytest.mark.parametrize(
+    "mu_a,mu_s,mu_sample,g,disableDirect,sampleTarget,polarized,err",
+    [
+        (0.0, 0.005, 0.05, 0.0, False, True, False, 4.5e-4),
+        (0.0, 0.005, 0.05, 0.0, False, False, False, 0.011),
+        (0.0, 0.005, 0.05, 0.0, True, True, False, 0.011),
+        (0.05, 0.01, 0.05, 0.0, False, True, False, 1.8e-3),
+        (0.05, 0.01, 0.05, 0.0, True, True, False, 2.6e-3),
+        (0.05, 0.01, 0.05, -0.9, False, True, False, 0.012),
+        (0.05, 0.01, 0.05, 0.9, True, True, False, 2.8e-4),
+        (0.05, 0.01, 0.05, 0.9, True, False, False, 2.9e-3),
+        (0.05, 0.01, np.nan, 0.9, False, True, True, 2.9e-3),
+        (0.0, 0.005, 0.05, 0.0, False, True, True, 5e-4),
+        (0.0, 0.005, 0.05, 0.0, True, True, True, 1.2e-3),
+        (0.05, 0.01, 0.05, -0.9, False, True, True, 0.012),
+    ],
+)
+def test_VolumeForwardTracer(mu_a, mu_s, mu_sample, g, disableDirect, sampleTarget, polarized, err) -> None:
+    """Spherical light source placed within a spherical target"""
+    position = (12.0, 15.0, 0.2) * u.m
+    radius = 100.0 * u.m
+    budget = 1e9
+    t0 = 10.0 * u.ns
+    lam = 400.0 * u.nm
+    max_length = 10
+    maxTime = float("inf")
+    batch_size = 512 * 1024
+    n_batches = 10
+
+    model = MediumModel(mu_a, mu_s, g)
+    medium = model.createMedium()
+    store = theia.material.MaterialStore([], media=[medium])
+
+    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
+    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
+    light = theia.light.SphericalLightSource(position=position, timeRange=(t0, t0), budget=budget)
+    target = InnerSphereTarget(position=position, radius=radius)
+    recorder = theia.response.HitRecorder(polarized=polarized)
+    tracer = theia.trace.VolumeForwardTracer(
+        batch_size, light, target, photons, recorder, rng,
+        medium=store.media["homogenous"], maxTime=maxTime, nScattering=max_length, scatterCoefficient=mu_sample,
+        polarized=polarized, disableDirectLighting=disableDirect, disableTargetSampling=not sampleTarget,
+    )
+    rng.autoAdvance = tracer.nRNGSamples
+
+    total = 0
+    stokes = []
+
+    def process(config: int, batch: int, args) -> None:
+        nonlocal total
+        result = recorder.queue.view(config)
+        result = result[: result.count]
+        # undo attenuation
+        vg = 1.0 / model.ng * u.c
+        d = vg * (result["time"] - t0)
+        value0 = result["contrib"] * np.exp(mu_a * d)
+        total += value0.sum(dtype=np.float64)
+        if polarized:
+            stokes.append(result["stokes"].copy())
+
+    pipeline = pl.Pipeline(tracer.collectStages())
+    scheduler = pl.PipelineScheduler(pipeline, processFn=process)
+    scheduler.schedule([{}] * n_batches)
+    scheduler.wait()
+    scheduler.destroy()
+
+    # calculate direct contribution without attenuation
+    directContrib = budget * np.exp(-mu_s * radius)
+    contrib = budget - directContrib if disableDirect else budget
+
+    # check for energy conservation
+    estimate = total / (batch_size * n_batches)
+    assert np.abs(estimate / contrib - 1.0) < err
+
+    if polarized:
+        stokes = np.concatenate(stokes)
+        assert np.abs(stokes[:, 0] - 1.0).max() < 1e-5
+        assert stokes[:, 1:].max() <= 1.0
+        assert stokes[:, 1:].min() >= -1.0
+        assert np.all(np.square(stokes[:, 1:]).sum(-1) <= 1.0 + 1e-6)

@@ -20,7 +20,7 @@ __all__ = [
     "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
     "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
-    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "EXPORTED_SYMBOLS",
+    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "EXPORTED_SYMBOLS",
 ]
 
 TRACER_VOLUME_FORWARD = 0
@@ -37,6 +37,7 @@ FLAG_WAVELENGTH_UNIFORM = 1 << 6
 FLAG_STATISTICS = 1 << 8
 FLAG_TRACK = 1 << 9
 FLAG_LIGHT_PENCIL = 1 << 10
+FLAG_TARGET_INNER = 1 << 11
 N_STATS = 20
 TRACK_WORDS = 12
 STAT_NAMES = (

@@ -418,6 +418,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         e = hipMalloc((void**)&t->hits, nb);
         if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
     }
+    // the memsets above run on the null stream, which is NOT ordered with the context's
+    // non-blocking stream: finish them before anything can be launched
+    if (e == hipSuccess) e = hipDeviceSynchronize();
     if (e != hipSuccess) { thx_tracer_destroy(t); return hipFail(e, "thx_tracer_create"); }
     *out = t;
     return THX_OK;
@@ -556,6 +559,7 @@ int thx_tracer_read_stage_profile(thx_tracer* t, uint64_t* out48) {
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemcpy(out48, t->prof, sizeof(uint64_t) * 48, hipMemcpyDeviceToHost));
     THX_HIP(hipMemset(t->prof, 0, sizeof(uint64_t) * 48));
+    THX_HIP(hipDeviceSynchronize()); // null-stream memset vs. launches on the non-blocking stream
     return THX_OK;
 }
 
@@ -564,6 +568,7 @@ int thx_tracer_reset_stats(thx_tracer* t) {
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS));
+    THX_HIP(hipDeviceSynchronize()); // null-stream memset vs. launches on the non-blocking stream
     return THX_OK;
 }
 
@@ -592,7 +597,13 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
         THX_HIP(hipMemcpyAsync((char*)out + off, (const char*)t->hits + off, bytes, hipMemcpyDeviceToHost, t->ctx->stream));
     }
     THX_HIP(hipStreamSynchronize(t->ctx->stream));
-    if (clear) THX_HIP(hipMemset(t->hits, 0, 4));
+    if (clear) {
+        // on the context's stream and completed before returning: a memset on the null stream
+        // is not ordered with the next launch on the (non-blocking) stream and would wipe the
+        // counter in the middle of the next batch
+        THX_HIP(hipMemsetAsync(t->hits, 0, 4, t->ctx->stream));
+        THX_HIP(hipStreamSynchronize(t->ctx->stream));
+    }
     return THX_OK;
 }
 

@@ -359,12 +359,13 @@ struct TargetSample {
     f3 position, normal;
     float dist, prob;
     bool valid;
+    f3 objPosition; // unit sphere of the target's frame; read by the HitRecorder response only
 };
-// target.sphere.glsl:36-41, 68-73: on the sphere target the object-space position and normal
-// are the world normal, world->object is the uniform scale 1/radius
+// target.sphere.glsl:36-41, 68-73 / target.sphere.inner.glsl:26-32, 50-56: the object-space
+// normal is the world normal, world->object is the uniform scale 1/radius
 THX_DEV HitFrame targetFrame(const thx_run_params& p, const TargetSample& hit) {
     const float ir = p.target.invRad;
-    return HitFrame{hit.normal, hit.normal, m3{f3{ir, 0.0f, 0.0f}, f3{0.0f, ir, 0.0f}, f3{0.0f, 0.0f, ir}}, p.volume.objectId};
+    return HitFrame{hit.objPosition, hit.normal, m3{f3{ir, 0.0f, 0.0f}, f3{0.0f, ir, 0.0f}, f3{0.0f, 0.0f, ir}}, p.volume.objectId};
 }
 
 // math.sphere.glsl:14-39 (nearest root)
@@ -385,15 +386,44 @@ THX_DEV float intersectSphereNear(f3 center, float radius, f3 origin, f3 directi
     return rx;
 }
 
-// target.sphere.glsl:45-78 (objPosition = objNormal = normal, worldToObj = 1/r)
-THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f3 direction) {
+// math.sphere.glsl:14-39 (farthest root)
+THX_DEV float intersectSphereFar(f3 center, float radius, f3 origin, f3 direction) {
+    f3 f = origin - center;
+    float b2 = dot(f, direction);
+    float r2 = radius * radius;
+    f3 fd = f - direction * b2;
+    float discr = r2 - dot(fd, fd);
+    float ry = INFINITY;
+    if (discr >= 0.0f) {
+        float cc = dot(f, f) - r2;
+        float q = -b2 - signBit(b2) * sqrtf(discr);
+        float rx = cc / q;
+        ry = q;
+        if (rx > ry) ry = rx;
+    }
+    return ry;
+}
+
+// target.sphere.glsl:45-78 (objPosition = objNormal = normal, worldToObj = 1/r);
+// inner: target.sphere.inner.glsl:36-57 (seen from inside: far root, normal towards the centre)
+THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f3 direction, bool inner) {
     f3 center = ld3(tp.position);
-    float t = intersectSphereNear(center, tp.radius, observer, direction);
     TargetSample s;
+    if (inner) {
+        float t = intersectSphereFar(center, tp.radius, observer, direction);
+        f3 pos = observer + direction * t;
+        f3 nrm = normalize(center - pos);
+        s.position = pos; s.normal = nrm; s.dist = t; s.prob = tp.hemisphereProb;
+        s.valid = (t > 0.0f) && !isinf(t);
+        s.objPosition = nrm * -1.0f;
+        return s;
+    }
+    float t = intersectSphereNear(center, tp.radius, observer, direction);
     bool hit = (t > 0.0f) && !isinf(t);
     if (!hit) { // target.common.glsl:79-91
         s.position = f3{0, 0, 0};
         s.normal = f3{0, 0, 0};
+        s.objPosition = f3{0, 0, 0};
         s.dist = INFINITY;
         s.prob = 0.0f;
         s.valid = false;
@@ -407,13 +437,25 @@ THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f
     bool valid = !isinf(prob);
     if (!valid) prob = 0.0f;
     s.position = pos; s.normal = nrm; s.dist = t; s.prob = prob; s.valid = valid;
+    s.objPosition = nrm;
     return s;
 }
 
-// target.sphere.glsl:18-43
+// target.sphere.glsl:18-43; inner: target.sphere.inner.glsl:18-34 (uniform over the sphere)
 template <class V>
-THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 observer) {
+THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 observer, bool inner) {
     f3 center = ld3(tp.position);
+    if (inner) {
+        float v0 = draw(L);
+        float v1 = draw(L);
+        f3 normal = sphericalToCartessian(TWO_PI * v0, 2.0f * v1 - 1.0f); // util.sample.glsl:84-88
+        f3 pos = normal * tp.radius + center;
+        TargetSample s;
+        s.position = pos; s.normal = normal * -1.0f; s.dist = distance(observer, pos);
+        s.prob = tp.hemisphereProb; s.valid = true;
+        s.objPosition = normal;
+        return s;
+    }
     f3 dir = normalize(observer - center);
     float d = distance(observer, center);
     float cosOpening = tp.radius / d;
@@ -429,6 +471,7 @@ THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 ob
     TargetSample s;
     s.position = pos; s.normal = normal; s.dist = distance(pos, observer); s.prob = prob;
     s.valid = valid;
+    s.objPosition = normal;
     return s;
 }
 
@@ -463,8 +506,9 @@ THX_DEV void volSampleTargetMIS(Lane<V>& L, const Ray& ray, uint64_t med) {
     float u0 = draw(L);
     float u1 = draw(L);
     f3 dirPhase = scatter(med, dir, u0, u1, pPP, L.cnt);
-    TargetSample phaseHit = intersectTarget(tg, obs, dirPhase);
-    TargetSample targetHit = sampleTarget(L, tg, obs);
+    const bool inner = (L.a->flags & THX_FLAG_TARGET_INNER) != 0;
+    TargetSample phaseHit = intersectTarget(tg, obs, dirPhase, inner);
+    TargetSample targetHit = sampleTarget(L, tg, obs, inner);
     f3 dirTarget = normalize(targetHit.position - obs);
     float pTT = targetHit.prob * jacobian_dAdW(obs, targetHit.position, targetHit.normal);
     float pPT = scatterProb(med, dir, dirTarget, L.cnt);
@@ -482,7 +526,7 @@ THX_DEV int volTrace(Lane<V>& L, Ray& ray, uint64_t med, bool allowResponse) {
     L.cnt.add(ST_STEPS);
     float u = draw(L);
     float dist = sampleScatterLength(ray, prop, u);
-    TargetSample hit = intersectTarget(L.a->p.target, ray.position, ray.direction);
+    TargetSample hit = intersectTarget(L.a->p.target, ray.position, ray.direction, (L.a->flags & THX_FLAG_TARGET_INNER) != 0);
     bool hitValid = hit.valid && (hit.dist <= dist);
     dist = fminf(hit.dist, dist);
     int result = propagateRay(ray, dist, prop);
@@ -511,14 +555,15 @@ THX_DEV bool volStep(Lane<V>& L, Ray& ray, uint32_t& step) {
     if (step == 0) {
         ray = sampleRay(L, med);
         onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
-        // target.sphere.glsl:80-83
-        if (distance(ray.position, ld3(A.p.target.position)) <= A.p.target.radius) {
+        // isOccludedByTarget: target.sphere.glsl:80-83 (inside), target.sphere.inner.glsl:59-61 (outside)
+        const float dTarget = distance(ray.position, ld3(A.p.target.position));
+        if ((A.flags & THX_FLAG_TARGET_INNER) ? (dTarget >= A.p.target.radius) : (dTarget <= A.p.target.radius)) {
             onEvent(L, ray, ERROR_CODE_TRACE_ABORT, 0);
             return false;
         }
         if constexpr (V::MIS) {
             if (!disable_direct) {
-                TargetSample directHit = intersectTarget(A.p.target, ray.position, ray.direction);
+                TargetSample directHit = intersectTarget(A.p.target, ray.position, ray.direction, (A.flags & THX_FLAG_TARGET_INNER) != 0);
                 volCreateResponse(L, ray, directHit, ray.direction, 1.0f, false, med);
             }
         }

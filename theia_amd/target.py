@@ -13,7 +13,7 @@ from . import units as u
 from .hp.glsl import vec3
 from .hp.pipeline import SourceCodeMixin
 
-__all__ = ["Target", "SphereTarget", "TargetGuide", "SphereTargetGuide"]
+__all__ = ["Target", "SphereTarget", "InnerSphereTarget", "TargetGuide", "SphereTargetGuide"]
 
 
 class Target(SourceCodeMixin):
@@ -45,6 +45,26 @@ class SphereTarget(Target):
         r = self.getParam("radius")
         x, y, z = self.getParam("position")
         self.setParams(_hemisphereProb=1.0 / (2.0 * np.pi * r**2), _invPos=(-x / r, -y / r, -z / r), _invRad=1.0 / r)
+
+
+class InnerSphereTarget(Target):
+    """Sphere seen from the inside (the light is inside the target); sampled uniformly over its
+    surface. Hits are reported on the unit sphere of the target's local frame with the normal
+    pointing to the centre. Reference: target.py:142-199, shader/target.sphere.inner.glsl."""
+
+    name = "Inner Sphere Target"
+
+    class TargetParams(Structure):
+        _fields_ = [("position", vec3), ("radius", c_float), ("_invPos", vec3), ("_invRad", c_float), ("_prob", c_float)]
+
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
+        super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams})
+        self.setParams(position=position, radius=radius)
+
+    def _finishParams(self, i: int) -> None:
+        r = self.getParam("radius")
+        x, y, z = self.getParam("position")
+        self.setParams(_prob=1.0 / (4.0 * np.pi * r**2), _invPos=(-x / r, -y / r, -z / r), _invRad=1.0 / r)
 
 
 class TargetGuide(SourceCodeMixin):

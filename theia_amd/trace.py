@@ -28,7 +28,7 @@ from .light import (ConstWavelengthSource, LightSource, PencilLightSource, Spher
 from .random import RNG, PhiloxRNG
 from .response import EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, TraceConfig
 from .scene import RectBBox, Scene
-from .target import SphereTarget, SphereTargetGuide, Target, TargetGuide
+from .target import InnerSphereTarget, SphereTarget, SphereTargetGuide, Target, TargetGuide
 
 __all__ = [
     "EmptyEventCallback", "EventResultCode", "EventStatisticCallback", "SceneForwardTracer", "Tracer",
@@ -460,8 +460,8 @@ class VolumeForwardTracer(Tracer):
         if traceBBox is None:
             traceBBox = RectBBox((-1.0 * u.km,) * 3, (1.0 * u.km,) * 3)
         self._checkComponents(source, wavelengthSource, response, rng, callback)
-        if not isinstance(target, SphereTarget):
-            raise _unsupported("target", target, "SphereTarget")
+        if not isinstance(target, (SphereTarget, InnerSphereTarget)):
+            raise _unsupported("target", target, "SphereTarget, InnerSphereTarget")
         # hits: one per scatter (+ one MIS sample each) + the direct one
         maxHitsPerThread = nScattering
         if not disableTargetSampling:
@@ -491,6 +491,7 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
+        flags |= capi.FLAG_TARGET_INNER if isinstance(target, InnerSphereTarget) else 0
         flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response)), None)
@@ -531,7 +532,8 @@ class VolumeForwardTracer(Tracer):
         for k, c in enumerate("xyz"):
             P.target.position[k] = getattr(g.position, c)
             P.target.invPos[k] = getattr(g._invPos, c)
-        P.target.radius, P.target.invRad, P.target.hemisphereProb = g.radius, g._invRad, g._hemisphereProb
+        P.target.radius, P.target.invRad = g.radius, g._invRad
+        P.target.hemisphereProb = g._prob if isinstance(self._target, InnerSphereTarget) else g._hemisphereProb
         return P
 
     def run(self, i: int):
