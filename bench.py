@@ -136,6 +136,7 @@ def main() -> None:
     for k in range(W):
         step(k, scratch.data_ptr())
     if dist is not None:
+        torch.cuda.synchronize()
         dist.all_reduce(scratch)  # warm the communicator outside the timed region
         dist.barrier()
     torch.cuda.synchronize()
@@ -143,6 +144,9 @@ def main() -> None:
     for k in range(K):
         step(W + k, curves[k].data_ptr())
     if dist is not None:
+        # the tracer works on the library's own (non-blocking) stream when torch's current stream
+        # is the default one: finish the reductions into `curves` before RCCL reads them
+        torch.cuda.synchronize()
         dist.all_reduce(curves)  # the single collective: K x n_bins floats
     torch.cuda.synchronize()
     if dist is not None:

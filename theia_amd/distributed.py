@@ -53,5 +53,11 @@ def reduce_histograms(hist, dist=None):
     the single collective of the sharded path. No-op for one process."""
     if dist is None:
         return hist
+    if getattr(hist, "is_cuda", False):
+        import torch
+
+        # the tracer / reducer kernels run on the library's own stream, which is not ordered
+        # with torch's: finish them before RCCL reads the histograms
+        torch.cuda.synchronize(hist.device)
     dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist
