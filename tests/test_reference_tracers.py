@@ -19,6 +19,7 @@ import theia.material
 import theia.random
 import theia.response
 import theia.scene
+import theia.target
 import theia.trace
 import theia.units as u
 from theia.scene import Transform
@@ -331,6 +332,196 @@ def test_tracer_reflection(backend, flag, reflectance, err):
     assert hits_ref.count + hits_trans.count == N
     reflectance_sim = hits_ref.count / N
     assert np.abs(reflectance_sim - reflectance) <= err
+
+
+def test_tracerReportsConfig():
+    """/root/reference/tests/test_trace.py:22-82 (host only): the tracer calls `prepare()` and
+    `updateConfig()` on its response with the right TraceConfig"""
+    batchSize = 64 * 1024
+    batchSize2 = 96 * 1024
+    capacity = 128 * 1024
+    polarized = True
+
+    class MockResponse(theia.response.EmptyResponse):
+        def __init__(self) -> None:
+            super().__init__()
+            self.prepareConfig = None
+            self.updatedConfig = None
+
+        def prepare(self, config):
+            self.prepareConfig = config
+
+        def updateConfig(self, config):
+            self.updatedConfig = config
+
+    philox = theia.random.PhiloxRNG(key=0xABBA)
+    target = theia.target.SphereTarget()
+    source = theia.light.SphericalLightSource()
+    photons = theia.light.ConstWavelengthSource()
+    response = MockResponse()
+    tracer = theia.trace.VolumeForwardTracer(batchSize, source, target, photons, response, rng=philox, medium=0,
+                                             capacity=capacity, polarized=polarized)
+
+    assert response.prepareConfig is not None
+    assert response.prepareConfig.batchSize == batchSize
+    assert response.prepareConfig.blockSize == tracer.blockSize
+    assert response.prepareConfig.capacity == capacity
+    assert response.prepareConfig.maxHitsPerThread == tracer.maxHitsPerThread
+    assert response.prepareConfig.normalization == tracer.normalization
+    assert response.prepareConfig.normalization == 1.0 / batchSize
+    assert response.prepareConfig.polarized == polarized
+
+    tracer.batchSize = batchSize2
+    tracer.update(0)
+    assert response.updatedConfig is not None
+    assert response.updatedConfig.batchSize == batchSize2
+    assert response.updatedConfig.blockSize == tracer.blockSize
+    assert response.updatedConfig.capacity == capacity
+    assert response.updatedConfig.maxHitsPerThread == tracer.maxHitsPerThread
+    assert response.updatedConfig.normalization == tracer.normalization
+    assert response.updatedConfig.normalization == 1.0 / batchSize2
+    assert response.updatedConfig.polarized == polarized
+
+
+def test_SceneForwardTracer_multiTarget(backend):
+    """/root/reference/tests/test_trace.py:460-525: targetId = -1 records hits of every detector.
+    (The reference indexes the whole queue; here the first `count` entries, as its other tests do.)"""
+    if not hp.isRaytracingEnabled():
+        pytest.skip("ray tracing is not supported")
+
+    N = 32 * 256
+    MAX_PATH = 10
+    T0, T1 = 10.0 * u.ns, 20.0 * u.ns
+    T_MAX = 1.0 * u.us
+    capacity = 48 * 256
+    light_pos = (-1.0, -7.0, 0.0) * u.m
+    light_budget = 1000.0
+
+    water = WaterTestModel().createMedium()
+    glass = theia.material.BK7Model().createMedium()
+    mat = theia.material.Material("mat", glass, water, flags=("DR", "B"))
+    matStore = theia.material.MaterialStore([mat])
+    store = theia.scene.MeshStore({"cube": S.bundled_mesh("cone"), "sphere": S.bundled_mesh("sphere")})
+    r, d = 40.0 * u.m, 5.0 * u.m
+    r_scale = 0.99547149974733 * u.m  # radius of inscribed sphere (icosphere)
+    x, y, z = 10.0, 5.0, -5.0
+    t1 = Transform.TRS(scale=r, translate=(x, y, z + r + d))
+    c1 = store.createInstance("sphere", "mat", t1, detectorId=0)
+    t2 = Transform.TRS(scale=r, translate=(x, y, z - r - d), rotate=(0.0, 0.0, 1.0, 110.0))
+    c2 = store.createInstance("sphere", "mat", t2, detectorId=1)
+    scene = theia.scene.Scene([c1, c2], matStore.material, medium=matStore.media["water"])
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource()
+    source = theia.light.SphericalLightSource(position=light_pos, timeRange=(T0, T1), budget=light_budget)
+    recorder = theia.response.HitRecorder()
+    stats = theia.trace.EventStatisticCallback()
+    tracer = theia.trace.SceneForwardTracer(N, source, photons, recorder, rng, scene, capacity=capacity, targetId=-1,
+                                            maxPathLength=MAX_PATH, maxTime=T_MAX, callback=stats)
+    pl.runPipeline(tracer.collectStages())
+    hits = recorder.queue.view(0)
+    hits = hits[: hits.count]
+
+    r_hits = np.sqrt(np.square(hits["position"]).sum(-1))
+    assert np.all((r_hits <= 1.0) & (r_hits >= r_scale))
+    assert np.allclose(np.square(hits["normal"]).sum(-1), 1.0)
+    assert (hits["objectId"] == 0).sum() > 0
+    assert (hits["objectId"] == 1).sum() > 0
+
+
+def test_EventStatisticCallback(backend):
+    """/root/reference/tests/test_trace.py:947-1045: every kind of event occurs and the counters add up"""
+    if not hp.isRaytracingEnabled():
+        pytest.skip("ray tracing is not supported")
+
+    N = 32 * 1024
+    T0, T1 = 10.0 * u.ns, 20.0 * u.ns
+
+    water = WaterTestModel().createMedium()
+    glass = theia.material.BK7Model().createMedium()
+    mat = theia.material.Material("mat", glass, water, flags=("DR", "B"))
+    vol = theia.material.Material("vol", glass, water, flags="V")
+    absorber = theia.material.Material("abs", glass, water, flags="B")
+    matStore = theia.material.MaterialStore([mat, vol, absorber])
+    store = theia.scene.MeshStore({"sphere": S.bundled_mesh("sphere")})
+    r, d = 20.0, 5.0
+    t1 = Transform.TRS(scale=r, translate=(17.0, 17.0, 17.0))
+    c1 = store.createInstance("sphere", "mat", t1, detectorId=0)
+    t2 = Transform.TRS(scale=r, translate=(-17.0, -17.0, -17.0))
+    c2 = store.createInstance("sphere", "mat", t2, detectorId=1)
+    t3 = Transform.TRS(scale=r, translate=(17.0, 17.0, -17.0))
+    c3 = store.createInstance("sphere", "vol", t3)
+    t4 = Transform.TRS(scale=r, translate=(-17.0, 17.0, 17.0))
+    c4 = store.createInstance("sphere", "abs", t4)
+    bbox = theia.scene.RectBBox((-50.0,) * 3, (50.0,) * 3)
+    scene = theia.scene.Scene([c1, c2, c3, c4], matStore.material, medium=matStore.media["water"], bbox=bbox)
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource()
+    source = theia.light.SphericalLightSource(timeRange=(T0, T1))
+    response = theia.response.EmptyResponse()
+    stats = theia.trace.EventStatisticCallback()
+    tracer = theia.trace.SceneForwardTracer(N, source, photons, response, rng, callback=stats, scene=scene, targetId=1,
+                                            maxPathLength=1, scatterCoefficient=0.005 / u.m, maxTime=100.0 * u.ns)
+    names = ("created", "absorbed", "hit", "detected", "scattered", "lost", "decayed", "volume", "maxIter", "error", "mismatch")
+    for n in names:  # stats start empty
+        assert getattr(stats, n) == 0
+    pl.runPipeline(tracer.collectStages())
+
+    assert stats.created == N
+    for n in ("absorbed", "hit", "detected", "scattered", "lost", "decayed", "volume", "maxIter"):
+        assert getattr(stats, n) > 0, n
+    assert stats.error == 0
+    assert stats.mismatch == 0
+    total = stats.absorbed + stats.hit + stats.detected + stats.scattered + stats.lost + stats.decayed + stats.volume
+    assert total == N
+    stats.reset()
+    for n in names:
+        assert getattr(stats, n) == 0
+
+
+@pytest.mark.parametrize("polarized", [True, False])
+def test_TrackRecordCallback(backend, polarized):
+    """/root/reference/tests/test_trace.py:1048-1119 with polarizedTrack=False (the polarized
+    track layout is not built)"""
+    N = 32 * 256
+    N_SCATTER = 6
+    LENGTH = N_SCATTER + 2  # one more than needed
+    T0, T1 = 10.0 * u.ns, 20.0 * u.ns
+    T_MAX = 500.0 * u.ns
+    target_pos, target_radius = (5.0, 2.0, -8.0) * u.m, 4.0 * u.m
+    light_pos = (100.0, -50.0, 20.0) * u.m
+    light_dir = (1.0, 0.0, 0.0)
+    stokes = (1.0, 0.5, 0.1, 0.4)
+    polRef = (0.0, 1.0, 0.0)
+
+    water = WaterTestModel().createMedium()
+    store = theia.material.MaterialStore([], media=[water])
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource()
+    source = theia.light.PencilLightSource(position=light_pos, direction=light_dir, timeRange=(T0, T1), stokes=stokes,
+                                           polarizationRef=polRef)
+    response = theia.response.EmptyResponse()
+    track = theia.trace.TrackRecordCallback(N, LENGTH, polarized=False)
+    tracer = theia.trace.VolumeForwardTracer(
+        N, source, SphereTarget(position=target_pos, radius=target_radius), photons, response, rng,
+        callback=track, medium=store.media["water"], nScattering=N_SCATTER, scatterCoefficient=0.1, maxTime=T_MAX,
+        traceBBox=theia.scene.RectBBox((-200.0 * u.m,) * 3, (200.0 * u.m,) * 3), polarized=polarized,
+    )
+    pl.runPipeline(tracer.collectStages())
+
+    tracks, lengths, codes = track.result(0)
+    assert tracks.shape == (N, LENGTH, 4)
+    assert np.all(tracks[:, 0, :3] == light_pos)
+    assert tracks[:, 0, 3].min() >= T0 and tracks[:, 0, 3].max() <= T1
+    # since we use a pencil beam in x direction, y and z for the first scatter are still deterministic
+    assert np.all(tracks[:, 1, 1] == light_pos[1])
+    assert np.all(tracks[:, 1, 2] == light_pos[2])
+    assert lengths.min() >= 1 and lengths.max() <= N_SCATTER
+    minCode = min(code.value for code in theia.trace.EventResultCode)
+    maxCode = max(code.value for code in theia.trace.EventResultCode)
+    assert codes.min() >= minCode and codes.max() <= maxCode
 
 
 def _hits_table(view) -> np.ndarray:
