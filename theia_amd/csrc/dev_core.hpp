@@ -31,6 +31,11 @@ struct m3 { // columns
 
 THX_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
 THX_DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
+// Pointers made from the 64-bit device addresses users hand in (medium / material / geometry
+// records, tables) carry the global address space: plain pointers would compile to FLAT loads,
+// which also tick the LDS counter and are waited for together with every LDS access.
+#define THX_GLOBAL __attribute__((address_space(1)))
+THX_DEV f3 ld3(const THX_GLOBAL float* p) { return f3{p[0], p[1], p[2]}; }
 THX_DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 THX_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 THX_DEV f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }
@@ -221,8 +226,8 @@ struct MediumConstants {
 template <bool ST>
 THX_DEV float lookUp(uint64_t table, float u, float nullValue, Counters<ST>& cnt) {
     if (table == 0) return nullValue;
-    const int32_t* hdr = reinterpret_cast<const int32_t*>(table);
-    const float* samples = reinterpret_cast<const float*>(hdr + 1);
+    const THX_GLOBAL int32_t* hdr = reinterpret_cast<const THX_GLOBAL int32_t*>(table);
+    const THX_GLOBAL float* samples = reinterpret_cast<const THX_GLOBAL float*>(hdr + 1);
     cnt.add(ST_LUT);
     u = clampf(u, 0.0f, 1.0f);
     u *= (float)(hdr[0] - 1);
@@ -234,7 +239,7 @@ THX_DEV float lookUp(uint64_t table, float u, float nullValue, Counters<ST>& cnt
 }
 
 // material.glsl:37-39
-THX_DEV float normalize_lambda(const MediumGLSL* m, float lambda) {
+THX_DEV float normalize_lambda(const THX_GLOBAL MediumGLSL* m, float lambda) {
     return clampf((lambda - m->lambda_min) / (m->lambda_max - m->lambda_min), 0.0f, 1.0f);
 }
 
@@ -242,7 +247,7 @@ THX_DEV float normalize_lambda(const MediumGLSL* m, float lambda) {
 template <bool ST>
 THX_DEV MediumConstants lookUpMedium(uint64_t medium, float lambda, Counters<ST>& cnt) {
     if (medium == 0) return MediumConstants{1.0f, SPEED_OF_LIGHT, 0.0f, 0.0f};
-    const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+    const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
     float u = normalize_lambda(m, lambda);
     float mu_a = lookUp(m->mu_a, u, 0.0f, cnt);
     float mu_s = lookUp(m->mu_s, u, 0.0f, cnt);
@@ -306,7 +311,7 @@ THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, 
                             Counters<ST>& cnt) {
     float m12 = 0.0f, m22 = 1.0f, m33 = 1.0f, m34 = 0.0f;
     if (medium != 0) {
-        const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+        const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
         float t = 0.5f * (cos_theta + 1.0f);
         m12 = lookUp(m->phase_m12, t, 0.0f, cnt);
         m22 = lookUp(m->phase_m22, t, 0.0f, cnt);
@@ -338,7 +343,7 @@ template <bool ST>
 THX_DEV float sampleScatterDir(uint64_t medium, float u0, float u1, float& cos_theta, float& phi,
                                Counters<ST>& cnt) {
     phi = u0 * TWO_PI;
-    const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+    const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
     if (medium != 0 && m->phase_sampling != 0) {
         float ct = lookUp(m->phase_sampling, u1, 0.0f, cnt);
         ct = clampf(ct, -1.0f, 1.0f);
@@ -360,7 +365,7 @@ THX_DEV f3 scatter(uint64_t medium, f3 inDir, float u0, float u1, float& p, Coun
 // scatter.volume.glsl:54-65
 template <bool ST>
 THX_DEV float scatterProb(uint64_t medium, f3 inDir, f3 outDir, Counters<ST>& cnt) {
-    const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(medium);
+    const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
     if (medium == 0 || m->log_phase == 0) return INV_4PI;
     float cos_theta = dot(inDir, outDir);
     float log_p = lookUp(m->log_phase, 0.5f * (cos_theta + 1.0f), 0.0f, cnt);

@@ -91,13 +91,25 @@ struct Pool {
     uint32_t* ctr;    // counters
     uint32_t P, cap, capShift; // pool size, ring capacity (power of two >= P) and its log2
     // ring s holds slot ids; the TS ring (last) has room for 2 cap entries (two shadow rays per photon)
-    THX_DEV volatile uint16_t* queue(int s) const { return q + (size_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * cap; }
+    uint32_t qHalf, ctrWord; // LDS half-word index of ring 0, LDS word index of the counters
+    // LDS half-word index of ring s
+    THX_DEV uint32_t queue(int s) const { return qHalf + (uint32_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * cap; }
     THX_DEV uint32_t mask(int s) const { return (s == S_TS ? 2u * cap : cap) - 1u; }
     // lap tag of ring position `pos` (bit 14 of the cell): a claimer never takes the entry of
     // the previous lap for its own, however late that lap's claimer empties the cell
     THX_DEV uint32_t lapTag(int s, uint32_t pos) const { return ((pos >> (s == S_TS ? capShift + 1u : capShift)) & 1u) << 14; }
     THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[4 * P + slot]) + 2; }
 };
+
+// Scheduler accesses to LDS that other wavefronts change concurrently: relaxed atomics on
+// the __shared__ symbol itself. (`volatile` pointers lose the LDS address space -- the compiler
+// then emits FLAT loads with system scope and a vmcnt+lgkmcnt wait for every counter or ring
+// cell read -- and plain loads could be hoisted out of the spin loops.)
+THX_DEV uint32_t ldsRead16(uint32_t half) { return __atomic_load_n(reinterpret_cast<uint16_t*>(thx_smem) + half, __ATOMIC_RELAXED); }
+THX_DEV void ldsWrite16(uint32_t half, uint32_t v) { __atomic_store_n(reinterpret_cast<uint16_t*>(thx_smem) + half, (uint16_t)v, __ATOMIC_RELAXED); }
+THX_DEV unsigned long long ldsRead64(uint32_t dword2) { return __atomic_load_n(reinterpret_cast<unsigned long long*>(thx_smem) + dword2, __ATOMIC_RELAXED); }
+THX_DEV void ldsWrite32(uint32_t word, uint32_t v) { __atomic_store_n(reinterpret_cast<uint32_t*>(thx_smem) + word, v, __ATOMIC_RELAXED); }
+constexpr uint32_t kNoCell = 0xFFFFFFFFu;
 
 // ---- state <-> registers -------------------------------------------------
 // chunk0 {pos.xyz, time} chunk1 {dir.xyz, wavelength} chunk2 {lin, log, medium lo, hi}
@@ -272,6 +284,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     pool.cap = Lay::qcap(P);
     pool.capShift = 31u - (uint32_t)__builtin_clz(pool.cap);
     pool.ctr = reinterpret_cast<uint32_t*>(pool.q + 8 * pool.cap);
+    pool.qHalf = 2u * (stackWord0 + args.stack_wave_words * (T >> 6));
+    pool.ctrWord = pool.qHalf / 2u + 4u * pool.cap;
 
     // response.histogram.glsl:20-29 initResponse; every slot starts free
     for (uint32_t i = tid; i < n_bins; i += T) hist[i] = 0.0f;
@@ -294,7 +308,6 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
 
     const thx_propagate_params& prop = args.p.scene.propagation;
     const uint64_t sceneMedium = (uint64_t)args.p.scene.sceneMedium[0] | ((uint64_t)args.p.scene.sceneMedium[1] << 32);
-    volatile uint32_t* const ctr = pool.ctr;
     auto rl = [](uint32_t v, uint32_t k) { return (uint32_t)__builtin_amdgcn_readlane((int)v, (int)k); };
 
     // What a finished stage hands to the scheduler: every lane appends at most two entries,
@@ -333,12 +346,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             if (__ballot(hasB) != 0ull)
                 if (hasB) posB = atomicAdd(&pool.ctr[cTail(S_TS)], 1u);
         }
-        const unsigned long long hv = reinterpret_cast<volatile unsigned long long*>(pool.ctr)[qLane]; // {head, tail} / {cursor, abort}
+        const unsigned long long hv = ldsRead64(pool.ctrWord / 2u + qLane); // {head, tail} / {cursor, abort}
         const uint32_t hvx = (uint32_t)hv, hvy = (uint32_t)(hv >> 32);
 
         // ring cells of this lane's entries
-        volatile uint16_t* cellA = nullptr;
-        volatile uint16_t* cellB = nullptr;
+        uint32_t cellA = kNoCell, cellB = kNoCell; // LDS half-word indices
         if (pushA) {
             cellA = pool.queue(dstA) + (posA & pool.mask(dstA));
             entA |= pool.lapTag(dstA, posA);
@@ -381,11 +393,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         // previous lap is ~10^4 cycles late), the claim itself (CAS on the ring head), and,
         // speculatively, the entries the claim would give this wavefront.
         uint32_t chkA = Q_EMPTY, chkB = Q_EMPTY, casOld = 0, spec = Q_EMPTY;
-        if (cellA) chkA = *cellA;
-        if (cellB) chkB = *cellB;
+        if (cellA != kNoCell) chkA = ldsRead16(cellA);
+        if (cellB != kNoCell) chkB = ldsRead16(cellB);
         if (lane == 0 && n0 > 0u) casOld = atomicCAS(&pool.ctr[cHead((int)qa)], ha, ha + n0);
         if (lane == 1 && n1 > 0u) casOld = atomicCAS(&pool.ctr[cHead(S_TS)], hb, hb + n1);
-        volatile uint16_t* claimCell = nullptr;
+        uint32_t claimCell = kNoCell;
         uint32_t wantTag = 0;
         if (lane < n0) {
             claimCell = pool.queue((int)qa) + ((ha + lane) & pool.mask((int)qa));
@@ -394,22 +406,22 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             claimCell = pool.queue(S_TS) + ((hb + (lane - n0)) & pool.mask(S_TS));
             wantTag = pool.lapTag(S_TS, hb + (lane - n0));
         }
-        if (claimCell) spec = *claimCell;
+        if (claimCell != kNoCell) spec = ldsRead16(claimCell);
 
         // ---- publish the entries of the finished stage
-        if (cellA) {
+        if (cellA != kNoCell) {
             for (uint32_t spin = 0; chkA != Q_EMPTY; ++spin) {
-                if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; break; }
-                chkA = *cellA;
+                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); break; }
+                chkA = ldsRead16(cellA);
             }
-            *cellA = (uint16_t)entA;
+            ldsWrite16(cellA, entA);
         }
-        if (cellB) {
+        if (cellB != kNoCell) {
             for (uint32_t spin = 0; chkB != Q_EMPTY; ++spin) {
-                if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; break; }
-                chkB = *cellB;
+                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); break; }
+                chkB = ldsRead16(cellB);
             }
-            *cellB = (uint16_t)entB;
+            ldsWrite16(cellB, entB);
         }
         dstA = -1; hasB = false;
 
@@ -429,7 +441,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             if (lane == 0) atomicAdd(&profLds[11], 1ull);
 #endif
             if (++idleSpins > kIdleSpinLimit) {
-                if (lane == 0) ctr[C_ABORT] = 1u;
+                if (lane == 0) ldsWrite32(pool.ctrWord + C_ABORT, 1u);
                 break;
             }
             if (best == 0u) __builtin_amdgcn_s_sleep(THX_IDLE_SLEEP);
@@ -444,10 +456,10 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             // reserved but not written yet: the cell is empty (or, after a very late claimer of
             // the previous lap, still holds that lap's entry: wrong tag)
             for (uint32_t spin = 0; (entry & 0xC000u) != wantTag; ++spin) {
-                if (spin > kCellSpinLimit) { ctr[C_ABORT] = 1u; entry = 0; act = false; break; }
-                entry = *claimCell;
+                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); entry = 0; act = false; break; }
+                entry = ldsRead16(claimCell);
             }
-            *claimCell = (uint16_t)Q_EMPTY;
+            ldsWrite16(claimCell, Q_EMPTY);
             entry &= 0x3FFFu;
         } else {
             entry = 0;
@@ -687,7 +699,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     __syncthreads();
     // a tripped scheduler watchdog (a bug, never seen) poisons the light curve instead of
     // returning a plausible partial one
-    const bool aborted = ctr[C_ABORT] != 0u;
+    const bool aborted = pool.ctr[C_ABORT] != 0u;
 #ifdef THX_STAGE_PROFILE
     if (tid < 48 && args.prof) atomicAdd(&args.prof[tid], reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF)[tid]);
 #endif

@@ -890,11 +890,11 @@ THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const Que
     const InstanceRecord* inst = sc.instances + q.instance;
     const GeometryGLSL geom = sc.geometries[inst->geometry];
     hit.customId = inst->customIndex;
-    const uint32_t* ix = reinterpret_cast<const uint32_t*>(geom.indices) + 3 * (size_t)q.prim;
-    const float* vb = reinterpret_cast<const float*>(geom.vertices);
-    const float* a = vb + 6 * (size_t)ix[0];
-    const float* b = vb + 6 * (size_t)ix[1];
-    const float* c = vb + 6 * (size_t)ix[2];
+    const THX_GLOBAL uint32_t* ix = reinterpret_cast<const THX_GLOBAL uint32_t*>(geom.indices) + 3 * (size_t)q.prim;
+    const THX_GLOBAL float* vb = reinterpret_cast<const THX_GLOBAL float*>(geom.vertices);
+    const THX_GLOBAL float* a = vb + 6 * (size_t)ix[0];
+    const THX_GLOBAL float* b = vb + 6 * (size_t)ix[1];
+    const THX_GLOBAL float* c = vb + 6 * (size_t)ix[2];
     f3 p0 = ld3(a), p1 = ld3(b), p2 = ld3(c);
     f3 n0 = ld3(a + 3), n1v = ld3(b + 3), n2v = ld3(c + 3);
     float bx = q.b1, by = q.b2;
@@ -917,7 +917,7 @@ THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const Que
     uint32_t flagsIn = 0, flagsOut = 0;
     hit.mat_inside = 0; hit.mat_outside = 0;
     if (geom.material != 0) {
-        const MaterialGLSL* mat = reinterpret_cast<const MaterialGLSL*>(geom.material);
+        const THX_GLOBAL MaterialGLSL* mat = reinterpret_cast<const THX_GLOBAL MaterialGLSL*>(geom.material);
         hit.mat_inside = mat->inside; hit.mat_outside = mat->outside;
         flagsIn = mat->flagsInwards; flagsOut = mat->flagsOutwards;
     }
@@ -950,7 +950,7 @@ THX_DEV Reflectance fresnelReflect(Lane<V>& L, const Ray& ray, const SurfaceHit&
     float n_i = ray.constants.n;
     float n_t = 1.0f;
     if (otherMed != 0) {
-        const MediumGLSL* m = reinterpret_cast<const MediumGLSL*>(otherMed);
+        const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(otherMed);
         float u_t = normalize_lambda(m, ray.wavelength);
         n_t = lookUp(m->n, u_t, 1.0f, L.cnt);
     }
