@@ -122,9 +122,9 @@ int thx_ctx_create(int device, thx_ctx** out) {
 
 int thx_ctx_destroy(thx_ctx* ctx) {
     if (!ctx) return THX_OK;
-    hipSetDevice(ctx->device);
-    hipStreamSynchronize(ctx->stream);
-    hipStreamDestroy(ctx->stream);
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return THX_OK;
 }
@@ -261,9 +261,9 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
 
 int thx_scene_destroy(thx_scene* scene) {
     if (!scene) return THX_OK;
-    hipSetDevice(scene->ctx->device);
-    hipStreamSynchronize(scene->ctx->stream);
-    for (void* p : scene->allocs) hipFree(p);
+    (void)hipSetDevice(scene->ctx->device);
+    (void)hipStreamSynchronize(scene->ctx->stream);
+    for (void* p : scene->allocs) (void)hipFree(p);
     delete scene;
     return THX_OK;
 }
@@ -282,7 +282,7 @@ int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out
     float *d_in = nullptr, *d_out = nullptr;
     THX_HIP(hipMalloc((void**)&d_in, sizeof(float) * 7 * (size_t)n));
     hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * 6 * (size_t)n);
-    if (e != hipSuccess) { hipFree(d_in); return hipFail(e, "hipMalloc"); }
+    if (e != hipSuccess) { (void)hipFree(d_in); return hipFail(e, "hipMalloc"); }
     e = hipMemcpy(d_in, rays7, sizeof(float) * 7 * (size_t)n, hipMemcpyHostToDevice);
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     if (e == hipSuccess) e = hipEventCreate(&ev0);
@@ -293,11 +293,11 @@ int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out
     if (e == hipSuccess) e = hipEventRecord(ev1, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess) e = hipEventElapsedTime(&scene->lastQueryMs, ev0, ev1);
-    if (ev0) hipEventDestroy(ev0);
-    if (ev1) hipEventDestroy(ev1);
+    if (ev0) (void)hipEventDestroy(ev0);
+    if (ev1) (void)hipEventDestroy(ev1);
     if (e == hipSuccess) e = hipMemcpy(out6, d_out, sizeof(float) * 6 * (size_t)n, hipMemcpyDeviceToHost);
-    hipFree(d_in);
-    hipFree(d_out);
+    (void)hipFree(d_in);
+    (void)hipFree(d_out);
     if (e != hipSuccess) return hipFail(e, "thx_scene_query");
     return THX_OK;
 }
@@ -428,20 +428,20 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
 
 int thx_tracer_destroy(thx_tracer* t) {
     if (!t) return THX_OK;
-    hipSetDevice(t->ctx->device);
-    hipStreamSynchronize(t->ctx->stream);
+    (void)hipSetDevice(t->ctx->device);
+    (void)hipStreamSynchronize(t->ctx->stream);
     for (int i = 0; i < 2; ++i) {
-        if (t->slabs[i]) hipFree(t->slabs[i]);
-        if (t->out[i]) hipFree(t->out[i]);
+        if (t->slabs[i]) (void)hipFree(t->slabs[i]);
+        if (t->out[i]) (void)hipFree(t->out[i]);
     }
     for (uint32_t i = 0; i < thx_tracer::kRing; ++i) {
-        if (t->evStart[i]) hipEventDestroy(t->evStart[i]);
-        if (t->evStop[i]) hipEventDestroy(t->evStop[i]);
+        if (t->evStart[i]) (void)hipEventDestroy(t->evStart[i]);
+        if (t->evStop[i]) (void)hipEventDestroy(t->evStop[i]);
     }
-    if (t->stats) hipFree(t->stats);
-    if (t->prof) hipFree(t->prof);
-    if (t->track) hipFree(t->track);
-    if (t->hits) hipFree(t->hits);
+    if (t->stats) (void)hipFree(t->stats);
+    if (t->prof) (void)hipFree(t->prof);
+    if (t->track) (void)hipFree(t->track);
+    if (t->hits) (void)hipFree(t->hits);
     delete t;
     return THX_OK;
 }
@@ -662,8 +662,8 @@ int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream,
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && out_u32) e = hipMemcpy(out_u32, d_u, 4 * total, hipMemcpyDeviceToHost);
     if (e == hipSuccess && out_f32) e = hipMemcpy(out_f32, d_f, 4 * total, hipMemcpyDeviceToHost);
-    if (d_u) hipFree(d_u);
-    if (d_f) hipFree(d_f);
+    if (d_u) (void)hipFree(d_u);
+    if (d_f) (void)hipFree(d_f);
     if (e != hipSuccess) return hipFail(e, "thx_rng_fill");
     return THX_OK;
 }
