@@ -125,6 +125,10 @@ typedef struct {
     thx_target_params target;
     thx_scene_trace_params scene;   /* kind == THX_TRACER_SCENE_FORWARD */
     thx_guide_params guide;
+    /* THX_FLAG_PHOTON: the reference runs nRuns dispatches of steps_per_run steps and starts
+     * run r at RNG dimension r * rng_per_run (trace.py:2489-2491, 2655-2659) */
+    uint32_t photon_steps_per_run;
+    uint32_t photon_rng_per_run;
 } thx_run_params;
 
 #pragma pack(pop)
@@ -143,6 +147,8 @@ enum {
     THX_FLAG_STATISTICS            = 1u << 8, /* EventStatisticCallback + traversal counters */
     THX_FLAG_TRACK                 = 1u << 9, /* per-event state dump (parity probe, TrackRecordCallback) */
     THX_FLAG_LIGHT_PENCIL          = 1u << 10, /* PencilLightSource, else SphericalLightSource */
+    THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
+                                                  absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;
                                                   thx_target_params.hemisphereProb then holds its `prob` = 1/area */
 };
@@ -174,7 +180,11 @@ typedef struct {
  *             hit_capacity entries each for posX posY posZ dirX dirY dirZ nrmX nrmY nrmZ
  *             [stokesI stokesQ stokesU stokesV polX polY polZ] wavelength time contrib and
  *             an int32 column objectId. Runs on the instrumented kernel variants. */
-enum { THX_RESPONSE_HISTOGRAM = 0, THX_RESPONSE_RECORD = 1 };
+/* STORE_TIME = StoreTimeHitResponse(UniformValueResponse()) (response.py:656-800,
+ *             shader/response.time.store.glsl): a hit is kept with probability `value`
+ *             (one random draw of the photon's stream); queue = uint32 count, float time[cap],
+ *             int32 objectId[cap] (the latter if hit_polarized, which here means storeObjectId) */
+enum { THX_RESPONSE_HISTOGRAM = 0, THX_RESPONSE_RECORD = 1, THX_RESPONSE_STORE_TIME = 2 };
 
 /* vertices [n][6] f32 = position + normal (shader/scene.types.glsl:6-9),
  * indices [m][3] u32 (:12-14) -- what hp.Mesh holds (scene.py:425-431) */
@@ -252,6 +262,7 @@ int thx_tracer_read_stage_profile(thx_tracer* tracer, uint64_t* out48);
  * synchronises), optionally followed by resetting its counter for the next batch. The counter
  * keeps counting past a full queue; entries beyond hit_capacity are dropped. */
 size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized);
+size_t thx_time_queue_bytes(uint32_t hit_capacity, uint32_t store_object_id); /* THX_RESPONSE_STORE_TIME queue */
 int thx_tracer_read_hits(thx_tracer* tracer, void* out, size_t nbytes, int clear);
 int thx_tracer_hits_device_ptr(thx_tracer* tracer, uint64_t* dev_addr);
 /* parity probe: per-event dump of the last run, [batch][path_length+3][THX_TRACK_WORDS] */

@@ -215,6 +215,22 @@ def set_hit_queue(queue: np.ndarray | None, capacity: int, polarized: bool) -> N
     fn(queue.ctypes.data if queue is not None else None, int(capacity), int(bool(polarized)))
 
 
+def set_time_queue(queue: np.ndarray | None, capacity: int, store_object_id: bool) -> None:
+    """StoreTimeHitResponse: the next traces keep a hit's time with probability `contrib`"""
+    fn = lib().orc_set_time_queue
+    fn.argtypes = [C.c_void_p, C.c_uint32, C.c_int]
+    fn.restype = None
+    fn(queue.ctypes.data if queue is not None else None, int(capacity), int(bool(store_object_id)))
+
+
+def set_photon_mode(steps_per_run: int, rng_per_run: int) -> None:
+    """ScenePhotonTracer semantics for the next scene traces; (0, 0) switches back"""
+    fn = lib().orc_set_photon_mode
+    fn.argtypes = [C.c_uint32, C.c_uint32]
+    fn.restype = None
+    fn(int(steps_per_run), int(rng_per_run))
+
+
 def trace_volume(common: Common, trace: VolumeTraceParams, target: TargetParams, *, threads: int = 0, track: bool = False):
     hist = np.zeros(common.n_bins, dtype=np.float32)
     stats = np.zeros(N_STATS, dtype=np.uint64)

@@ -304,6 +304,8 @@ typedef struct {
     float* hist;   /* partial histogram of the current block */
     float* track;  /* per-event dump (may be NULL) */
     uint32_t track_events;
+    uint32_t cur_idx;   /* RNG stream / dimension of the photon being traced: responses that */
+    uint32_t* cur_dim;  /* draw random numbers (response.time.store.glsl) use them */
 } Ctx;
 
 static inline uint64_t rayMedium(const Ctx* x, const Ray* r) {
@@ -592,6 +594,36 @@ void orc_set_hit_queue(uint32_t* queue, uint32_t capacity, int polarized) {
     g_hit_queue = queue; g_hit_capacity = capacity; g_hit_polarized = polarized;
 }
 
+/* StoreTimeHitResponse(UniformValueResponse()): queue = uint32 count, float time[cap], int32 objectId[cap] */
+static uint32_t* g_time_queue = NULL;
+static uint32_t g_time_capacity = 0;
+static int g_time_store_id = 0;
+void orc_set_time_queue(uint32_t* queue, uint32_t capacity, int store_object_id) {
+    g_time_queue = queue; g_time_capacity = capacity; g_time_store_id = store_object_id;
+}
+/* ScenePhotonTracer (tracer.scene.photon.{init,loop}.glsl): steps per run and RNG dimensions
+ * per run (trace.py:2489-2491, 2655-2659); 0 steps = forward tracer */
+static uint32_t g_photon_steps_per_run = 0, g_photon_rng_per_run = 0;
+void orc_set_photon_mode(uint32_t steps_per_run, uint32_t rng_per_run) {
+    g_photon_steps_per_run = steps_per_run; g_photon_rng_per_run = rng_per_run;
+}
+
+
+/* response.time.store.glsl:14-25 with response.uniform.glsl:4-6 */
+static void storeTime(Ctx* x, const HitItem* it) {
+    float value = it->contrib;
+    if (rnd(x, x->cur_idx, x->cur_dim) < value) {
+        uint32_t id;
+        x->cnt.stats[ST_RESPONSES]++;
+#pragma omp atomic capture
+        id = g_time_queue[0]++;
+        if (id >= g_time_capacity) return;
+        float* t = (float*)(g_time_queue + 1) + id;
+        *t = it->time;
+        if (g_time_store_id) *(int32_t*)(t + g_time_capacity) = it->objectId;
+    }
+}
+
 static void recordHit(Ctx* x, const HitItem* it) {
     uint32_t id;
     x->cnt.stats[ST_RESPONSES]++;
@@ -620,6 +652,7 @@ static void recordHit(Ctx* x, const HitItem* it) {
 
 /* response.histogram.glsl:59-68 with response.uniform.glsl:4-6 */
 static void response(Ctx* x, const HitItem* item) {
+    if (g_time_queue) { storeTime(x, item); return; }
     if (g_hit_queue) { recordHit(x, item); return; }
     float value = item->contrib;
     float f = floorf((item->time - x->c->response.t0) / x->c->response.binSize);
@@ -729,6 +762,7 @@ static Ray sampleRay(Ctx* x, uint64_t medium, uint32_t idx, uint32_t* dim) {
             r.stokes.z = c->light.stokes[2]; r.stokes.w = c->light.stokes[3];
             r.polRef = V3(c->light.polRef[0], c->light.polRef[1], c->light.polRef[2]);
         }
+        if (g_photon_steps_per_run) r.lin_contrib = 1.0f; /* tracer.scene.photon.init.glsl:49-53 */
         return r;
     }
     /* sampleLight */
@@ -754,6 +788,7 @@ static Ray sampleRay(Ctx* x, uint64_t medium, uint32_t idx, uint32_t* dim) {
         r.stokes.x = 1.0f; r.stokes.y = 0.0f; r.stokes.z = 0.0f; r.stokes.w = 0.0f;
         r.polRef = createLocalCOSY(rayDir).c0;
     }
+    if (g_photon_steps_per_run) r.lin_contrib = 1.0f; /* tracer.scene.photon.init.glsl:49-53 */
     return r;
 }
 
@@ -980,6 +1015,7 @@ static void vol_traceMain(Ctx* x, const orc_volume_trace_params* tp, const orc_t
     const orc_common* c = x->c;
     uint32_t dim = 0;
     uint32_t idx = c->photon_offset + local_idx;
+    x->cur_idx = idx; x->cur_dim = &dim;
     int disable_mis = (c->flags & ORC_FLAG_DISABLE_MIS) != 0;
     int disable_direct = (c->flags & ORC_FLAG_DISABLE_DIRECT) != 0;
     int DIRECT_LIGHTING = disable_mis && !disable_direct; /* :211-215 */
@@ -1710,15 +1746,32 @@ static void scn_traceMain(Ctx* x, const SceneArgs* a, uint32_t local_idx) {
     uint32_t dim = 0;
     uint32_t idx = c->photon_offset + local_idx;
     uint64_t medium = (uint64_t)a->tp->sceneMedium[0] | ((uint64_t)a->tp->sceneMedium[1] << 32);
+    x->cur_idx = idx; x->cur_dim = &dim;
     Ray ray = sampleRay(x, medium, idx, &dim);
     onEvent(x, &ray, RESULT_CODE_RAY_CREATED, local_idx, 0, dim);
     int allowResponse = !(c->flags & ORC_FLAG_DISABLE_DIRECT);
+    const uint32_t perRun = g_photon_steps_per_run; /* != 0: ScenePhotonTracer */
     for (uint32_t i = 1; i <= c->path_length; ++i) {
-        int last = i == c->path_length;
+        int last = i == c->path_length && !perRun; /* photon loop: processInteraction(..., last = false) */
+        /* run r of the photon tracer starts at RNG dimension r * rng_per_run (Push.dim) */
+        if (perRun && i > 1 && (i - 1) % perRun == 0) dim = ((i - 1) / perRun) * g_photon_rng_per_run;
         SurfaceHit hit;
         int result = scn_trace(x, a, &ray, &hit, idx, &dim, allowResponse);
         if (result >= 0)
             result = processInteraction(x, a, &ray, &hit, idx, &dim, allowResponse, last);
+        if (perRun && result >= 0) { /* tracer.scene.photon.loop.glsl:68-83 */
+            if (x->polarized) {
+                ray.lin_contrib *= ray.stokes.x;
+                float s0 = ray.stokes.x;
+                ray.stokes.x /= s0; ray.stokes.y /= s0; ray.stokes.z /= s0; ray.stokes.w /= s0;
+            }
+            if (ray.lin_contrib * expf(ray.log_contrib) <= rnd(x, idx, &dim)) {
+                result = RESULT_CODE_RAY_ABSORBED;
+            } else {
+                ray.lin_contrib = 1.0f;
+                ray.log_contrib = 0.0f;
+            }
+        }
         onEvent(x, &ray, result, local_idx, i, dim);
         if (result < 0) return;
         if (!(c->flags & ORC_FLAG_DISABLE_MIS)) allowResponse = result != RESULT_CODE_RAY_SCATTERED;

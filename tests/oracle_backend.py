@@ -111,6 +111,7 @@ class OracleBackend:
         spec = t.spec
         c = orc.Common()
         flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER))
+        photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE
         c.flags = flags
@@ -125,17 +126,26 @@ class OracleBackend:
         _copy(c.wavelength, params.wavelength)
         _copy(c.response, params.response)
         want_track = bool(spec.flags & capi.FLAG_TRACK)
-        record = getattr(spec, "response_kind", 0) == capi.RESPONSE_RECORD
+        kind = getattr(spec, "response_kind", 0)
+        record = kind in (capi.RESPONSE_RECORD, capi.RESPONSE_STORE_TIME)
         if record:
             if t.hits is None:
-                ncol = 20 if spec.hit_polarized else 13
+                ncol = (2 if spec.hit_polarized else 1) if kind == capi.RESPONSE_STORE_TIME else (20 if spec.hit_polarized else 13)
                 t.hits = np.zeros(1 + ncol * spec.hit_capacity, dtype=np.uint32)
-            orc.set_hit_queue(t.hits, spec.hit_capacity, spec.hit_polarized)
+            if kind == capi.RESPONSE_STORE_TIME:
+                orc.set_time_queue(t.hits, spec.hit_capacity, spec.hit_polarized)
+            else:
+                orc.set_hit_queue(t.hits, spec.hit_capacity, spec.hit_polarized)
+        if photon:
+            orc.set_photon_mode(params.photon_steps_per_run, params.photon_rng_per_run)
         try:
             hist, stats, track = self._trace(spec, t, c, params, want_track)
         finally:
             if record:
                 orc.set_hit_queue(None, 0, False)
+                orc.set_time_queue(None, 0, False)
+            if photon:
+                orc.set_photon_mode(0, 0)
         t.raw[cfg] = hist
         t.stats += stats
         t.track = track

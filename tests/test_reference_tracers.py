@@ -524,6 +524,72 @@ def test_TrackRecordCallback(backend, polarized):
     assert codes.min() >= minCode and codes.max() <= maxCode
 
 
+@pytest.mark.parametrize("polarized", [False, True])
+def test_ScenePhotonTracer(backend, polarized):
+    """/root/reference/tests/test_trace.py:1466-1561"""
+    if not hp.isRaytracingEnabled():
+        pytest.skip("ray tracing not supported")
+
+    N = 32 * 256
+    N_RUNS = 5
+    N_SCATTER = 5
+    T0, T1 = 10.0 * u.ns, 20.0 * u.ns
+    T_MAX = 1.0 * u.ms
+    capacity = 48 * 256
+    light_pos = (-1.0, -7.0, 0.0) * u.m
+    light_budget = float(N)
+
+    water = WaterTestModel().createMedium()
+    glass = theia.material.BK7Model().createMedium()
+    mat = theia.material.Material("mat", glass, water, flags=("DR", "B"))
+    matStore = theia.material.MaterialStore([mat])
+    store = theia.scene.MeshStore({"cube": S.bundled_mesh("cone"), "sphere": S.bundled_mesh("sphere")})
+    r, d = 40.0 * u.m, 5.0 * u.m
+    r_scale = 0.99547149974733 * u.m  # radius of inscribed sphere (icosphere)
+    x, y, z = 10.0, 5.0, -5.0
+    t1 = Transform.TRS(scale=r, translate=(x, y, z + r + d))
+    c1 = store.createInstance("sphere", "mat", t1, detectorId=0)
+    t2 = Transform.TRS(scale=r, translate=(x, y, z - r - d), rotate=(0.0, 0.0, 1.0, 110.0))
+    c2 = store.createInstance("sphere", "mat", t2, detectorId=1)
+    scene = theia.scene.Scene([c1, c2], matStore.material, medium=matStore.media["water"])
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource()
+    source = theia.light.SphericalLightSource(position=light_pos, timeRange=(T0, T1), budget=light_budget)
+    recorder = theia.response.HitRecorder(polarized=polarized)
+    stats = theia.trace.EventStatisticCallback()
+    tracer = theia.trace.ScenePhotonTracer(N, source, photons, recorder, rng, scene, capacity=capacity, targetId=-1,
+                                           nRuns=N_RUNS, nScatteringPerRun=N_SCATTER, maxTime=T_MAX, callback=stats,
+                                           polarized=polarized)
+    pl.runPipeline(tracer.collectStages())
+    hits = recorder.queue.view(0)
+
+    assert hits.count > 0
+    assert hits.count <= tracer.maxHits
+    hits = hits[: hits.count]
+    assert stats.created == N
+
+    r_hits = np.sqrt(np.square(hits["position"]).sum(-1))
+    assert np.all((r_hits <= 1.0) & (r_hits >= r_scale))
+    assert np.allclose(np.square(hits["normal"]).sum(-1), 1.0)
+    assert np.max(hits["time"]) <= T_MAX
+    assert (hits["objectId"] == 0).sum() > 0
+    assert (hits["objectId"] == 1).sum() > 0
+
+    if polarized:
+        assert np.abs(hits["stokes"][:, 0] - 1.0).max() < 1e-6
+        assert np.sqrt(np.square(hits["stokes"][:, 1:]).sum(-1).max()) - 1.0 <= 1e-6
+        assert hits["stokes"][:, 1:].max() <= 1.0
+        assert hits["stokes"][:, 1:].min() >= -1.0
+        polRef = hits["polarizationRef"]
+        assert np.abs(np.square(polRef).sum(-1) - 1.0).max() < 1e-6
+        polRef_exp = np.cross(hits["direction"], hits["normal"])
+        d = np.square(polRef_exp).sum(-1)
+        mask = d > 1e-7
+        polRef_exp /= np.sqrt(d)[:, None]
+        assert np.abs(np.abs((polRef_exp * polRef).sum(-1))[mask] - 1.0).max() < 1e-6
+
+
 def _hits_table(view) -> np.ndarray:
     """one row per hit: time, contrib, wavelength, position, direction, normal[, stokes, polRef]"""
     h = view[: view.count]
@@ -534,9 +600,31 @@ def _hits_table(view) -> np.ndarray:
     return t[np.lexsort((t[:, 2], t[:, 0]))]
 
 
+def _photon_case(polarized, N=32 * 256):
+    water = WaterTestModel().createMedium()
+    glass = theia.material.BK7Model().createMedium()
+    mat = theia.material.Material("mat", glass, water, flags=("DR", "B"))
+    matStore = theia.material.MaterialStore([mat])
+    store = theia.scene.MeshStore({"sphere": S.bundled_mesh("sphere")})
+    r, d = 40.0 * u.m, 5.0 * u.m
+    x, y, z = 10.0, 5.0, -5.0
+    c1 = store.createInstance("sphere", "mat", Transform.TRS(scale=r, translate=(x, y, z + r + d)), detectorId=0)
+    c2 = store.createInstance("sphere", "mat", Transform.TRS(scale=r, translate=(x, y, z - r - d), rotate=(0.0, 0.0, 1.0, 110.0)),
+                              detectorId=1)
+    scene = theia.scene.Scene([c1, c2], matStore.material, medium=matStore.media["water"])
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource()
+    source = theia.light.SphericalLightSource(position=(-1.0, -7.0, 0.0), timeRange=(10.0, 20.0), budget=float(N))
+    recorder = theia.response.HitRecorder(polarized=polarized)
+    tracer = theia.trace.ScenePhotonTracer(N, source, photons, recorder, rng, scene, targetId=-1, nRuns=5, nScatteringPerRun=5,
+                                           maxTime=1.0 * u.ms, polarized=polarized)
+    pl.runPipeline(tracer.collectStages())
+    return tracer, recorder, None, dict(keep=(matStore, store, scene))
+
+
 @pytest.mark.gpu
 @pytest.mark.parametrize("polarized", [False, True])
-@pytest.mark.parametrize("kind", ["volume", "scene"])
+@pytest.mark.parametrize("kind", ["volume", "scene", "photon"])
 def test_recorded_hits_match_oracle(kind, polarized):
     """the HIP kernels record the oracle's hits: same number up to the photons that flip a
     branch inside libm noise, and hit by hit the same time / contribution / geometry"""
@@ -550,8 +638,10 @@ def test_recorded_hits_match_oracle(kind, polarized):
         try:
             if kind == "volume":
                 _, rec, _, keep = _volume_case(False, False, False, True, polarized)
-            else:
+            elif kind == "scene":
                 _, rec, _, keep = _scene_case(polarized, False, False, False, False, False, True)
+            else:
+                _, rec, _, keep = _photon_case(polarized, 4 * 8192)
             tables.append(_hits_table(rec.queue.view(0)))
         finally:
             _backend._backend = prev

@@ -20,13 +20,14 @@ __all__ = [
     "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
     "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
-    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "EXPORTED_SYMBOLS",
+    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "EXPORTED_SYMBOLS",
 ]
 
 TRACER_VOLUME_FORWARD = 0
 TRACER_SCENE_FORWARD = 1
 RESPONSE_HISTOGRAM = 0
 RESPONSE_RECORD = 1
+RESPONSE_STORE_TIME = 2
 FLAG_POLARIZED = 1 << 0
 FLAG_DISABLE_DIRECT = 1 << 1
 FLAG_DISABLE_MIS = 1 << 2
@@ -38,6 +39,7 @@ FLAG_STATISTICS = 1 << 8
 FLAG_TRACK = 1 << 9
 FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_TARGET_INNER = 1 << 11
+FLAG_PHOTON = 1 << 12
 N_STATS = 20
 TRACK_WORDS = 12
 STAT_NAMES = (
@@ -112,6 +114,8 @@ class RunParams(_Packed):
         ("target", TargetParams),
         ("scene", SceneTraceParams),
         ("guide", GuideParams),
+        ("photon_steps_per_run", c_uint32),
+        ("photon_rng_per_run", c_uint32),
     ]
 
 
@@ -167,6 +171,7 @@ _PROTOS = {
     "thx_tracer_read_stage_profile": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_read_track": (c_int, [c_void_p, POINTER(c_float), c_size_t]),
     "thx_hit_queue_bytes": (c_size_t, [c_uint32, c_uint32]),
+    "thx_time_queue_bytes": (c_size_t, [c_uint32, c_uint32]),
     "thx_tracer_read_hits": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "thx_tracer_hits_device_ptr": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),

@@ -84,6 +84,13 @@ struct thx_tracer {
     int lastSlot[2] = {-1, -1};  // ring slot of the most recent launch per config
 };
 
+// 4-byte columns of a tracer's hit queue (record: response.queue.glsl:6-33, store time:
+// response.time.store.glsl:4-10)
+static size_t hitColumns(const thx_tracer_desc& d) {
+    if (d.response_kind == THX_RESPONSE_STORE_TIME) return d.hit_polarized ? 2 : 1;
+    return d.hit_polarized ? 20 : 13;
+}
+
 extern "C" {
 
 const char* thx_last_error(void) { return g_error.c_str(); }
@@ -317,8 +324,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
     if (desc->kind == THX_TRACER_SCENE_FORWARD && !scene)
         return fail(THX_ERR_INVALID, "scene tracer needs a scene");
-    const bool record = desc->response_kind == THX_RESPONSE_RECORD;
-    if (desc->response_kind > THX_RESPONSE_RECORD) return fail(THX_ERR_INVALID, "unknown response kind");
+    const bool record = desc->response_kind == THX_RESPONSE_RECORD || desc->response_kind == THX_RESPONSE_STORE_TIME;
+    if (desc->response_kind > THX_RESPONSE_STORE_TIME) return fail(THX_ERR_INVALID, "unknown response kind");
     if (record && desc->hit_capacity == 0) return fail(THX_ERR_INVALID, "cannot create a hit queue of size 0 (response.py:266-267)");
     if (!record && (desc->n_bins == 0 || desc->n_bins > 8192))
         return fail(THX_ERR_INVALID, "n_bins must be in [1, 8192] (LDS histogram, response.py:1098)");
@@ -414,7 +421,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (e == hipSuccess) e = hipMemset(t->track, 0, nb);
     }
     if (e == hipSuccess && record) {
-        const size_t nb = thx_hit_queue_bytes(desc->hit_capacity, desc->hit_polarized);
+        const size_t nb = 4 + hitColumns(*desc) * 4 * (size_t)desc->hit_capacity;
         e = hipMalloc((void**)&t->hits, nb);
         if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
     }
@@ -502,6 +509,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.hits = t->hits;
     a.hit_capacity = t->desc.hit_capacity;
     a.hit_polarized = t->desc.hit_polarized;
+    a.hit_kind = t->desc.response_kind;
     a.track = t->track;
     if (t->scene) a.scene = t->scene->view;
     uint32_t grid, ppw;
@@ -572,6 +580,10 @@ int thx_tracer_reset_stats(thx_tracer* t) {
     return THX_OK;
 }
 
+size_t thx_time_queue_bytes(uint32_t hit_capacity, uint32_t store_object_id) {
+    return 4 + (store_object_id ? 2 : 1) * 4 * (size_t)hit_capacity; // response.time.store.glsl:4-10
+}
+
 size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized) {
     const size_t columns = hit_polarized ? 20 : 13; // response.queue.glsl:6-33
     return 4 + columns * 4 * (size_t)hit_capacity;
@@ -584,7 +596,7 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
     THX_HIP(hipDeviceSynchronize());
     // the counter first, then of every column only the entries that were appended (a queue is
     // sized for the worst case, maxHitsPerThread * batch: reading it whole would move ~10x more)
-    const size_t cap = t->desc.hit_capacity, columns = t->desc.hit_polarized ? 20 : 13;
+    const size_t cap = t->desc.hit_capacity, columns = hitColumns(t->desc);
     if (nbytes < 4) return fail(THX_ERR_INVALID, "output buffer too small");
     uint32_t count = 0;
     THX_HIP(hipMemcpy(&count, t->hits, 4, hipMemcpyDeviceToHost));

@@ -187,8 +187,9 @@ THX_DEV bool rootHit(Lane<V>& L, f3 org, f3 dir, float tmax) {
 // end of one loop iteration of tracer.scene.forward.glsl:70-105; returns true if
 // the photon goes on to another step
 template <class V>
-THX_DEV bool endStep(Lane<V>& L, const Ray& ray, Meta& m, int result) {
+THX_DEV bool endStep(Lane<V>& L, Ray& ray, Meta& m, int result) {
     const uint32_t step = (m.flags & F_STEP_MASK) >> F_STEP_SHIFT;
+    if (L.a->flags & THX_FLAG_PHOTON) result = photonRoulette(L, ray, result); // changes the ray: store it afterwards
     onEvent(L, ray, result, step);
     if (result < 0) {
         m.flags &= ~F_ALIVE;
@@ -217,7 +218,8 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
     Meta m = loadMeta(pool, slot);
     bindLane(L, m);
     const uint32_t step = (m.flags & F_STEP_MASK) >> F_STEP_SHIFT;
-    const bool last = step == args.path_length;
+    // the photon tracer always scatters: processInteraction(..., last = false)
+    const bool last = step == args.path_length && !(args.flags & THX_FLAG_PHOTON);
     const bool allowResponse = (m.flags & F_ALLOW) != 0u;
     float4 s0 = pool.sc[0 * pool.P + slot];
     float dist = s0.x;
@@ -248,10 +250,10 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
             result = RESULT_CODE_RAY_SCATTERED;
         }
     }
-    storeRay(pool, slot, ray);
     int dest;
     if (scatterNeeded) dest = 1;
     else dest = endStep(L, ray, m, result) ? 2 : 3;
+    storeRay(pool, slot, ray);
     m.dim = L.dim;
     storeMeta(pool, slot, m);
     return dest;
@@ -586,8 +588,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 float u0 = draw(L);
                 float u1 = draw(L);
                 scatterRay(L, rayA, rayA.medium, u0, u1);
-                storeRay(pool, slotA, rayA);
                 doA = endStep(L, rayA, mA, RESULT_CODE_RAY_SCATTERED);
+                storeRay(pool, slotA, rayA);
                 mA.dim = L.dim;
                 if (!doA) {
                     storeMeta(pool, slotA, mA);
@@ -605,6 +607,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             int dest = 0; // 1 traversal, 2 propagate-only, 3 finished
             if (doA) {
                 bindLane(L, mA);
+                if (args.flags & THX_FLAG_PHOTON) photonRunDim(L, (mA.flags & F_STEP_MASK) >> F_STEP_SHIFT);
                 L.cnt.add(ST_STEPS);
                 if (isRayBad(rayA)) {
                     endStep(L, rayA, mA, ERROR_CODE_RAY_BAD);

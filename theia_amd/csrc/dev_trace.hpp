@@ -45,7 +45,8 @@ struct LaunchArgs {
     float* slabs;              // [gridDim.x][n_bins] partial histograms
     uint32_t* hits;            // HitRecorder queue (response.queue.glsl layout) or null: histogram response
     uint32_t hit_capacity;     // entries per SoA column of the queue
-    uint32_t hit_polarized;    // queue has the stokes / polRef columns
+    uint32_t hit_polarized;    // queue has the stokes / polRef columns (store-time queue: the objectId column)
+    uint32_t hit_kind;         // THX_RESPONSE_RECORD or THX_RESPONSE_STORE_TIME
     unsigned long long* stats; // [THX_N_STATS]
     float* track;              // [batch][track_events][THX_TRACK_WORDS] or null
     unsigned long long* prof;  // staged kernel, THX_STAGE_PROFILE builds: [3][16] cycles/rounds/items per stage
@@ -200,8 +201,24 @@ THX_DEV void respond(Lane<V>& L, const Ray& r, const HitFrame& fr) {
                 contrib *= st.x;
                 stokes = f4{st.x / st.x, st.y / st.x, st.z / st.x, st.w / st.x};
             }
-            if (contrib > 0.0f)
-                recordHit(L, fr.objPos, objHitDir, fr.objNrm, stokes, hitPolRef, r.wavelength, r.time, contrib, fr.objectId);
+            if (contrib > 0.0f) {
+                if (L.a->hit_kind == THX_RESPONSE_STORE_TIME) {
+                    // response.time.store.glsl:14-25 with response.uniform.glsl: value = contrib is
+                    // the detection probability, one draw of the photon's stream decides
+                    if (draw(L) < contrib) {
+                        L.cnt.add(ST_RESPONSES);
+                        const uint32_t cap = L.a->hit_capacity;
+                        const uint32_t id = atomicAdd(L.a->hits, 1u);
+                        if (id < cap) {
+                            float* t = reinterpret_cast<float*>(L.a->hits + 1) + id;
+                            *t = r.time;
+                            if (L.a->hit_polarized) *reinterpret_cast<int*>(t + cap) = fr.objectId;
+                        }
+                    }
+                } else {
+                    recordHit(L, fr.objPos, objHitDir, fr.objNrm, stokes, hitPolRef, r.wavelength, r.time, contrib, fr.objectId);
+                }
+            }
             return;
         }
     }
@@ -330,6 +347,7 @@ THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
             r.stokes = f4{P.light.stokes[0], P.light.stokes[1], P.light.stokes[2], P.light.stokes[3]};
             r.polRef = ld3(P.light.polRef);
         }
+        if (L.a->flags & THX_FLAG_PHOTON) r.lin_contrib = 1.0f; // tracer.scene.photon.init.glsl:49-53
         return r;
     }
     float u0 = draw(L);
@@ -348,7 +366,32 @@ THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
     r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
     r.polRef = f3{0.0f, 0.0f, 0.0f};
     if constexpr (V::POL) r.polRef = createLocalCOSY(rayDir).c0;
+    if (L.a->flags & THX_FLAG_PHOTON) r.lin_contrib = 1.0f; // tracer.scene.photon.init.glsl:49-53
     return r;
+}
+
+// tracer.scene.photon.{init,loop}.glsl:84-99 / :68-83: after a step the photon survives with
+// probability contrib (one draw) and goes on with contribution 1; the Stokes vector is
+// normalised first. Returns the step's result code.
+template <class V>
+THX_DEV int photonRoulette(Lane<V>& L, Ray& ray, int result) {
+    if (result < 0) return result;
+    if constexpr (V::POL) {
+        ray.lin_contrib *= ray.stokes.x;
+        const float s0 = ray.stokes.x;
+        ray.stokes = f4{ray.stokes.x / s0, ray.stokes.y / s0, ray.stokes.z / s0, ray.stokes.w / s0};
+    }
+    if (ray.lin_contrib * thx_exp(ray.log_contrib) <= draw(L)) return RESULT_CODE_RAY_ABSORBED;
+    ray.lin_contrib = 1.0f;
+    ray.log_contrib = 0.0f;
+    return result;
+}
+// RNG dimension at the start of step `step` (1-based): the reference starts run r of the
+// photon tracer at dimension r * rng_per_run (trace.py:2655-2659, Push.dim)
+template <class V>
+THX_DEV void photonRunDim(Lane<V>& L, uint32_t step) {
+    const uint32_t per = L.a->p.photon_steps_per_run;
+    if (step > 1u && per != 0u && (step - 1u) % per == 0u) L.dim = ((step - 1u) / per) * L.a->p.photon_rng_per_run;
 }
 
 // ============================================================================
@@ -1164,7 +1207,10 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
             return false;
         }
     }
+    const bool photon = (A.flags & THX_FLAG_PHOTON) != 0;
     const bool last = step == A.path_length;
+    const bool lastNoScatter = last && !photon; // the photon tracer always scatters (processInteraction(..., last = false))
+    if (photon) photonRunDim(L, step);
     L.cnt.add(ST_STEPS);
 
     int result = RESULT_CODE_SUCCESS;
@@ -1237,7 +1283,7 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
         if (hit.valid) {
             result = processHit(L, ray, hit, allowResponse);
         } else {
-            if (!last) {
+            if (!lastNoScatter) {
                 if constexpr (V::MIS) { // sampleTargetMIS, :234-269
                     float pPP;
                     float u0 = draw(L);
@@ -1265,6 +1311,7 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
         float u1 = draw(L);
         scatterRay(L, ray, ray.medium, u0, u1);
     }
+    if (photon) result = photonRoulette(L, ray, result);
 
     onEvent(L, ray, result, step);
     if (result < 0) return false;

@@ -19,8 +19,8 @@ from . import units as u
 from .hp.pipeline import SourceCodeMixin
 from .hp.queue import IOQueue
 
-__all__ = ["HitItem", "PolarizedHitItem", "TraceConfig", "HitResponse", "EmptyResponse", "HitRecorder", "ValueResponse",
-           "UniformValueResponse", "HistogramHitResponse"]
+__all__ = ["HitItem", "PolarizedHitItem", "HitTimeItem", "HitTimeAndIdItem", "TraceConfig", "HitResponse", "EmptyResponse",
+           "HitRecorder", "StoreTimeHitResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse"]
 
 
 class HitItem(Structure):
@@ -187,6 +187,86 @@ class UniformValueResponse(ValueResponse):
 
     def __init__(self) -> None:
         super().__init__()
+
+
+class HitTimeItem(Structure):
+    """queue item of `StoreTimeHitResponse(storeObjectId=False)` (response.py:626-629)"""
+
+    _fields_ = [("time", c_float)]
+
+
+class HitTimeAndIdItem(Structure):
+    """queue item of `StoreTimeHitResponse` (response.py:632-638)"""
+
+    _fields_ = [("time", c_float), ("objectId", c_int32)]
+
+
+class StoreTimeHitResponse(HitResponse):
+    """
+    Keeps the arrival time (and the detector id) of a hit with the probability the value
+    response assigns to it -- with a photon tracer the stored times are single detected photons
+    (response.py:656-800, shader/response.time.store.glsl). One random number per hit, drawn
+    from the photon's own stream; therefore not available for tracers with target sampling,
+    whose shadow-ray hits are evaluated out of order on this backend. `result(i)` is the queue
+    of the most recent batch run with config `i` (`.count`, `["time"]`, `["objectId"]`).
+    """
+
+    name = "Store Time Hit Response"
+
+    def __init__(self, response: ValueResponse, queue=None, *, retrieve: bool = True, storeObjectId: bool = True,
+                 updateResponse: bool = True) -> None:
+        super().__init__(nRNGSamples=response.nRNGSamples + 1)
+        if not isinstance(response, UniformValueResponse):
+            raise NotImplementedError("The HIP backend implements StoreTimeHitResponse(UniformValueResponse())")
+        if queue is not None:
+            raise NotImplementedError("user supplied queue tensors are not supported; the queue lives in the tracer")
+        self._response = response
+        self._retrieve = retrieve
+        self._storeObjectId = storeObjectId
+        self._updateResponse = updateResponse
+        self._queue: IOQueue | None = None
+        self._capacity = 0
+        self._program = None
+
+    response = property(lambda self: self._response, doc="value response producing the acceptance probability")
+    retrieve = property(lambda self: self._retrieve)
+    storeObjectId = property(lambda self: self._storeObjectId)
+    capacity = property(lambda self: self._capacity, doc="maximum number of hits kept per batch")
+    queue = property(lambda self: self._queue)
+
+    def prepare(self, config: TraceConfig) -> None:
+        self._response.prepare(config)
+        maxHits = config.maxHitsPerThread * config.capacity
+        if self._queue is None:
+            self._capacity = maxHits
+            self._queue = IOQueue(HitTimeAndIdItem if self._storeObjectId else HitTimeItem, mode="retrieve")
+            self._queue.initialize(maxHits)
+        elif self._capacity < maxHits:
+            warn(f"The queue's capacity ({self._capacity}) is less than the max hit count reported by the tracer ({maxHits})")
+
+    def result(self, i: int):
+        if not self._retrieve or self._queue is None:
+            return None
+        return self._queue.view(i)
+
+    def _bindParams(self, program, i: int) -> None:
+        if self._queue is None:
+            raise RuntimeError("Hit response has not been prepared")
+        super()._bindParams(program, i)
+        self._program = program
+
+    def update(self, i: int) -> None:
+        super().update(i)
+        if self._updateResponse:
+            self._response.update(i)
+
+    def run(self, i: int):
+        def retrieve() -> None:
+            if self._program is None:
+                raise RuntimeError("StoreTimeHitResponse is not bound to a tracer")
+            self._program.read_hits(self._queue.buffer(i), clear=True)
+
+        return [retrieve] if self._retrieve else []
 
 
 class HistogramHitResponse(HitResponse):

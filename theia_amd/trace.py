@@ -26,13 +26,13 @@ from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .light import (ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
                     WavelengthSource)
 from .random import RNG, PhiloxRNG
-from .response import EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, TraceConfig
+from .response import EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, StoreTimeHitResponse, TraceConfig
 from .scene import RectBBox, Scene
 from .target import InnerSphereTarget, SphereTarget, SphereTargetGuide, Target, TargetGuide
 
 __all__ = [
     "EmptyEventCallback", "EventResultCode", "EventStatisticCallback", "SceneForwardTracer", "Tracer",
-    "TraceEventCallback", "TrackRecordCallback", "VolumeForwardTracer",
+    "ScenePhotonTracer", "TraceEventCallback", "TrackRecordCallback", "VolumeForwardTracer",
 ]
 
 
@@ -400,6 +400,8 @@ class Tracer(PipelineStage):
         """(n_bins, capacity, response_kind, hit_capacity, hit_polarized) of the TracerSpec"""
         if isinstance(response, HitRecorder):
             return (1, self.capacity, capi.RESPONSE_RECORD, response.capacity, response.polarized)
+        if isinstance(response, StoreTimeHitResponse):  # hit_polarized carries storeObjectId for this kind
+            return (1, self.capacity, capi.RESPONSE_STORE_TIME, response.capacity, response.storeObjectId)
         if isinstance(response, EmptyResponse):  # response.empty.glsl: hits are dropped (a one-bin histogram nobody reads)
             return (1, self.capacity, capi.RESPONSE_HISTOGRAM, 0, False)
         return (response.nBins, self.capacity, capi.RESPONSE_HISTOGRAM, 0, False)
@@ -420,8 +422,9 @@ class Tracer(PipelineStage):
             raise _unsupported("light source", source, "SphericalLightSource, PencilLightSource")
         if not isinstance(wavelength, (ConstWavelengthSource, UniformWavelengthSource)):
             raise _unsupported("wavelength source", wavelength, "ConstWavelengthSource, UniformWavelengthSource")
-        if not isinstance(response, (HistogramHitResponse, HitRecorder, EmptyResponse)):
-            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder, EmptyResponse")
+        if not isinstance(response, (HistogramHitResponse, HitRecorder, EmptyResponse, StoreTimeHitResponse)):
+            raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder, "
+                               "StoreTimeHitResponse(UniformValueResponse()), EmptyResponse")
         if not isinstance(rng, PhiloxRNG):
             raise _unsupported("random number generator", rng, "PhiloxRNG")
         if not isinstance(callback, (EmptyEventCallback, EventStatisticCallback, TrackRecordCallback)):
@@ -575,6 +578,9 @@ class SceneForwardTracer(Tracer):
         self._checkComponents(source, wavelengthSource, response, rng, callback)
         if targetGuide is not None and not isinstance(targetGuide, SphereTargetGuide):
             raise _unsupported("target guide", targetGuide, "SphereTargetGuide, None")
+        if targetGuide is not None and response.nRNGSamples > 0:
+            raise NotImplementedError("responses that draw random numbers (StoreTimeHitResponse) are not available together "
+                                      "with a target guide on the HIP backend")
         maxHits = maxPathLength - 1
         rngStride = 4
         if targetGuide is not None:
@@ -650,3 +656,51 @@ class SceneForwardTracer(Tracer):
         self.callback.bindParams(self._program, i)
         self.response.bindParams(self._program, i)
         return [lambda: self._program.run(i, self._assemble(i))]
+
+
+class ScenePhotonTracer(SceneForwardTracer):
+    """
+    Path tracer simulating individual photons: a path carries one photon, produces at most one
+    hit and is absorbed at random according to the media's absorption (survival roulette after
+    every step); the hit's contribution is its survival chance. Parameters and stage parameters
+    as in the reference (trace.py:2370-2665): `batchSize, source, wavelengthSource, response, rng,
+    scene, *, capacity=None, callback, targetId=-1, sourceMedium=None, maxTime=1 ms,
+    nScatteringPerRun=10, nRuns=10, polarized, disableTransmission, disableVolumeBorder,
+    useRefractedHitDir, blockSize=128`.
+
+    The reference runs `nRuns` dispatches of `nScatteringPerRun` steps with a photon queue in
+    between to re-pack the surviving photons; the staged kernel of this backend re-packs photons
+    after every stage anyway, so one launch traces all `nRuns * nScatteringPerRun` steps. What the
+    runs determine is kept: run r draws its random numbers from dimension `r * nRNGPerRun` on.
+    """
+
+    name = "Scene Photon Tracer"
+
+    def __init__(self, batchSize: int, source: LightSource, wavelengthSource: WavelengthSource, response: HitResponse,
+                 rng: RNG, scene: Scene, *, capacity: int | None = None, callback: TraceEventCallback | None = None,
+                 targetId: int = -1, sourceMedium: int | None = None, maxTime: float = 1.0 * u.ms,
+                 nScatteringPerRun: int = 10, nRuns: int = 10, polarized: bool = False, disableTransmission: bool = False,
+                 disableVolumeBorder: bool = False, useRefractedHitDir: bool = False, blockSize: int = 128) -> None:
+        self._nRuns, self._nScatteringPerRun = nRuns, nScatteringPerRun
+        self._nRNGPerRun = 5 * nScatteringPerRun + response.nRNGSamples
+        super().__init__(batchSize, source, wavelengthSource, response, rng, scene, capacity=capacity, callback=callback,
+                         maxPathLength=nRuns * nScatteringPerRun, targetId=targetId, targetGuide=None,
+                         scatterCoefficient=float("NaN"), sourceMedium=sourceMedium, maxTime=maxTime, polarized=polarized,
+                         disableDirectLighting=False, disableTransmission=disableTransmission,
+                         disableVolumeBorder=disableVolumeBorder, useRefractedHitDir=useRefractedHitDir, blockSize=blockSize)
+        # trace.py:2487-2501: one hit per photon, 5 draws per step
+        self._maxHitsPerThread = 1
+        self._nRNGSamples = source.nRNGForward + wavelengthSource.nRNGSamples + 5 * nRuns * nScatteringPerRun + response.nRNGSamples
+        response.prepare(self._getTraceConfig())
+        spec = self._program._spec
+        spec.flags |= capi.FLAG_PHOTON
+        self._program = _Program(spec, scene)
+
+    nRuns = property(lambda self: self._nRuns, doc="number of runs; nRuns * nScatteringPerRun steps are simulated")
+    nScatteringPerRun = property(lambda self: self._nScatteringPerRun, doc="scatter events per run")
+
+    def _assemble(self, i: int) -> capi.RunParams:
+        P = super()._assemble(i)
+        P.photon_steps_per_run = self._nScatteringPerRun
+        P.photon_rng_per_run = self._nRNGPerRun
+        return P
