@@ -1009,9 +1009,69 @@ static int vol_trace(Ctx* x, const orc_volume_trace_params* tp, const orc_target
     return RESULT_CODE_RAY_SCATTERED;
 }
 
+/* VolumePhotonTracer: tracer.volume.photon.common.glsl:37-121, tracer.volume.photon.init.glsl:46-62
+ * (all runs in one loop; run r starts at RNG dimension r * rng_per_run; events carry the running
+ * step index where the reference restarts it per run) */
+static void vol_photonMain(Ctx* x, const orc_volume_trace_params* tp, const orc_target_params* tg,
+                           uint32_t local_idx) {
+    const orc_common* c = x->c;
+    uint32_t dim = 0;
+    uint32_t idx = c->photon_offset + local_idx;
+    x->cur_idx = idx; x->cur_dim = &dim;
+    Ray ray = sampleRay(x, x->global_medium, idx, &dim);
+    onEvent(x, &ray, RESULT_CODE_RAY_CREATED, local_idx, 0, dim);
+    vec3 center = V3(tg->position[0], tg->position[1], tg->position[2]);
+    if (g_target_inner ? (v_distance(ray.position, center) >= tg->radius) : (v_distance(ray.position, center) <= tg->radius)) {
+        onEvent(x, &ray, ERROR_CODE_TRACE_ABORT, local_idx, 0, dim);
+        return;
+    }
+    const uint32_t perRun = g_photon_steps_per_run;
+    for (uint32_t i = 1; i <= c->path_length; ++i) {
+        if (i > 1 && (i - 1) % perRun == 0) dim = ((i - 1) / perRun) * g_photon_rng_per_run;
+        x->cnt.stats[ST_STEPS]++;
+        float u = rnd(x, idx, &dim);
+        float dist = sampleScatterLength(&ray, &x->prop, u);
+        TargetSample hit = intersectTarget(tg, ray.position, ray.direction);
+        int hitValid = hit.valid && (hit.dist <= dist);
+        dist = fminf(hit.dist, dist);
+        int result = propagateRay(&ray, dist, &x->prop);
+        updateRayIS(&ray, dist, &x->prop, hitValid);
+        if (result >= 0) {
+            if (hitValid) {
+                alignRayToHit(x, &ray, hit.normal);
+                HitItem item = createHit(x, &ray, hit.objPosition, hit.objNormal, tp->objectId, diag3(hit.invRad));
+                if (item.contrib > 0.0f) response(x, &item);
+                result = RESULT_CODE_RAY_ABSORBED;
+            } else {
+                result = RESULT_CODE_RAY_SCATTERED;
+            }
+        }
+        float u0 = rnd(x, idx, &dim);
+        float u1 = rnd(x, idx, &dim);
+        scatterRay(x, &ray, u0, u1);
+        if (result >= 0) {
+            if (x->polarized) {
+                ray.lin_contrib *= ray.stokes.x;
+                float s0 = ray.stokes.x;
+                ray.stokes.x /= s0; ray.stokes.y /= s0; ray.stokes.z /= s0; ray.stokes.w /= s0;
+            }
+            if (ray.lin_contrib * expf(ray.log_contrib) <= rnd(x, idx, &dim)) {
+                result = RESULT_CODE_RAY_ABSORBED;
+            } else {
+                ray.lin_contrib = 1.0f;
+                ray.log_contrib = 0.0f;
+            }
+        }
+        onEvent(x, &ray, result, local_idx, i, dim);
+        if (result < 0) return;
+    }
+    onEvent(x, &ray, RESULT_CODE_MAX_ITER, local_idx, c->path_length + 1, dim);
+}
+
 /* tracer.volume.forward.glsl:231-276 */
 static void vol_traceMain(Ctx* x, const orc_volume_trace_params* tp, const orc_target_params* tg,
                           uint32_t local_idx) {
+    if (g_photon_steps_per_run) { vol_photonMain(x, tp, tg, local_idx); return; }
     const orc_common* c = x->c;
     uint32_t dim = 0;
     uint32_t idx = c->photon_offset + local_idx;

@@ -434,3 +434,74 @@ def test_ScenePhotonTracer(mu_a: float, mu_s: float, g: float, polarized: bool):
     else:
         # no absorption means we should recover all photons
         assert hits.count == int(budget)
+
+
+@pytest.mark.parametrize(
+    "mu_a,mu_s,g,polarized",
+    [
+        (0.0, 0.05, 0.0, False),
+        (0.05, 0.05, 0.0, False),
+        (0.05, 0.01, -0.9, False),
+        (0.05, 0.01, 0.9, False),
+        # FIXME (reference): Polarization seems broken for now
+        # (0.0, 0.05, 0.0, True),
+        (0.05, 0.01, -0.9, True),
+    ],
+)
+def test_VolumePhotonTracer(mu_a: float, mu_s: float, g: float, polarized: bool):
+    """/root/reference/tests/test_trace_energy.py:1467-1590: photons a VolumePhotonTracer detects inside an
+    InnerSphereTarget against the light-curve integral of the VolumeForwardTracer (target sampling on)"""
+    position = (12.0, 15.0, 0.2) * u.m
+    radius = 60.0 * u.m
+    budget = 1e6
+    t0 = 10.0 * u.ns
+    lam = 400.0 * u.nm
+    max_length = 80
+    maxTime = float("inf")
+    scatter_coef = 0.05
+    n_runs = 40
+    n_scatterPerRun = 5
+    batch_size = 1 * 1024 * 1024
+    n_batches = 20
+
+    model = MediumModel(mu_a, mu_s, g)
+    medium = model.createMedium()
+    store = theia.material.MaterialStore([], media=[medium])
+
+    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
+    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
+    light = theia.light.SphericalLightSource(position=position, timeRange=(t0, t0), budget=budget)
+    target = InnerSphereTarget(position=position, radius=radius)
+    # use volume tracer as known truth source for estimating the amount of hits
+    hist_response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), binSize=50.0 * u.ns, nBins=400)
+    hist_tracer = theia.trace.VolumeForwardTracer(batch_size, light, target, photons, hist_response, rng,
+                                                  medium=store.media["homogenous"], maxTime=maxTime, nScattering=max_length,
+                                                  scatterCoefficient=scatter_coef, polarized=polarized)
+    rng.autoAdvance = hist_tracer.nRNGSamples
+    hists = []
+    process = lambda c, b, _: hists.append(hist_response.result(c).copy())
+    hist_pipeline = pl.Pipeline(hist_tracer.collectStages())
+    scheduler = pl.PipelineScheduler(hist_pipeline, processFn=process)
+    scheduler.schedule([{} for i in range(n_batches)])
+    scheduler.wait()
+    scheduler.destroy()
+
+    hist = np.mean(hists, 0)
+    exp_hits = hist.sum()
+
+    response = theia.response.StoreTimeHitResponse(theia.response.UniformValueResponse())
+    stats = theia.trace.EventStatisticCallback()
+    tracer = theia.trace.VolumePhotonTracer(
+        int(budget),  # this way a single batch is enough
+        light, target, photons, response, rng,
+        medium=store.media["homogenous"], nScatteringPerRun=n_scatterPerRun, nRuns=n_runs, maxTime=maxTime,
+        polarized=polarized, callback=stats,
+    )
+    pl.runPipeline(tracer.collectStages())
+    hits = response.result(0)
+    assert hits is not None
+    if mu_a != 0.0:
+        assert np.abs(hits.count - exp_hits) < 5.0 * np.sqrt(exp_hits)
+    else:
+        # no absorption means we should recover all photons
+        assert hits.count == int(budget)

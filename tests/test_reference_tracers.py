@@ -590,6 +590,63 @@ def test_ScenePhotonTracer(backend, polarized):
         assert np.abs(np.abs((polRef_exp * polRef).sum(-1))[mask] - 1.0).max() < 1e-6
 
 
+@pytest.mark.parametrize("polarized", [False, True])
+def test_VolumePhotonTracer(backend, polarized):
+    """/root/reference/tests/test_trace.py:1563-1646"""
+    N = 32 * 256
+    N_RUNS = 5
+    N_SCATTER = 5
+    T0, T1 = 10.0 * u.ns, 20.0 * u.ns
+    T_MAX = float("inf")
+    capacity = 48 * 256
+    objectId = 42
+    light_pos = (-1.0, -7.0, 0.0) * u.m
+    light_budget = 1000.0
+    target_pos, target_radius = (5.0, 2.0, -8.0) * u.m, 4.0 * u.m
+
+    water = WaterTestModel().createMedium()
+    store = theia.material.MaterialStore([], media=[water])
+    d_min = np.sqrt(np.square(np.subtract(light_pos, target_pos)).sum(-1)) - target_radius
+    v_max = np.max(water.group_velocity)
+    t_min = d_min / v_max + T0
+
+    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+    photons = theia.light.UniformWavelengthSource()
+    source = theia.light.SphericalLightSource(position=light_pos, budget=light_budget, timeRange=(T0, T1))
+    target = SphereTarget(position=target_pos, radius=target_radius)
+    recorder = theia.response.HitRecorder(polarized=polarized)
+    stats = theia.trace.EventStatisticCallback()
+    tracer = theia.trace.VolumePhotonTracer(N, source, target, photons, recorder, rng, medium=store.media["water"],
+                                            objectId=objectId, capacity=capacity, nRuns=N_RUNS, nScatteringPerRun=N_SCATTER,
+                                            maxTime=T_MAX, callback=stats, polarized=polarized)
+    pl.runPipeline(tracer.collectStages())
+    hits = recorder.queue.view(0)
+
+    assert hits.count > 0
+    assert hits.count <= N
+    hits = hits[: hits.count]
+    assert stats.created == N
+
+    assert np.allclose(np.square(hits["position"]).sum(-1), 1.0)
+    assert np.allclose(np.square(hits["normal"]).sum(-1), 1.0)
+    assert np.min(hits["time"]) >= t_min
+    assert np.max(hits["time"]) <= T_MAX
+    assert np.allclose(hits["objectId"], objectId)
+
+    if polarized:
+        assert np.abs(hits["stokes"][:, 0] - 1.0).max() < 1e-6
+        assert np.square(hits["stokes"][:, 1:]).sum(-1).max() <= 1.0 + 1e-6
+        assert hits["stokes"][:, 1:].max() <= 1.0
+        assert hits["stokes"][:, 1:].min() >= -1.0
+        polRef = hits["polarizationRef"]
+        assert np.abs(np.square(polRef).sum(-1) - 1.0).max() < 1e-6
+        polRef_exp = np.cross(hits["direction"], hits["normal"])
+        d = np.square(polRef_exp).sum(-1)
+        mask = d > 1e-7
+        polRef_exp /= np.sqrt(d)[:, None]
+        assert np.abs(np.abs((polRef_exp * polRef).sum(-1))[mask] - 1.0).max() < 1e-6
+
+
 def _hits_table(view) -> np.ndarray:
     """one row per hit: time, contrib, wavelength, position, direction, normal[, stokes, polRef]"""
     h = view[: view.count]

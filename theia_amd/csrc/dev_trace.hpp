@@ -628,6 +628,64 @@ THX_DEV bool volStep(Lane<V>& L, Ray& ray, uint32_t& step) {
     return true;
 }
 
+// VolumePhotonTracer (THX_FLAG_PHOTON on the volume kind): tracer.volume.photon.common.glsl:37-78
+// trace() and :80-121 traceLoop(), tracer.volume.photon.init.glsl:46-62. One lane-step = birth
+// (step 0) + one loop iteration: trace, scatter for the next iteration (always, also after a
+// stop code), survival roulette, event. The reference restarts the event index with every
+// run; the running step index is used here (only a TrackRecordCallback could tell).
+template <class V>
+THX_DEV bool volPhotonStep(Lane<V>& L, Ray& ray, uint32_t& step) {
+    const LaunchArgs& A = *L.a;
+    const uint64_t med = (uint64_t)A.p.volume.medium[0] | ((uint64_t)A.p.volume.medium[1] << 32);
+    const thx_propagate_params& prop = A.p.volume.propagation;
+    const bool inner = (A.flags & THX_FLAG_TARGET_INNER) != 0;
+    if (step == 0) {
+        ray = sampleRay(L, med); // contribution 1: survival chance
+        onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
+        const float dTarget = distance(ray.position, ld3(A.p.target.position));
+        if (inner ? (dTarget >= A.p.target.radius) : (dTarget <= A.p.target.radius)) {
+            onEvent(L, ray, ERROR_CODE_TRACE_ABORT, 0);
+            return false;
+        }
+        step = 1;
+        if (A.path_length == 0) {
+            onEvent(L, ray, RESULT_CODE_MAX_ITER, 1);
+            return false;
+        }
+    }
+    photonRunDim(L, step);
+    L.cnt.add(ST_STEPS);
+    // trace()
+    float dist = sampleScatterLength(ray, prop, draw(L));
+    TargetSample hit = intersectTarget(A.p.target, ray.position, ray.direction, inner);
+    const bool hitValid = hit.valid && (hit.dist <= dist);
+    dist = fminf(hit.dist, dist);
+    int result = propagateRay(ray, dist, prop);
+    updateRayIS(ray, dist, prop, hitValid);
+    if (result >= 0) {
+        if (hitValid) {
+            alignRayToHit<V>(ray, hit.normal);
+            respond(L, ray, targetFrame(A.p, hit));
+            result = RESULT_CODE_RAY_ABSORBED; // so that the photon is not detected twice
+        } else {
+            result = RESULT_CODE_RAY_SCATTERED;
+        }
+    }
+    // scatter for the next iteration
+    float u0 = draw(L);
+    float u1 = draw(L);
+    scatterRay(L, ray, med, u0, u1);
+    result = photonRoulette(L, ray, result);
+    onEvent(L, ray, result, step);
+    if (result < 0) return false;
+    if (step == A.path_length) {
+        onEvent(L, ray, RESULT_CODE_MAX_ITER, A.path_length + 1);
+        return false;
+    }
+    step += 1;
+    return true;
+}
+
 // ============================================================================
 // SCENE: BVH walk (replaces the driver's VK_KHR_ray_query) + surface physics
 // ============================================================================

@@ -80,7 +80,7 @@ __global__ void __launch_bounds__(kTraceBlock, THX_WAVES_PER_SIMD) traceKernel(c
         if (__ballot(active) == 0ull) break;
         if (active) {
             if constexpr (KIND == THX_TRACER_SCENE_FORWARD) active = sceneStep(L, ray, step, allowResponse);
-            else active = volStep(L, ray, step);
+            else active = (args.flags & THX_FLAG_PHOTON) ? volPhotonStep(L, ray, step) : volStep(L, ray, step);
         }
     }
 

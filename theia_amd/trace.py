@@ -32,7 +32,7 @@ from .target import InnerSphereTarget, SphereTarget, SphereTargetGuide, Target, 
 
 __all__ = [
     "EmptyEventCallback", "EventResultCode", "EventStatisticCallback", "SceneForwardTracer", "Tracer",
-    "ScenePhotonTracer", "TraceEventCallback", "TrackRecordCallback", "VolumeForwardTracer",
+    "ScenePhotonTracer", "TraceEventCallback", "TrackRecordCallback", "VolumeForwardTracer", "VolumePhotonTracer",
 ]
 
 
@@ -698,6 +698,49 @@ class ScenePhotonTracer(SceneForwardTracer):
 
     nRuns = property(lambda self: self._nRuns, doc="number of runs; nRuns * nScatteringPerRun steps are simulated")
     nScatteringPerRun = property(lambda self: self._nScatteringPerRun, doc="scatter events per run")
+
+    def _assemble(self, i: int) -> capi.RunParams:
+        P = super()._assemble(i)
+        P.photon_steps_per_run = self._nScatteringPerRun
+        P.photon_rng_per_run = self._nRNGPerRun
+        return P
+
+
+class VolumePhotonTracer(VolumeForwardTracer):
+    """
+    Photon tracer in a homogeneous medium with an analytic target: a path carries one photon,
+    is absorbed at random (survival roulette after every step) and produces at most one hit whose
+    contribution is its survival chance. Parameters as in the reference (trace.py:2668-2959):
+    `batchSize, source, target, wavelengthSource, response, rng, *, medium, objectId=0, capacity=None,
+    callback, traceBBox, maxTime=1000 ns, nScatteringPerRun=10, nRuns=10, polarized, blockSize=128`.
+    One launch traces all `nRuns * nScatteringPerRun` steps (see `ScenePhotonTracer`).
+    """
+
+    name = "Volume Photon Tracer"
+
+    def __init__(self, batchSize: int, source: LightSource, target: Target, wavelengthSource: WavelengthSource,
+                 response: HitResponse, rng: RNG, *, medium: int, objectId: int = 0, capacity: int | None = None,
+                 callback: TraceEventCallback | None = None, traceBBox: RectBBox | None = None,
+                 maxTime: float = 1000.0 * u.ns, nScatteringPerRun: int = 10, nRuns: int = 10, polarized: bool = False,
+                 blockSize: int = 128, code: bytes | None = None) -> None:
+        self._nRuns, self._nScatteringPerRun = nRuns, nScatteringPerRun
+        self._nRNGPerRun = 4 * nScatteringPerRun + response.nRNGSamples
+        super().__init__(batchSize, source, target, wavelengthSource, response, rng, medium=medium, objectId=objectId,
+                         capacity=capacity, callback=callback, nScattering=nRuns * nScatteringPerRun,
+                         scatterCoefficient=float("NaN"), traceBBox=traceBBox, maxTime=maxTime, polarized=polarized,
+                         disableDirectLighting=True, disableTargetSampling=True, blockSize=blockSize, code=code)
+        # trace.py:2783-2797: one hit per photon, 4 draws per step
+        self._maxHitsPerThread = 1
+        self._nRNGSamples = source.nRNGForward + wavelengthSource.nRNGSamples + 4 * nRuns * nScatteringPerRun + response.nRNGSamples
+        response.prepare(self._getTraceConfig())
+        spec = self._program._spec
+        spec.flags |= capi.FLAG_PHOTON
+        spec.path_length = nRuns * nScatteringPerRun
+        self._program = _Program(spec, None)
+
+    nRuns = property(lambda self: self._nRuns, doc="number of runs; nRuns * nScatteringPerRun steps are simulated")
+    nScatteringPerRun = property(lambda self: self._nScatteringPerRun, doc="scatter events per run")
+    maxPathLength = property(lambda self: self._nRuns * self._nScatteringPerRun, doc="maximum number of events per photon")
 
     def _assemble(self, i: int) -> capi.RunParams:
         P = super()._assemble(i)
