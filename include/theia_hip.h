@@ -106,10 +106,14 @@ typedef struct {
     thx_propagate_params propagation;
 } thx_scene_trace_params;
 
-/* src/theia/response.py:1256-1257; shader/response.histogram.glsl:11-14 */
+/* src/theia/response.py:1256-1257; shader/response.histogram.glsl:11-14.
+ * THX_FLAG_KERNEL_HISTOGRAM: KernelHistogramHitResponse, response.py:1495-1501,
+ * shader/response.histogram.kernel.glsl:11-19 (Gaussian kernel bandwidth and support) */
 typedef struct {
     float t0;
     float binSize;
+    float kernelBandwidth;
+    float kernelSupport;
 } thx_response_params;
 
 /* everything one batch needs (one `stage.update(i)` round of the reference's
@@ -147,6 +151,7 @@ enum {
     THX_FLAG_STATISTICS            = 1u << 8, /* EventStatisticCallback + traversal counters */
     THX_FLAG_TRACK                 = 1u << 9, /* per-event state dump (parity probe, TrackRecordCallback) */
     THX_FLAG_LIGHT_PENCIL          = 1u << 10, /* PencilLightSource, else SphericalLightSource */
+    THX_FLAG_KERNEL_HISTOGRAM      = 1u << 13, /* histogram response smears every hit with a Gaussian kernel */
     THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
                                                   absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;

@@ -25,6 +25,7 @@ FLAG_HIT_USE_TRANSMITTED = 1 << 5
 FLAG_WAVELENGTH_UNIFORM = 1 << 6
 FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_TARGET_INNER = 1 << 11
+FLAG_KERNEL_HISTOGRAM = 1 << 13
 FLAG_BRUTE_FORCE = 1 << 7
 TRACK_WORDS = 12
 N_STATS = 20
@@ -68,7 +69,7 @@ class SceneTraceParams(_P):
 
 
 class ResponseParams(_P):
-    _fields_ = [("t0", C.c_float), ("binSize", C.c_float)]
+    _fields_ = [("t0", C.c_float), ("binSize", C.c_float), ("kernelBandwidth", C.c_float), ("kernelSupport", C.c_float)]
 
 
 class Common(C.Structure):

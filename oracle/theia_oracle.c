@@ -654,6 +654,29 @@ static void recordHit(Ctx* x, const HitItem* it) {
 static void response(Ctx* x, const HitItem* item) {
     if (g_time_queue) { storeTime(x, item); return; }
     if (g_hit_queue) { recordHit(x, item); return; }
+    if (x->c->flags & ORC_FLAG_KERNEL_HISTOGRAM) { /* response.histogram.kernel.glsl:62-99 */
+        const orc_response_params* rp = &x->c->response;
+        x->cnt.stats[ST_RESPONSES]++;
+        float t = item->time - rp->t0;
+        int firstBin = (int)floorf((t - rp->kernelSupport) / rp->binSize);
+        int lastBin = (int)ceilf((t + rp->kernelSupport) / rp->binSize);
+        if (firstBin < 0) firstBin = 0;
+        if (lastBin > (int)x->c->n_bins) lastBin = (int)x->c->n_bins;
+        lastBin -= 1;
+        t = (float)firstBin * rp->binSize + rp->t0 - item->time;
+        const float h = 1.0f / rp->kernelBandwidth;
+#define KCDF(v) (0.5f + 0.5f * tanhf(7.779374467827938f * (v) - 55.5f * atanf(0.1257926109373887f * (v))))
+        float prev_cdf = KCDF(t * h);
+        for (int i = firstBin; i <= lastBin; ++i) {
+            t += rp->binSize;
+            float cdf = KCDF(t * h);
+            float w = cdf - prev_cdf;
+            prev_cdf = cdf;
+            x->hist[i] += w * item->contrib;
+        }
+#undef KCDF
+        return;
+    }
     float value = item->contrib;
     float f = floorf((item->time - x->c->response.t0) / x->c->response.binSize);
     x->cnt.stats[ST_RESPONSES]++;

@@ -110,7 +110,7 @@ class OracleBackend:
         t = self._tracers[tracer]
         spec = t.spec
         c = orc.Common()
-        flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER))
+        flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER | capi.FLAG_KERNEL_HISTOGRAM))
         photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE

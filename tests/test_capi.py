@@ -35,7 +35,8 @@ def test_parameter_block_layouts():
     assert C.sizeof(capi.PropagateParams) == 36
     assert C.sizeof(capi.VolumeTraceParams) == 48 and C.sizeof(capi.SceneTraceParams) == 48
     assert capi.SceneTraceParams.sceneMedium.offset == 4  # uvec2 right behind the int
-    assert C.sizeof(capi.ResponseParams) == 8 and C.sizeof(capi.DispatchParams) == 16
+    # response block: histogram UBO (8 B) + the kernel histogram's bandwidth and support
+    assert C.sizeof(capi.ResponseParams) == 16 and capi.ResponseParams.kernelBandwidth.offset == 8 and C.sizeof(capi.DispatchParams) == 16
     # the oracle uses identical layouts
     for a, b in [(capi.PhiloxParams, orc.PhiloxParams), (capi.LightParams, orc.LightParams), (capi.TargetParams, orc.TargetParams),
                  (capi.GuideParams, orc.GuideParams), (capi.VolumeTraceParams, orc.VolumeTraceParams),

@@ -647,6 +647,118 @@ def test_VolumePhotonTracer(backend, polarized):
         assert np.abs(np.abs((polRef_exp * polRef).sum(-1))[mask] - 1.0).max() < 1e-6
 
 
+def test_kernelHistogramResponse(backend):
+    """KernelHistogramHitResponse against the binned Gaussian KDE of the same hits, as in
+    /root/reference/tests/test_response.py:129-171 (which replays synthetic hits through HitReplay;
+    here the hits are those the tracer itself records in a second run with the same random numbers)."""
+    from scipy import stats as sps
+
+    N = 64 * 1024
+    N_BINS, BIN_SIZE, T0 = 200, 1.2 * u.ns, 20.0 * u.ns
+    BANDWIDTH, SUPPORT, NORM = 10.0 * u.ns, 50.0 * u.ns, 5e-4
+
+    water = WaterTestModel().createMedium()
+    store = theia.material.MaterialStore([], media=[water])
+
+    def run(response):
+        rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
+        photons = theia.light.UniformWavelengthSource()
+        source = theia.light.SphericalLightSource(position=(-1.0, -7.0, 0.0), budget=1000.0, timeRange=(10.0, 20.0))
+        target = SphereTarget(position=(5.0, 2.0, -8.0), radius=4.0)
+        tracer = theia.trace.VolumeForwardTracer(N, source, target, photons, response, rng, medium=store.media["water"],
+                                                 nScattering=6, maxTime=1.0 * u.us)
+        pl.runPipeline(tracer.collectStages())
+
+    response = theia.response.KernelHistogramHitResponse(
+        theia.response.UniformValueResponse(), nBins=N_BINS, t0=T0, binSize=BIN_SIZE, kernelBandwidth=BANDWIDTH,
+        kernelSupport=SUPPORT, normalization=NORM)
+    run(response)
+    result = response.result(0)
+    recorder = theia.response.HitRecorder()
+    run(recorder)
+    hits = recorder.queue.view(0)
+    hits = hits[: hits.count]
+    assert hits.count > 1000
+
+    x = np.arange(N_BINS + 1) * BIN_SIZE + T0
+    cdf = sps.norm.cdf(x[None, :], loc=hits["time"][:, None].astype(np.float64), scale=BANDWIDTH)
+    exp_result = np.diff((hits["contrib"][:, None].astype(np.float64) * cdf).sum(0)) * NORM
+    assert exp_result.max() > 0
+    # the shader's tanh/atan CDF is good to ~1e-4 (Vazquez-Leal et al. 2011); reference tolerance 6e-4 at a peak of ~40
+    assert np.abs(result - exp_result).max() < 1e-3 * exp_result.max()
+
+
+def test_ConvergeHistogramTask(backend):
+    """/root/reference/tests/test_task.py:18-117"""
+    import theia.task
+    from theia.light import SphericalLightSource, UniformWavelengthSource
+    from theia.material import MaterialStore
+    from theia.random import PhiloxRNG
+    from theia.response import HistogramHitResponse, UniformValueResponse
+    from theia.trace import VolumeForwardTracer
+
+    target_pos = (0.0, 0.0, 0.0) * u.m
+    radius = 5.0 * u.m
+    light_pos = (-6.0, 0.0, 0.0) * u.m
+    budget = 1e5
+    lambda_range = (400.0, 700.0) * u.nm
+    light_t0 = 20.0 * u.ns
+    batch_size = 256 * 1024 if backend == "hip" else 16 * 1024  # the oracle runs a sixteenth of the reference's batch
+    max_length = 10
+    scatter_coef = 0.01
+    maxTime = 600.0 * u.ns
+    bin_t0 = 0.0
+    bin_size = 5.0 * u.ns
+    n_bins = 100
+    initBatches = 10
+    newBatches = 5
+    max_batches = 400
+    atol = 0.1
+    rtol = 5e-4 if backend == "hip" else 2e-3
+
+    medium = WaterTestModel().createMedium()
+    store = MaterialStore([], media=[medium])
+    rng = PhiloxRNG(key=0xC0FFEE)
+    photons = UniformWavelengthSource(lambdaRange=lambda_range)
+    light = SphericalLightSource()  # we will pass light params through the task
+    target = SphereTarget(position=target_pos, radius=radius)
+    response = HistogramHitResponse(UniformValueResponse(), nBins=n_bins, binSize=bin_size, t0=bin_t0)
+    tracer = VolumeForwardTracer(batch_size, light, target, photons, response, rng, medium=store.media["water"],
+                                 maxTime=maxTime, nScattering=max_length, scatterCoefficient=scatter_coef)
+    rng.autoAdvance = tracer.nRNGSamples
+    pipeline = pl.Pipeline(tracer.collectStages())
+    scheduler = pl.DynamicTaskScheduler(pipeline)
+
+    callbackCalled = False
+
+    def callback(task: theia.task.ConvergeHistogramTask):
+        nonlocal callbackCalled
+        callbackCalled = True
+
+    params = {
+        "lightSource__position": light_pos,
+        "lightSource__budget": budget,
+        "lightSource__timeRange": (light_t0, light_t0),
+    }
+    task = theia.task.ConvergeHistogramTask(response, params, initialBatchCount=initBatches, extraBatchCount=newBatches,
+                                            maxBatchCount=max_batches, atol=atol, rtol=rtol, finishedCallback=callback)
+    scheduler.scheduleTask(task)
+    scheduler.waitAll()
+    scheduler.destroy()
+
+    assert task.converged
+    assert callbackCalled
+    assert task.totalBatches <= max_batches
+    assert task.totalBatches > initBatches  # to ensure we test the reissuing of batches
+    error_thres = budget * rtol + atol  # upper limit
+    assert task.error > 0.0 and task.error <= error_thres
+    # to ensure we didn't "converge" to zero -> compare with the last batch
+    lastBatch = response.result(0)
+    assert lastBatch is not None
+    # (a single oracle batch is 16x smaller, its bins fluctuate 4x more)
+    assert np.abs(task.result - lastBatch).max() < (1e-3 if backend == "hip" else 1e-2) * budget
+
+
 def _hits_table(view) -> np.ndarray:
     """one row per hit: time, contrib, wavelength, position, direction, normal[, stokes, polRef]"""
     h = view[: view.count]

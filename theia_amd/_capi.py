@@ -20,7 +20,7 @@ __all__ = [
     "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
     "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
-    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "EXPORTED_SYMBOLS",
+    "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "FLAG_KERNEL_HISTOGRAM", "EXPORTED_SYMBOLS",
 ]
 
 TRACER_VOLUME_FORWARD = 0
@@ -40,6 +40,7 @@ FLAG_TRACK = 1 << 9
 FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_TARGET_INNER = 1 << 11
 FLAG_PHOTON = 1 << 12
+FLAG_KERNEL_HISTOGRAM = 1 << 13
 N_STATS = 20
 TRACK_WORDS = 12
 STAT_NAMES = (
@@ -99,7 +100,7 @@ class SceneTraceParams(_Packed):
 
 
 class ResponseParams(_Packed):
-    _fields_ = [("t0", c_float), ("binSize", c_float)]
+    _fields_ = [("t0", c_float), ("binSize", c_float), ("kernelBandwidth", c_float), ("kernelSupport", c_float)]
 
 
 class RunParams(_Packed):

@@ -137,6 +137,29 @@ struct HitFrame {
 // LDS float atomic (ds_add_f32), the partial histogram is flushed per workgroup.
 template <class V>
 THX_DEV void response(Lane<V>& L, const HitItem& item) {
+    if (L.a->flags & THX_FLAG_KERNEL_HISTOGRAM) {
+        // response.histogram.kernel.glsl:62-99: the hit is smeared over the bins within the
+        // kernel support; Gaussian CDF by the tanh/atan approximation of Vazquez-Leal et al.
+        const thx_response_params& rp = L.a->p.response;
+        L.cnt.add(ST_RESPONSES);
+        auto kernelCdf = [](float x) { return 0.5f + 0.5f * tanhf(7.779374467827938f * x - 55.5f * atanf(0.1257926109373887f * x)); };
+        float t = item.time - rp.t0;
+        int firstBin = (int)floorf((t - rp.kernelSupport) / rp.binSize);
+        int lastBin = (int)ceilf((t + rp.kernelSupport) / rp.binSize);
+        firstBin = max(firstBin, 0);
+        lastBin = min(lastBin, (int)L.a->n_bins) - 1;
+        t = (float)firstBin * rp.binSize + rp.t0 - item.time;
+        const float h = 1.0f / rp.kernelBandwidth;
+        float prev_cdf = kernelCdf(t * h);
+        for (int i = firstBin; i <= lastBin; ++i) {
+            t += rp.binSize;
+            float cdf = kernelCdf(t * h);
+            float w = cdf - prev_cdf;
+            prev_cdf = cdf;
+            atomicAdd(&ldsHist()[i], w * item.contrib);
+        }
+        return;
+    }
     float f = floorf((item.time - L.a->p.response.t0) / L.a->p.response.binSize);
     L.cnt.add(ST_RESPONSES);
     // `uint bin = int(floor(..))`: negative values wrap and fail bin < N_BINS

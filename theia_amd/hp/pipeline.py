@@ -20,7 +20,8 @@ from ctypes import Array, Structure
 from queue import Queue
 from typing import Any, Callable, Iterable
 
-__all__ = ["Command", "PipelineStage", "SourceCodeMixin", "Pipeline", "PipelineScheduler", "runPipeline"]
+__all__ = ["Command", "PipelineStage", "SourceCodeMixin", "Pipeline", "PipelineScheduler", "runPipeline", "DynamicTask",
+           "DynamicTaskScheduler"]
 
 Command = Callable[[], None]
 
@@ -296,4 +297,130 @@ class PipelineScheduler:
             finally:
                 with self._cv:
                     self._finished += 1
+                    self._cv.notify_all()
+
+
+class DynamicTask:
+    """
+    A task that decides, batch by batch, how many more batches of a pipeline it needs
+    (hephaistos.pipeline.DynamicTask as theia's `ConvergeHistogramTask` uses it, task.py:22-196):
+    `parameters` are applied to the pipeline for its batches, `processBatch(config)` is called
+    after every batch and returns the number of batches to issue in addition, `onTaskFinished()`
+    once no batch is left. `batchesRemaining` = issued and not yet processed.
+    """
+
+    def __init__(self, parameters: dict, pipeline: str | None = None, *, initialBatchCount: int = 1) -> None:
+        if initialBatchCount < 1:
+            raise ValueError("initialBatchCount must be at least 1")
+        self._parameters = dict(parameters)
+        self._pipeline = pipeline
+        self._initial = initialBatchCount
+        self._remaining = 0
+        self._finished = False
+
+    @property
+    def parameters(self) -> dict:
+        return self._parameters
+
+    @property
+    def pipeline(self) -> str | None:
+        return self._pipeline
+
+    @property
+    def initialBatchCount(self) -> int:
+        return self._initial
+
+    @property
+    def batchesRemaining(self) -> int:
+        """batches issued for this task that have not been processed yet"""
+        return self._remaining
+
+    @property
+    def isFinished(self) -> bool:
+        return self._finished
+
+    def processBatch(self, config: int) -> int:  # pragma: no cover - interface
+        raise NotImplementedError
+
+    def onTaskFinished(self) -> None:
+        pass
+
+
+class DynamicTaskScheduler:
+    """Runs `DynamicTask`s on one or several pipelines (background thread, configs alternate 0/1):
+    `scheduleTask(task)`, `waitAll()`, `destroy()`."""
+
+    def __init__(self, pipeline, *, queueSize: int = 0) -> None:
+        self._pipelines = pipeline if isinstance(pipeline, dict) else {None: pipeline}
+        self._queue: Queue = Queue(queueSize)
+        self._cv = threading.Condition()
+        self._open = 0  # tasks scheduled and not finished
+        self._error: BaseException | None = None
+        self._alive = True
+        self._thread = threading.Thread(target=self._worker, name="theia-task-scheduler", daemon=True)
+        self._thread.start()
+
+    def scheduleTask(self, task: DynamicTask) -> None:
+        with self._cv:
+            self._open += 1
+        self._queue.put(task)
+
+    def scheduleTasks(self, tasks: Iterable) -> None:
+        for t in tasks:
+            self.scheduleTask(t)
+
+    def waitAll(self) -> None:
+        with self._cv:
+            self._cv.wait_for(lambda: self._open == 0 or self._error is not None)
+        if self._error is not None:
+            err, self._error = self._error, None
+            raise err
+
+    def destroy(self) -> None:
+        if self._alive:
+            self._alive = False
+            self._queue.put(None)
+            self._thread.join(timeout=5.0)
+
+    def __del__(self) -> None:
+        try:
+            self.destroy()
+        except Exception:
+            pass
+
+    def _worker(self) -> None:
+        batch = 0
+        while True:
+            task = self._queue.get()
+            if task is None:
+                return
+            try:
+                name = task.pipeline
+                if name not in self._pipelines:
+                    if name is None and len(self._pipelines) == 1:
+                        name = next(iter(self._pipelines))
+                    else:
+                        raise ValueError(f"There is no pipeline with name {name}")
+                pipe = self._pipelines[name]
+                if task.parameters:
+                    pipe.setParams(**task.parameters)
+                todo = task.initialBatchCount
+                task._remaining = todo
+                while todo > 0:
+                    cfg = batch % 2
+                    pipe.run(cfg)
+                    batch += 1
+                    todo -= 1
+                    task._remaining -= 1
+                    more = int(task.processBatch(cfg) or 0)
+                    if more > 0:
+                        todo += more
+                        task._remaining += more
+                task._finished = True
+                task.onTaskFinished()
+            except BaseException as exc:  # surfaced by waitAll()
+                self._error = exc
+            finally:
+                with self._cv:
+                    self._open -= 1
                     self._cv.notify_all()

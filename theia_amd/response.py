@@ -20,7 +20,8 @@ from .hp.pipeline import SourceCodeMixin
 from .hp.queue import IOQueue
 
 __all__ = ["HitItem", "PolarizedHitItem", "HitTimeItem", "HitTimeAndIdItem", "TraceConfig", "HitResponse", "EmptyResponse",
-           "HitRecorder", "StoreTimeHitResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse"]
+           "HitRecorder", "StoreTimeHitResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse",
+           "KernelHistogramHitResponse"]
 
 
 class HitItem(Structure):
@@ -378,3 +379,25 @@ class HistogramHitResponse(HitResponse):
             self._buffer[i][...] = self._program.read_hist(i)
 
         return [reduce, retrieve] if self._retrieve else [reduce]
+
+
+class KernelHistogramHitResponse(HistogramHitResponse):
+    """
+    Histogram of hit times in which every hit is smeared with a Gaussian kernel (a binned kernel
+    density estimate): `kernelBandwidth` = standard deviation, `kernelSupport` limits the kernel
+    to +- the support. Other parameters as `HistogramHitResponse`. Reference:
+    response.py:1424-1673, shader/response.histogram.kernel.glsl.
+    """
+
+    name = "Kernel Histogram Hit Response"
+
+    class Params(Structure):
+        _fields_ = [("t0", c_float), ("binSize", c_float), ("kernelBandwidth", c_float), ("kernelSupport", c_float)]
+
+    def __init__(self, response: ValueResponse, *, nBins: int = 100, t0: float = 0.0 * u.ns, binSize: float = 1.0 * u.ns,
+                 kernelBandwidth: float = 1.0 * u.ns, kernelSupport: float = 3.0 * u.ns, normalization: float | None = None,
+                 retrieve: bool = True, reduceBlockSize: int = 128, updateResponse: bool = True,
+                 useSharedMemory: bool = True) -> None:
+        super().__init__(response, nBins=nBins, t0=t0, binSize=binSize, normalization=normalization, retrieve=retrieve,
+                         reduceBlockSize=reduceBlockSize, updateResponse=updateResponse, useSharedMemory=useSharedMemory)
+        self.setParams(kernelBandwidth=kernelBandwidth, kernelSupport=kernelSupport)

@@ -26,7 +26,8 @@ from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .light import (ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
                     WavelengthSource)
 from .random import RNG, PhiloxRNG
-from .response import EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, StoreTimeHitResponse, TraceConfig
+from .response import (EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, KernelHistogramHitResponse,
+                       StoreTimeHitResponse, TraceConfig)
 from .scene import RectBBox, Scene
 from .target import InnerSphereTarget, SphereTarget, SphereTargetGuide, Target, TargetGuide
 
@@ -394,6 +395,8 @@ class Tracer(PipelineStage):
         if isinstance(response, HistogramHitResponse):
             rp = response._getParamsBlock("ResponseParams", i)
             P.response.t0, P.response.binSize = rp.t0, rp.binSize
+            if isinstance(response, KernelHistogramHitResponse):
+                P.response.kernelBandwidth, P.response.kernelSupport = rp.kernelBandwidth, rp.kernelSupport
         return P
 
     def _responseSpec(self, response) -> tuple:
@@ -496,6 +499,7 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
         flags |= capi.FLAG_TARGET_INNER if isinstance(target, InnerSphereTarget) else 0
         flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
+        flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response)), None)
 
@@ -616,6 +620,7 @@ class SceneForwardTracer(Tracer):
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
         flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
+        flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response)), scene)
 
