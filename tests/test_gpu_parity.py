@@ -241,3 +241,17 @@ def test_sharding_is_seed_identical(hip_backend):
         sc.tracer.photonOffset = k * (n // 2)
         parts.append(S.run_batches(sc, 1)[0])
     assert np.abs((parts[0] + parts[1]) - h_full).max() <= 1e-5 * h_full.sum()
+
+
+def test_scheduler_watchdog_is_loud(hip_backend, monkeypatch):
+    """a tripped scheduler watchdog (forced through the THX_TEST_ABORT hook) must not return a
+    plausible partial light curve: the kernel poisons its slabs, reading the histogram fails"""
+    from theia_amd._capi import ThxError
+
+    monkeypatch.setenv("THX_TEST_ABORT", "1")
+    sc = S.config2_sphere(batch=10000)
+    with pytest.raises(ThxError, match="watchdog"):
+        S.run_batches(sc, 1)
+    monkeypatch.delenv("THX_TEST_ABORT")
+    sc = S.config2_sphere(batch=10000)
+    assert np.isfinite(S.run_batches(sc, 1)[0]).all()

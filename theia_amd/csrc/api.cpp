@@ -493,6 +493,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     std::memset(&a, 0, sizeof(a));
     a.p = *params;
     a.flags = t->desc.flags;
+    if (std::getenv("THX_TEST_ABORT")) a.flags |= 1u << 31; // test hook: the staged kernel starts with its abort flag set
     a.path_length = t->desc.path_length;
     a.n_bins = t->desc.n_bins;
     a.track_events = t->trackEvents;
@@ -543,6 +544,10 @@ int thx_tracer_read_hist(thx_tracer* t, uint32_t cfg, float* out, uint32_t n_bin
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemcpy(out, t->out[cfg], sizeof(float) * n_bins, hipMemcpyDeviceToHost));
+    // a workgroup whose scheduler watchdog tripped poisons its slab with NaN (dev_staged.hpp)
+    if (t->staged)
+        for (uint32_t i = 0; i < n_bins; ++i)
+            if (std::isnan(out[i])) return fail(THX_ERR_HIP, "the staged kernel's scheduler watchdog tripped: the light curve is invalid");
     return THX_OK;
 }
 

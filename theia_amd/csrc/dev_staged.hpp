@@ -306,6 +306,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const uint32_t begin = b64 < batch ? (uint32_t)b64 : batch;
     const uint32_t end = (b64 + per) < batch ? (uint32_t)(b64 + per) : batch;
     if (tid < C_NUM) pool.ctr[tid] = tid == (uint32_t)cTail(S_BIRTH) ? P : (tid == C_CURSOR ? begin : 0u);
+    if (tid == 0 && (args.flags & (1u << 31))) pool.ctr[C_ABORT] = 1u; // THX_TEST_ABORT: exercises the watchdog exit
     __syncthreads();
 
     const thx_propagate_params& prop = args.p.scene.propagation;
