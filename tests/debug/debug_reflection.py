@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Event counters of the beam-splitter scene of tests/test_reference_tracers.py::test_tracer_reflection."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hephaistos.pipeline as pl

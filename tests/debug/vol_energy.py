@@ -2,7 +2,7 @@
 """Deviations of the reference's volume energy test (tests/test_reference_energy.py::test_VolumeForwardTracer)
 for every parameter row, on the HIP backend or (argument `oracle`, reduced size) on the oracle."""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, os.path.join(ROOT, "oracle"))
 import numpy as np
 import hephaistos.pipeline as pl
