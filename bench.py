@@ -88,10 +88,16 @@ def main() -> None:
     from theia_amd import _backend, distributed
     from theia_amd.hp.pipeline import Pipeline
 
+    # rehearsal on a box with fewer GPUs than ranks (THX_BENCH_BACKEND=gloo): ranks share devices
+    ndev = max(torch.cuda.device_count(), 1)
+    backend = os.environ.get("THX_BENCH_BACKEND", "nccl")
+    if backend == "nccl" and world > ndev:
+        sys.exit(f"bench.py: {world} ranks need {world} GPUs for RCCL, found {ndev}")
+    local %= ndev
     hip = _backend.HipBackend(local)
     _backend.install(hip)
     torch.cuda.set_device(local)
-    dist = distributed.init_from_env("nccl") if world > 1 else None
+    dist = distributed.init_from_env(backend) if world > 1 else None
     dev = torch.device("cuda", local)
     stream = torch.cuda.current_stream().cuda_stream
 
