@@ -216,3 +216,114 @@ def test_scene_validation(oracle_backend):
     assert np.allclose(inst.bbox.lowerCorner, [-1, 0, 1], atol=1e-2)
     sc = Scene([inst], store, medium=0)
     assert sc.medium == 0 and sc.bbox.diagonal == pytest.approx(np.sqrt(3) * 2000.0)
+
+
+def test_example02_scene_tracing_flow(oracle_backend):
+    """examples/02_scene_tracing.ipynb (cells 3-10, reduced batch): media by name, vacuum source medium,
+    nested glass spheres around the light, detector sphere with a target guide, scheduler"""
+    import hephaistos.pipeline as hpl
+    import theia
+    from theia.light import SphericalLightSource, UniformWavelengthSource
+    from theia.material import BK7Model, HenyeyGreensteinPhaseFunction, Material, MaterialStore, MediumModel, WaterBaseModel
+    from theia.random import PhiloxRNG
+    from theia.response import HistogramHitResponse, UniformValueResponse
+    from theia.scene import MeshStore, Scene, Transform
+    from theia.target import SphereTargetGuide
+    from theia.trace import SceneForwardTracer
+
+    meshStore = MeshStore({"sphere": S.bundled_mesh("sphere")})  # notebook: ../assets/*.stl
+
+    class WaterModel(WaterBaseModel, HenyeyGreensteinPhaseFunction, MediumModel):
+        def __init__(self):
+            WaterBaseModel.__init__(self, temperature=4.0, pressure=10_000, salinity=35.0)
+            HenyeyGreensteinPhaseFunction.__init__(self, 0.9)
+
+    lamMin, lamMax = 400.0 * u.nm, 800.0 * u.nm
+    water = WaterModel().createMedium(lamMin, lamMax, name="water")
+    glass = BK7Model().createMedium(lamMin, lamMax, name="glass")
+    glass_water = Material("glass_water", glass, water, flags=("TR", "T"))
+    air_glass = Material("air_glass", None, "glass", flags="T")
+    det_water = Material("det_water", None, water, flags="BD")
+    matStore = MaterialStore([glass_water, air_glass, det_water])
+
+    light_pos = (3.0, 0.0, 0.0) * u.m
+    det_pos = (0.0, 3.0, 0.0) * u.m
+    outer_sphere = meshStore.createInstance("sphere", "glass_water", Transform.TRS(scale=80.0 * u.cm, translate=light_pos))
+    inner_sphere = meshStore.createInstance("sphere", "air_glass", Transform.TRS(scale=75.0 * u.cm, translate=light_pos))
+    det_sphere = meshStore.createInstance("sphere", "det_water", Transform.TRS(scale=60.0 * u.cm, translate=det_pos), detectorId=1)
+    scene = Scene([outer_sphere, inner_sphere, det_sphere], materials=matStore.material, medium=matStore.media["water"])
+
+    batch_size, n_bins, bin_size = 16 * 1024, 100, 5.0 * u.ns
+    wavelength = UniformWavelengthSource(lambdaRange=(lamMin, lamMax))
+    light = SphericalLightSource(position=light_pos, timeRange=(0.0, 10.0) * u.ns, budget=1.0e5)
+    guide = SphereTargetGuide(position=det_pos, radius=60.0 * u.cm)
+    response = HistogramHitResponse(UniformValueResponse(), nBins=n_bins, binSize=bin_size)
+    rng = PhiloxRNG(key=42)
+    stats = EventStatisticCallback()
+    tracer = SceneForwardTracer(batch_size, light, wavelength, response, rng, scene, maxPathLength=10, sourceMedium=0,
+                                scatterCoefficient=0.05 / u.m, targetId=1, targetGuide=guide, callback=stats)
+    rng.autoAdvance = tracer.nRNGSamples
+
+    hists = []
+    pipeline = hpl.Pipeline(tracer.collectStages())
+    scheduler = hpl.PipelineScheduler(pipeline, processFn=lambda c, b, a: hists.append(response.result(c).copy()))
+    scheduler.schedule([{}] * 4)
+    scheduler.wait()
+    scheduler.destroy()
+    final_hist = np.mean(hists, 0)
+    assert len(hists) == 4 and final_hist.sum() > 0
+    # a few rays are totally reflected inside the glass shell at a surface that only transmits ("T"):
+    # GLSL refract() returns 0 there, the ray turns NaN and is counted as an error, never raised
+    assert stats.created == 4 * batch_size and stats.mismatch == 0 and stats.error < 1e-3 * stats.created
+    # light leaves the air sphere through two glass surfaces, then ~3.2 m of water: nothing before ~12 ns
+    first = np.nonzero(final_hist)[0][0] * bin_size
+    assert 10.0 <= first <= 25.0
+
+
+def test_example03_shared_stages_between_pipelines(oracle_backend):
+    """examples/03_multiple_lightsources.ipynb: two tracers share target, wavelength source, response
+    and RNG; a scheduler feeds two named pipelines. The shared response must return the result of the
+    pipeline that just ran."""
+    import hephaistos.pipeline as hpl
+    import theia
+
+    medium = theia.testing.WaterTestModel().createMedium()
+    store = theia.material.MaterialStore([], media=[medium])
+    rng = theia.random.PhiloxRNG(key=0xABBA)
+    response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), nBins=100, binSize=5.0 * u.ns)
+    target = theia.target.SphereTarget(position=(-1.0, 0.0, 0.0) * u.m, radius=50.0 * u.cm)
+    wavelength = theia.light.ConstWavelengthSource(500.0 * u.nm)
+    sharedStages = [target, wavelength, response, rng]
+    sphereLight = theia.light.SphericalLightSource()
+    pencilLight = theia.light.PencilLightSource()
+    batchSize = 16 * 1024
+    tracerParams = {"nScattering": 10, "medium": store.media["water"]}
+    sphereTracer = theia.trace.VolumeForwardTracer(batchSize, sphereLight, *sharedStages, **tracerParams)
+    pencilTracer = theia.trace.VolumeForwardTracer(batchSize, pencilLight, *sharedStages, **tracerParams)
+    rng.autoAdvance = max(sphereTracer.nRNGSamples, pencilTracer.nRNGSamples)
+    spherePipeline = hpl.Pipeline(sphereTracer.collectStages())
+    pencilPipeline = hpl.Pipeline(pencilTracer.collectStages())
+
+    hists = []
+    scheduler = hpl.PipelineScheduler({"sphere": spherePipeline, "pencil": pencilPipeline},
+                                      processFn=lambda c, b, a: hists.append(response.result(c).copy()))
+    tasks = [
+        ("sphere", {"lightSource__budget": 1e5, "lightSource__timeRange": (0.0, 10.0) * u.ns,
+                    "lightSource__position": (1.0, 0.0, 0.0) * u.m}),
+        ("sphere", {}), ("sphere", {}),
+        ("pencil", {"lightSource__position": (0.0, 1.0, 0.0) * u.m, "lightSource__direction": (-0.8, -0.36, -0.24),
+                    "lightSource__budget": 5e6, "lightSource__timeRange": (8.0, 8.5) * u.ns}),
+        ("pencil", {}), ("pencil", {}),
+    ]
+    scheduler.schedule(tasks)
+    scheduler.wait()
+    scheduler.destroy()
+    sphereSignal = np.mean(hists[:3], 0)
+    pencilSignal = np.mean(hists[3:], 0)
+    assert sphereSignal.sum() > 0 and pencilSignal.sum() > 0
+    # the pencil beam starts at 8 ns, 1.35 m from the target: nothing in the first bin (0..5 ns);
+    # the spherical source (t in 0..10 ns, 1.5 m away) already contributes to bin 1 (5..10 ns)
+    assert pencilSignal[0] == 0 and pencilSignal[1] == 0
+    assert sphereSignal[1] > 0
+    # different sources, different curves: the shared response returned each pipeline's own result
+    assert pencilSignal.sum() > sphereSignal.sum() and np.argmax(pencilSignal) != np.argmax(sphereSignal)

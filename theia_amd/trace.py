@@ -546,7 +546,16 @@ class VolumeForwardTracer(Tracer):
     def run(self, i: int):
         self.callback.bindParams(self._program, i)
         self.response.bindParams(self._program, i)
-        return [lambda: self._program.run(i, self._assemble(i))]
+
+        def launch() -> None:
+            # stages may be shared between several tracers / pipelines (examples/03): bind them to
+            # THIS tracer again when the batch actually runs, so that the response stage that
+            # follows reduces and retrieves this tracer's result
+            self.callback.bindParams(self._program, i)
+            self.response.bindParams(self._program, i)
+            self._program.run(i, self._assemble(i))
+
+        return [launch]
 
 
 class SceneForwardTracer(Tracer):
@@ -660,7 +669,16 @@ class SceneForwardTracer(Tracer):
     def run(self, i: int):
         self.callback.bindParams(self._program, i)
         self.response.bindParams(self._program, i)
-        return [lambda: self._program.run(i, self._assemble(i))]
+
+        def launch() -> None:
+            # stages may be shared between several tracers / pipelines (examples/03): bind them to
+            # THIS tracer again when the batch actually runs, so that the response stage that
+            # follows reduces and retrieves this tracer's result
+            self.callback.bindParams(self._program, i)
+            self.response.bindParams(self._program, i)
+            self._program.run(i, self._assemble(i))
+
+        return [launch]
 
 
 class ScenePhotonTracer(SceneForwardTracer):
