@@ -326,4 +326,4 @@ def test_example03_shared_stages_between_pipelines(oracle_backend):
     assert pencilSignal[0] == 0 and pencilSignal[1] == 0
     assert sphereSignal[1] > 0
     # different sources, different curves: the shared response returned each pipeline's own result
-    assert pencilSignal.sum() > sphereSignal.sum() and np.argmax(pencilSignal) != np.argmax(sphereSignal)
+    assert pencilSignal.sum() > sphereSignal.sum() and not np.allclose(pencilSignal, sphereSignal, rtol=0.1)
