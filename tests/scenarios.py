@@ -178,6 +178,31 @@ def config5_suzanne_grid(batch: int = 1_000_000, *, polarized: bool = True, stat
                     response=response, rng=rng, guide=guide, tracer=tracer, callback=callback)
 
 
+def many_cubes(batch: int = 10_000, *, n_side: int = 17, stats: bool = False, track: bool = False, key: int = 7) -> Scenario:
+    """n_side^3 small glass cubes (>= 4096 instances: beyond the staged kernel's packed hit ids, so the
+    lane kernel runs) around a detector sphere; unpolarized, no guide."""
+    water = WaterTestModel().createMedium(400.0 * u.nm, 800.0 * u.nm, name="water")
+    glass = BK7Model().createMedium(400.0 * u.nm, 800.0 * u.nm, name="glass")
+    store = MaterialStore([Material("glass", glass, water, flags="TR"), Material("det", None, water, flags="BD")])
+    meshes = MeshStore({"cube": bundled_mesh("cube"), "sphere": bundled_mesh("sphere")})
+    pitch = 2.0
+    instances = [meshes.createInstance("cube", "glass", Transform.TRS(scale=0.3, translate=(ix * pitch, iy * pitch, iz * pitch)))
+                 for ix in range(n_side) for iy in range(n_side) for iz in range(n_side)]
+    c = 0.5 * (n_side - 1) * pitch + 1.0
+    instances.append(meshes.createInstance("sphere", "det", Transform.TRS(scale=0.6, translate=(c, c, c)), detectorId=1))
+    scene = Scene(instances, store.material, medium=store.media["water"])
+    photons = UniformWavelengthSource(lambdaRange=(400.0 * u.nm, 800.0 * u.nm))
+    light = SphericalLightSource(position=(c - pitch, c - pitch, c - pitch), timeRange=(0.0, 10.0) * u.ns, budget=1.0e5)
+    response = HistogramHitResponse(UniformValueResponse(), nBins=100, binSize=5.0 * u.ns)
+    rng = PhiloxRNG(key=key)
+    callback = EventStatisticCallback() if stats else EmptyEventCallback()
+    tracer = SceneForwardTracer(batch, light, photons, response, rng, scene, maxPathLength=12, targetId=1,
+                                scatterCoefficient=0.05 / u.m, callback=callback, trackEvents=track)
+    rng.autoAdvance = tracer.nRNGSamples
+    return Scenario(name="many_cubes", store=store, meshes=meshes, scene=scene, light=light, photons=photons,
+                    response=response, rng=rng, guide=None, tracer=tracer, callback=callback)
+
+
 def run_batches(sc: Scenario, n_batches: int = 1) -> list[np.ndarray]:
     """Runs the scenario's pipeline synchronously and returns one histogram per batch."""
     from theia_amd.hp.pipeline import Pipeline

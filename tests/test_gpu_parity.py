@@ -255,3 +255,14 @@ def test_scheduler_watchdog_is_loud(hip_backend, monkeypatch):
     monkeypatch.delenv("THX_TEST_ABORT")
     sc = S.config2_sphere(batch=10000)
     assert np.isfinite(S.run_batches(sc, 1)[0]).all()
+
+
+def test_scene_with_more_instances_than_the_staged_kernel_packs(hip_backend):
+    """4914 instances: the tracer falls back to the lane kernel (12-bit instance ids in the staged
+    kernel's shadow-ray entries) and still follows the oracle photon by photon"""
+    n = 6000
+    res = _both(S.many_cubes, batch=n, stats=True, track=True)
+    sc = res[1][0]
+    info = sc.tracer.program.launch_info(n)
+    assert info["block"] == 256  # lane kernel geometry
+    _compare(res, n, code_agree=0.99)
