@@ -137,7 +137,11 @@ typedef struct {
 
 #pragma pack(pop)
 
-enum { THX_TRACER_VOLUME_FORWARD = 0, THX_TRACER_SCENE_FORWARD = 1 };
+/* THX_TRACER_HIT_REPLAY: HitReplay (response.py:278-423, shader/response.replay.glsl): no tracing,
+ * every item of an input hit queue of `capacity` entries (uploaded with thx_tracer_write_hits;
+ * THX_FLAG_POLARIZED = the queue has the stokes / polRef columns) is fed to the response with
+ * idx = its position in the queue and RNG dimension 0 */
+enum { THX_TRACER_VOLUME_FORWARD = 0, THX_TRACER_SCENE_FORWARD = 1, THX_TRACER_HIT_REPLAY = 2 };
 
 /* compile-time macros of the reference's shaders (trace.py:660-666, 1226-1235) */
 enum {
@@ -270,6 +274,10 @@ size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized);
 size_t thx_time_queue_bytes(uint32_t hit_capacity, uint32_t store_object_id); /* THX_RESPONSE_STORE_TIME queue */
 int thx_tracer_read_hits(thx_tracer* tracer, void* out, size_t nbytes, int clear);
 int thx_tracer_hits_device_ptr(thx_tracer* tracer, uint64_t* dev_addr);
+/* HitReplay input (replaces hephaistos IOQueue(mode="update") of response.py:357-359): copies a
+ * host queue (uint32 count + SoA columns of `capacity` entries, layout of thx_hit_queue_bytes
+ * (capacity, polarized)) to the device queue the next THX_TRACER_HIT_REPLAY runs read */
+int thx_tracer_write_hits(thx_tracer* tracer, const void* src, size_t nbytes);
 /* parity probe: per-event dump of the last run, [batch][path_length+3][THX_TRACK_WORDS] */
 int thx_tracer_read_track(thx_tracer* tracer, float* out, size_t n_floats);
 /* launch geometry chosen by the library: workgroups, threads per workgroup,

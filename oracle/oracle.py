@@ -245,6 +245,21 @@ def trace_volume(common: Common, trace: VolumeTraceParams, target: TargetParams,
     return hist, stats, tr
 
 
+def replay(common: Common, queue: np.ndarray, capacity: int, polarized: bool, *, threads: int = 0):
+    """HitReplay: every item of `queue` (uint8/uint32 array, count + SoA columns) -> response"""
+    fn = lib().orc_replay
+    fn.argtypes = [C.POINTER(Common), C.c_void_p, C.c_uint32, C.c_int, C.c_int, C.POINTER(C.c_float), C.POINTER(C.c_uint64)]
+    fn.restype = C.c_int
+    hist = np.zeros(common.n_bins, dtype=np.float32)
+    stats = np.zeros(N_STATS, dtype=np.uint64)
+    q = np.ascontiguousarray(queue)
+    rc = fn(C.byref(common), q.ctypes.data, int(capacity), int(bool(polarized)), threads, _fp(hist),
+            stats.ctypes.data_as(C.POINTER(C.c_uint64)))
+    if rc != 0:
+        raise RuntimeError(f"orc_replay failed: {rc}")
+    return hist, stats
+
+
 def trace_scene(common: Common, trace: SceneTraceParams, guide: GuideParams | None, scene: Scene, *, threads: int = 0, track: bool = False):
     hist = np.zeros(common.n_bins, dtype=np.float32)
     stats = np.zeros(N_STATS, dtype=np.uint64)

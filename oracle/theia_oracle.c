@@ -1940,6 +1940,44 @@ int orc_trace_volume(const orc_common* c, const orc_volume_trace_params* t,
     return run_blocks(c, &x, vol_photon, &a, n_threads, hist_out, stats, track, c->path_length + 3);
 }
 
+/* response.replay.glsl:37-52: item idx of the input queue (response.queue.glsl layout) goes to
+ * response(hit, idx, dim = 0); c->batch_size = capacity of the queue */
+typedef struct { const uint32_t* queue; uint32_t capacity; int polarized; } ReplayArgs;
+static void replay_item(Ctx* x, const void* a, uint32_t idx) {
+    const ReplayArgs* r = (const ReplayArgs*)a;
+    uint32_t count = r->queue[0] < r->capacity ? r->queue[0] : r->capacity;
+    if (idx >= count) return;
+    const float* col = (const float*)(r->queue + 1) + idx;
+    const size_t cap = r->capacity;
+    HitItem h;
+    memset(&h, 0, sizeof(h));
+#define GET() (*col); col += cap
+    h.position.x = GET(); h.position.y = GET(); h.position.z = GET();
+    h.direction.x = GET(); h.direction.y = GET(); h.direction.z = GET();
+    h.normal.x = GET(); h.normal.y = GET(); h.normal.z = GET();
+    if (r->polarized) {
+        h.stokes.x = GET(); h.stokes.y = GET(); h.stokes.z = GET(); h.stokes.w = GET();
+        h.polRef.x = GET(); h.polRef.y = GET(); h.polRef.z = GET();
+    }
+    h.wavelength = GET(); h.time = GET(); h.contrib = GET();
+#undef GET
+    h.objectId = *(const int32_t*)col;
+    uint32_t dim = 0;
+    x->cur_idx = idx;
+    x->cur_dim = &dim;
+    response(x, &h);
+}
+
+int orc_replay(const orc_common* c, const uint32_t* queue, uint32_t capacity, int polarized,
+               int n_threads, float* hist_out, uint64_t stats[20]) {
+    Ctx x;
+    memset(&x, 0, sizeof(x));
+    x.c = c;
+    x.polarized = polarized != 0;
+    ReplayArgs a = {queue, capacity, polarized};
+    return run_blocks(c, &x, replay_item, &a, n_threads, hist_out, stats, NULL, 0);
+}
+
 int orc_trace_scene(const orc_common* c, const orc_scene_trace_params* t,
                     const orc_guide_params* guide, const orc_scene* scene, int n_threads,
                     float* hist_out, uint64_t stats[20], float* track) {

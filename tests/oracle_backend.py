@@ -150,7 +150,14 @@ class OracleBackend:
         t.stats += stats
         t.track = track
 
+    def tracer_write_hits(self, tracer: int, data: np.ndarray) -> None:
+        self._tracers[tracer].replay_in = np.array(data, dtype=np.uint8, copy=True)
+
     def _trace(self, spec, t, c, params, want_track):
+        if spec.kind == capi.TRACER_HIT_REPLAY:
+            c.batch_size = spec.capacity
+            hist, stats = orc.replay(c, t.replay_in, spec.capacity, bool(spec.flags & capi.FLAG_POLARIZED), threads=self.threads)
+            return hist, stats, None
         if spec.kind == capi.TRACER_VOLUME_FORWARD:
             tp, tg = orc.VolumeTraceParams(), orc.TargetParams()
             _copy(tp, params.volume)

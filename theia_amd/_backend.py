@@ -172,6 +172,11 @@ class HipBackend:
         """copies the HitRecorder queue into `out` (uint8) and resets its counter"""
         capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
 
+    def tracer_write_hits(self, tracer: int, data: np.ndarray) -> None:
+        """uploads the input queue (uint8, count + SoA columns) of a hit replay"""
+        data = np.ascontiguousarray(data)
+        capi.check(self._lib.thx_tracer_write_hits(C.c_void_p(tracer), data.ctypes.data_as(C.c_void_p), data.nbytes))
+
     def tracer_launch_info(self, tracer: int, batch: int) -> dict:
         g, b, l = C.c_uint32(), C.c_uint32(), C.c_uint32()
         capi.check(self._lib.thx_tracer_launch_info(C.c_void_p(tracer), int(batch), C.byref(g), C.byref(b), C.byref(l)))

@@ -17,7 +17,7 @@ __all__ = [
     "DispatchParams", "PhiloxParams", "LightParams", "WavelengthParams", "TargetParams",
     "GuideParams", "PropagateParams", "VolumeTraceParams", "SceneTraceParams", "ResponseParams",
     "RunParams", "TracerDesc", "MeshDesc", "InstanceDesc", "SceneInfo",
-    "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
+    "TRACER_VOLUME_FORWARD", "TRACER_SCENE_FORWARD", "TRACER_HIT_REPLAY", "N_STATS", "TRACK_WORDS", "STAT_NAMES",
     "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
     "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "FLAG_KERNEL_HISTOGRAM", "EXPORTED_SYMBOLS",
@@ -25,6 +25,7 @@ __all__ = [
 
 TRACER_VOLUME_FORWARD = 0
 TRACER_SCENE_FORWARD = 1
+TRACER_HIT_REPLAY = 2
 RESPONSE_HISTOGRAM = 0
 RESPONSE_RECORD = 1
 RESPONSE_STORE_TIME = 2
@@ -175,6 +176,7 @@ _PROTOS = {
     "thx_time_queue_bytes": (c_size_t, [c_uint32, c_uint32]),
     "thx_tracer_read_hits": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "thx_tracer_hits_device_ptr": (c_int, [c_void_p, POINTER(c_uint64)]),
+    "thx_tracer_write_hits": (c_int, [c_void_p, c_void_p, c_size_t]),
     "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "thx_tracer_last_kernel_ms": (c_int, [c_void_p, c_uint32, POINTER(c_float)]),
     "thx_tracer_kernel_times": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_uint32)]),

@@ -75,6 +75,7 @@ struct thx_tracer {
     unsigned long long* prof = nullptr;
     float* track = nullptr;
     uint32_t* hits = nullptr;     // HitRecorder queue (count + SoA columns) or null
+    uint32_t* replayIn = nullptr; // THX_TRACER_HIT_REPLAY: the input hit queue
     uint32_t trackEvents = 0;
     uint32_t lastBatch = 0;
     // ring of HIP event pairs bracketing the tracing kernel on its launch stream
@@ -320,8 +321,8 @@ int thx_scene_query_ms(const thx_scene* scene, float* ms) {
 int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scene, thx_tracer** out) {
     if (!ctx || !desc || !out) return fail(THX_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (desc->kind != THX_TRACER_VOLUME_FORWARD && desc->kind != THX_TRACER_SCENE_FORWARD)
-        return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
+    if (desc->kind > THX_TRACER_HIT_REPLAY) return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
+    const bool replay = desc->kind == THX_TRACER_HIT_REPLAY;
     if (desc->kind == THX_TRACER_SCENE_FORWARD && !scene)
         return fail(THX_ERR_INVALID, "scene tracer needs a scene");
     const bool record = desc->response_kind == THX_RESPONSE_RECORD || desc->response_kind == THX_RESPONSE_STORE_TIME;
@@ -340,10 +341,10 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     desc = &t->desc;
     const bool pol = (desc->flags & THX_FLAG_POLARIZED) != 0;
     const bool mis = (desc->flags & THX_FLAG_DISABLE_MIS) == 0;
-    t->variant = traceVariant(desc->kind, pol, mis);
+    if (!replay) t->variant = traceVariant(desc->kind, pol, mis);
     // the record response is compiled into the instrumented variants only
     t->debug = record || (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK)) != 0;
-    t->block = kTraceBlock;
+    t->block = replay ? kReplayBlock : kTraceBlock;
     if (scene) {
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
         t->stack16 = scene->info.n_nodes < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
@@ -351,7 +352,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     }
     // kernel form: the staged scene kernel unless the scene exceeds its packed hit ids
     // (12-bit instance, 20-bit primitive) or THX_KERNEL=lane asks for the lane kernel
-    t->staged = desc->kind == THX_TRACER_SCENE_FORWARD && scene->info.n_instances < 4096 &&
+    t->staged = desc->kind == THX_TRACER_SCENE_FORWARD && scene && scene->info.n_instances < 4096 &&
                 scene->info.n_triangles < (1u << 20) && desc->path_length >= 1;
     if (const char* env = std::getenv("THX_KERNEL")) {
         if (std::strcmp(env, "lane") == 0) t->staged = false;
@@ -392,7 +393,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     if (std::getenv("THX_VERBOSE"))
         std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u stack16=%d ldsNodes=%u\n",
                      (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, (int)t->stack16, t->ldsNodes);
-    int perCU = t->variant.occupancy(t->mode, t->block, t->lds);
+    // replay streams its queue once: a few workgroups per CU hide the load latency
+    int perCU = replay ? 8 : t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
     uint32_t mult = 1;
     if (const char* env = std::getenv("THX_GRID_MULT")) mult = (uint32_t)std::max(1, std::atoi(env));
@@ -425,6 +427,11 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         e = hipMalloc((void**)&t->hits, nb);
         if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
     }
+    if (e == hipSuccess && replay) {
+        const size_t nb = thx_hit_queue_bytes(desc->capacity, pol);
+        e = hipMalloc((void**)&t->replayIn, nb);
+        if (e == hipSuccess) e = hipMemset(t->replayIn, 0, nb);
+    }
     // the memsets above run on the null stream, which is NOT ordered with the context's
     // non-blocking stream: finish them before anything can be launched
     if (e == hipSuccess) e = hipDeviceSynchronize();
@@ -449,11 +456,18 @@ int thx_tracer_destroy(thx_tracer* t) {
     if (t->prof) (void)hipFree(t->prof);
     if (t->track) (void)hipFree(t->track);
     if (t->hits) (void)hipFree(t->hits);
+    if (t->replayIn) (void)hipFree(t->replayIn);
     delete t;
     return THX_OK;
 }
 
 static void launchGeometry(const thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* ppw) {
+    if (t->desc.kind == THX_TRACER_HIT_REPLAY) { // one hit per thread until the chip is full, then grid-stride
+        const uint64_t need = ((uint64_t)t->desc.capacity + t->block - 1) / t->block;
+        *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, need));
+        *ppw = 0;
+        return;
+    }
     if (t->staged) { // one pool-owning workgroup per CU; each gets a contiguous photon range
         uint64_t need = ((uint64_t)batch + t->pool - 1) / t->pool;
         *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, need));
@@ -520,7 +534,10 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     t->lastBatch = batch;
     const uint32_t slot = (uint32_t)(t->launches % thx_tracer::kRing);
     THX_HIP(hipEventRecord(t->evStart[slot], s));
-    THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
+    if (t->desc.kind == THX_TRACER_HIT_REPLAY)
+        THX_HIP(launchReplay(a, t->replayIn, t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) != 0, grid, s));
+    else
+        THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
     THX_HIP(hipEventRecord(t->evStop[slot], s));
     t->lastSlot[cfg] = (int)slot;
     t->launches += 1;
@@ -621,6 +638,17 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
         THX_HIP(hipMemsetAsync(t->hits, 0, 4, t->ctx->stream));
         THX_HIP(hipStreamSynchronize(t->ctx->stream));
     }
+    return THX_OK;
+}
+
+int thx_tracer_write_hits(thx_tracer* t, const void* src, size_t nbytes) {
+    if (!t || !src) return fail(THX_ERR_INVALID, "null argument");
+    if (!t->replayIn) return fail(THX_ERR_INVALID, "tracer is not a THX_TRACER_HIT_REPLAY");
+    const size_t have = thx_hit_queue_bytes(t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) ? 1u : 0u);
+    if (nbytes != have) return fail(THX_ERR_INVALID, "queue size does not match the replay's capacity / polarization");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipMemcpyAsync(t->replayIn, src, nbytes, hipMemcpyHostToDevice, t->ctx->stream));
+    THX_HIP(hipStreamSynchronize(t->ctx->stream)); // `src` may be reused by the caller
     return THX_OK;
 }
 

@@ -467,7 +467,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         } else {
             entry = 0;
         }
-        const uint32_t n = (ok0 ? n0 : 0u) + (ok1 ? n1 : 0u);
+        [[maybe_unused]] const uint32_t n = (ok0 ? n0 : 0u) + (ok1 ? n1 : 0u);
         // photon indices of a birth batch; beyond `end` the slot goes back to the free ring
         uint32_t birthFirst = 0;
         if (stage == (uint32_t)S_BIRTH) {

@@ -36,6 +36,10 @@ const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis);
 
 hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
                         float norm, hipStream_t stream);
+// response.replay.glsl: one response() call per item of the input queue
+hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32_t in_capacity, bool in_polarized,
+                        uint32_t grid, hipStream_t stream);
+constexpr uint32_t kReplayBlock = 256;
 hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,
                          uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
                          float* out_f32, hipStream_t stream);

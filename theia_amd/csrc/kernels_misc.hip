@@ -72,6 +72,67 @@ hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_
     return hipGetLastError();
 }
 
+// HitReplay (response.replay.glsl:37-52): hit idx of the input queue -> response(hit, idx, dim = 0).
+// A fixed grid strides over the queue; the histogram responses bin into the workgroup's LDS
+// histogram (flushed to its slab, summed by reduceKernel), the record / store-time responses
+// append to the output queue. Input and output are structure-of-arrays queues: a wavefront reads
+// and writes 256 contiguous bytes per column.
+__global__ void __launch_bounds__(kReplayBlock) replayKernel(const LaunchArgs args, const uint32_t* __restrict__ in,
+                                                             uint32_t in_capacity, uint32_t in_polarized) {
+    using V = Variant<false, true, false, false>;
+    const uint32_t tid = threadIdx.x;
+    const uint32_t n_bins = args.n_bins;
+    float* hist = ldsHist();
+    for (uint32_t i = tid; i < n_bins; i += blockDim.x) hist[i] = 0.0f;
+    __syncthreads();
+
+    Lane<V> L;
+    L.a = &args;
+    L.stackBase = 0;
+    L.cnt.clear();
+    const uint32_t count = min(in[0], in_capacity);
+    const float* cols = reinterpret_cast<const float*>(in + 1);
+    const uint32_t tail = in_polarized ? 16u : 9u; // column of the wavelength
+    for (uint32_t idx = blockIdx.x * blockDim.x + tid; idx < count; idx += gridDim.x * blockDim.x) {
+        auto col = [&](uint32_t c) { return cols[(size_t)c * in_capacity + idx]; };
+        L.idx = idx; L.local = idx; L.dim = 0;
+        const float time = col(tail + 1), contrib = col(tail + 2);
+        if (args.hits == nullptr) {
+            response(L, HitItem{time, contrib});
+        } else if (args.hit_kind == THX_RESPONSE_STORE_TIME) {
+            // response.time.store.glsl:14-25 with response.uniform.glsl: value = contrib
+            if (draw(L) < contrib) {
+                const uint32_t id = atomicAdd(args.hits, 1u);
+                if (id < args.hit_capacity) {
+                    float* t = reinterpret_cast<float*>(args.hits + 1) + id;
+                    *t = time;
+                    if (args.hit_polarized) *reinterpret_cast<int*>(t + args.hit_capacity) = __float_as_int(col(tail + 3));
+                }
+            }
+        } else {
+            f4 stokes{1.0f, 0.0f, 0.0f, 0.0f};
+            f3 polRef{0.0f, 0.0f, 0.0f};
+            if (in_polarized) {
+                stokes = f4{col(9), col(10), col(11), col(12)};
+                polRef = f3{col(13), col(14), col(15)};
+            }
+            recordHit(L, f3{col(0), col(1), col(2)}, f3{col(3), col(4), col(5)}, f3{col(6), col(7), col(8)}, stokes, polRef,
+                      col(tail), time, contrib, __float_as_int(col(tail + 3)));
+        }
+    }
+    __syncthreads();
+    float* slab = args.slabs + (size_t)blockIdx.x * n_bins;
+    for (uint32_t i = tid; i < n_bins; i += blockDim.x) slab[i] = hist[i];
+}
+
+hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32_t in_capacity, bool in_polarized,
+                        uint32_t grid, hipStream_t stream) {
+    const size_t lds = ((size_t)args.n_bins * 4 + 15) & ~(size_t)15;
+    hipLaunchKernelGGL(replayKernel, dim3(grid), dim3(kReplayBlock), lds, stream, args, in_queue, in_capacity,
+                       in_polarized ? 1u : 0u);
+    return hipGetLastError();
+}
+
 // random.sink.glsl equivalent: raw words + floats behind random(stream, dim)
 __global__ void rngFillKernel(thx_philox_params p, uint32_t base_stream, uint32_t n_streams,
                               uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,

@@ -5,9 +5,11 @@ use: src/theia/response.py:219, 268-274; device layout shader/response.queue.gls
 -- `uint count`, then one column of `capacity` entries per scalar of the item, in
 field order; a `c_float * 3` field is three columns).
 
-Only the host side lives here: `QueueView` gives numpy views onto a retrieved queue,
-`IOQueue(mode="retrieve")` owns the two host buffers of the double-buffered pipeline.
-The device queue belongs to the tracer the recorder is bound to.
+Only the host side lives here: `QueueView` gives numpy views onto a queue in host memory,
+`IOQueue` owns the two host buffers of the double-buffered pipeline: `mode="retrieve"` is
+filled from the device after every batch (HitRecorder), `mode="update"` is written by the
+user and uploaded before it (HitReplay, response.py:357-359). The device queue belongs to
+the tracer / replay the stage is bound to.
 """
 from __future__ import annotations
 
@@ -99,7 +101,35 @@ class QueueView:
             idx = range(start, stop, step)[key]
             return QueueView(self._data, self._item, self._capacity, skipCounter=self._skipCounter,
                              _slice=slice(idx.start, idx.stop, idx.step))
-        raise TypeError("index a QueueView with a field name or a slice")
+        if isinstance(key, (np.ndarray, list)):
+            # items picked / reordered by index (`results[np.argsort(results["contrib"])]`): a copy
+            sel = np.asarray(key)
+            n = len(sel) if sel.dtype != np.bool_ else int(sel.sum())
+            out = QueueView(np.zeros(queueSize(self._item, max(n, 1), skipCounter=self._skipCounter), dtype=np.uint8),
+                            self._item, max(n, 1), skipCounter=self._skipCounter, _slice=slice(0, n))
+            for name in self.fields:
+                out[name] = self[name][sel]
+            if not self._skipCounter:
+                out.count = n
+            return out
+        raise TypeError("index a QueueView with a field name, a slice or an index array")
+
+    def __setitem__(self, key: str, value) -> None:
+        """`view["time"] = array`: writes a column (block) of the queue, converting to its type"""
+        if not isinstance(key, str):
+            raise TypeError("only whole fields of a QueueView can be assigned")
+        for name, dtype, n, col in self._cols:
+            if name == key:
+                base = self._data[self._offset + 4 * col * self._capacity:
+                                  self._offset + 4 * (col + n) * self._capacity].view(dtype)
+                target = base.reshape(n, self._capacity)[:, self._slice]  # column major: one row per scalar
+                value = np.asarray(value)
+                if n == 1:
+                    target[0, :] = value
+                else:
+                    target[:, :] = np.broadcast_to(value, (target.shape[1], n)).T
+                return
+        raise KeyError(key)
 
     def __iter__(self):
         return iter(self.fields)
@@ -118,14 +148,17 @@ def dumpQueue(view: QueueView) -> dict[str, np.ndarray]:
 class IOQueue:
     """Host side of a queue that is filled on the device and retrieved after each batch."""
 
-    def __init__(self, item: type[Structure], *, mode: str = "retrieve", skipCounter: bool = False) -> None:
-        if mode != "retrieve":
-            raise NotImplementedError("only IOQueue(mode='retrieve') exists on the HIP backend")
+    def __init__(self, item: type[Structure], capacity: int | None = None, *, mode: str = "retrieve",
+                 skipCounter: bool = False) -> None:
+        if mode not in ("retrieve", "update"):
+            raise NotImplementedError("IOQueue modes on the HIP backend: 'retrieve', 'update'")
         self._item = item
         self._mode = mode
         self._skipCounter = skipCounter
         self._capacity = 0
         self._buffers: list[np.ndarray] | None = None
+        if capacity is not None:
+            self.initialize(capacity)
 
     @property
     def item(self) -> type[Structure]:
@@ -154,6 +187,11 @@ class IOQueue:
             raise ValueError("capacity must be positive")
         self._capacity = int(capacity)
         self._buffers = [np.zeros(self.nbytes, dtype=np.uint8) for _ in range(2)]
+        if self._mode == "update" and not self._skipCounter:
+            # a queue the user fills starts out full: the reference's tests write all `capacity`
+            # items and never touch the counter (tests/test_response.py:24-37)
+            for b in self._buffers:
+                b[:4].view(np.uint32)[0] = self._capacity
 
     def buffer(self, i: int) -> np.ndarray:
         if self._buffers is None:

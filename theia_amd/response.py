@@ -16,11 +16,12 @@ from warnings import warn
 import numpy as np
 
 from . import units as u
-from .hp.pipeline import SourceCodeMixin
+from . import _capi as capi
+from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .hp.queue import IOQueue
 
 __all__ = ["HitItem", "PolarizedHitItem", "HitTimeItem", "HitTimeAndIdItem", "TraceConfig", "HitResponse", "EmptyResponse",
-           "HitRecorder", "StoreTimeHitResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse",
+           "HitRecorder", "HitReplay", "StoreTimeHitResponse", "ValueResponse", "UniformValueResponse", "HistogramHitResponse",
            "KernelHistogramHitResponse"]
 
 
@@ -401,3 +402,100 @@ class KernelHistogramHitResponse(HistogramHitResponse):
         super().__init__(response, nBins=nBins, t0=t0, binSize=binSize, normalization=normalization, retrieve=retrieve,
                          reduceBlockSize=reduceBlockSize, updateResponse=updateResponse, useSharedMemory=useSharedMemory)
         self.setParams(kernelBandwidth=kernelBandwidth, kernelSupport=kernelSupport)
+
+
+class HitReplay(PipelineStage):
+    """
+    Reads hits from a queue and feeds each to the given response (response.py:278-423,
+    shader/response.replay.glsl): hit `k` of the queue is passed to `response(hit, idx=k, dim=0)`.
+    Parameters as in the reference: `capacity, response, *, rng=None, normalization=1.0,
+    polarized=False, blockSize=128, code=None`. `replay.queue.view(i)` is the host queue the
+    next batch run with config `i` uploads (`view["time"] = ...`; it starts out with
+    `count == capacity`).
+
+    Responses: `HistogramHitResponse` / `KernelHistogramHitResponse(UniformValueResponse())`,
+    `HitRecorder`, `StoreTimeHitResponse(UniformValueResponse())` (needs `rng`).
+    """
+
+    name = "Hit Replay"
+
+    def __init__(self, capacity: int, response: HitResponse, *, rng=None, normalization: float = 1.0,
+                 polarized: bool = False, blockSize: int = 128, code: bytes | None = None) -> None:
+        if response.nRNGSamples > 0 and rng is None:
+            raise ValueError("response requires a rng but none was given!")
+        super().__init__()
+        if not isinstance(response, (HistogramHitResponse, HitRecorder, StoreTimeHitResponse)):
+            raise NotImplementedError(
+                f"{type(response).__name__} is not supported as response of a hit replay by the HIP backend "
+                "(supported: HistogramHitResponse, KernelHistogramHitResponse, HitRecorder, StoreTimeHitResponse)")
+        if isinstance(response, HitRecorder) and response.polarized != polarized:
+            # the reference's shader refuses to compile: "mismatch in hit queue definition"
+            # (response.replay.glsl:22-27)
+            raise RuntimeError("mismatch in hit queue definition: HitRecorder and HitReplay differ in polarization")
+        self._blockSize = blockSize
+        self._capacity = capacity
+        self._polarized = polarized
+        self._response = response
+        self._rng = rng
+        self._code = b"" if code is None else code
+        self._config = TraceConfig(capacity, blockSize, capacity, 1, normalization, polarized)
+        response.prepare(self._config)
+        self._queue = IOQueue(PolarizedHitItem if polarized else HitItem, capacity, mode="update")
+
+        from . import _backend
+        from .trace import _Program  # the tracers' handle type; imported late (trace imports this module)
+
+        flags = capi.FLAG_POLARIZED if polarized else 0
+        if isinstance(response, HitRecorder):
+            spec = (1, capacity, capi.RESPONSE_RECORD, response.capacity, response.polarized)
+        elif isinstance(response, StoreTimeHitResponse):
+            spec = (1, capacity, capi.RESPONSE_STORE_TIME, response.capacity, response.storeObjectId)
+        else:
+            flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
+            spec = (response.nBins, capacity, capi.RESPONSE_HISTOGRAM, 0, False)
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_HIT_REPLAY, flags, 0, blockSize, *spec), None)
+
+    blockSize = property(lambda self: self._blockSize, doc="number of hits processed per work group (API parity)")
+    capacity = property(lambda self: self._capacity, doc="maximum number of hits processed per run")
+    code = property(lambda self: self._code, doc="kept for API parity; kernels are precompiled")
+    polarized = property(lambda self: self._polarized, doc="whether the hits carry polarization")
+    queue = property(lambda self: self._queue, doc="queue holding the hits of the next batch")
+    rng = property(lambda self: self._rng)
+    response = property(lambda self: self._response)
+    program = property(lambda self: self._program)
+
+    def collectStages(self) -> list[PipelineStage]:
+        if self.rng is not None:
+            return [self.rng, self, self.response]
+        return [self, self.response]
+
+    def _finishParams(self, i: int) -> None:
+        super()._finishParams(i)
+        self.response.updateConfig(self._config)
+
+    def _assemble(self, i: int) -> capi.RunParams:
+        P = capi.RunParams()
+        P.dispatch.batchSize = self._capacity
+        P.dispatch.groupCountX = -(self._capacity // -self._blockSize)
+        P.dispatch.groupCountY = P.dispatch.groupCountZ = 1
+        if self._rng is not None:
+            r = self._rng._getParamsBlock("PhiloxParams", i)
+            P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
+            for k in range(4):
+                P.philox.offset[k] = r.offset.word[k]
+        if isinstance(self._response, HistogramHitResponse):
+            rp = self._response._getParamsBlock("ResponseParams", i)
+            P.response.t0, P.response.binSize = rp.t0, rp.binSize
+            if isinstance(self._response, KernelHistogramHitResponse):
+                P.response.kernelBandwidth, P.response.kernelSupport = rp.kernelBandwidth, rp.kernelSupport
+        return P
+
+    def run(self, i: int):
+        self.response.bindParams(self._program, i)
+
+        def launch() -> None:
+            self.response.bindParams(self._program, i)
+            self._program.write_hits(self._queue.buffer(i))
+            self._program.run(i, self._assemble(i))
+
+        return [launch]

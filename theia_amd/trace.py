@@ -225,6 +225,9 @@ class _Program:
     def read_hits(self, out: np.ndarray, clear: bool = True) -> None:
         self.backend.tracer_read_hits(self.handle, out, clear)
 
+    def write_hits(self, data: np.ndarray) -> None:
+        self.backend.tracer_write_hits(self.handle, data)
+
     def read_stats(self) -> np.ndarray:
         return self.backend.tracer_read_stats(self.handle)
 
