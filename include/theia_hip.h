@@ -166,8 +166,9 @@ enum {
  * in the order of shader/callback.stat.glsl:7-20, then queries, nodes,
  * triangles, instances, hits, lut_reads, responses, steps */
 #define THX_N_STATS 20
-/* words per event in the track buffer: code, pos.xyz, dir.xyz, time, lin, log, wavelength, dim */
-#define THX_TRACK_WORDS 12
+/* words per event in the track buffer: code, pos.xyz, dir.xyz, time, lin, log, wavelength, dim,
+ * stokes.iquv, polRef.xyz ((1,0,0,0), 0 for an unpolarized tracer: callback.track.glsl:84-88), pad */
+#define THX_TRACK_WORDS 20
 
 typedef struct {
     uint32_t kind;        /* THX_TRACER_* */

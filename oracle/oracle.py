@@ -27,7 +27,7 @@ FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_TARGET_INNER = 1 << 11
 FLAG_KERNEL_HISTOGRAM = 1 << 13
 FLAG_BRUTE_FORCE = 1 << 7
-TRACK_WORDS = 12
+TRACK_WORDS = 20
 N_STATS = 20
 
 

@@ -740,6 +740,14 @@ static void onEvent(Ctx* x, const Ray* r, int code, uint32_t local_idx, uint32_t
         t[4] = r->direction.x; t[5] = r->direction.y; t[6] = r->direction.z;
         t[7] = r->time; t[8] = r->lin_contrib; t[9] = r->log_contrib;
         t[10] = r->wavelength; t[11] = (float)dim;
+        if (x->polarized) {
+            t[12] = r->stokes.x; t[13] = r->stokes.y; t[14] = r->stokes.z; t[15] = r->stokes.w;
+            t[16] = r->polRef.x; t[17] = r->polRef.y; t[18] = r->polRef.z;
+        } else { /* callback.track.glsl:84-88 */
+            t[12] = 1.0f; t[13] = 0.0f; t[14] = 0.0f; t[15] = 0.0f;
+            t[16] = 0.0f; t[17] = 0.0f; t[18] = 0.0f;
+        }
+        t[19] = 0.0f;
     }
 }
 

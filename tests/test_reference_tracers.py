@@ -481,9 +481,9 @@ def test_EventStatisticCallback(backend):
 
 
 @pytest.mark.parametrize("polarized", [True, False])
-def test_TrackRecordCallback(backend, polarized):
-    """/root/reference/tests/test_trace.py:1048-1119 with polarizedTrack=False (the polarized
-    track layout is not built)"""
+@pytest.mark.parametrize("polarizedTrack", [True, False])
+def test_TrackRecordCallback(backend, polarizedTrack, polarized):
+    """/root/reference/tests/test_trace.py:1048-1119"""
     N = 32 * 256
     N_SCATTER = 6
     LENGTH = N_SCATTER + 2  # one more than needed
@@ -503,7 +503,7 @@ def test_TrackRecordCallback(backend, polarized):
     source = theia.light.PencilLightSource(position=light_pos, direction=light_dir, timeRange=(T0, T1), stokes=stokes,
                                            polarizationRef=polRef)
     response = theia.response.EmptyResponse()
-    track = theia.trace.TrackRecordCallback(N, LENGTH, polarized=False)
+    track = theia.trace.TrackRecordCallback(N, LENGTH, polarized=polarizedTrack)
     tracer = theia.trace.VolumeForwardTracer(
         N, source, SphereTarget(position=target_pos, radius=target_radius), photons, response, rng,
         callback=track, medium=store.media["water"], nScattering=N_SCATTER, scatterCoefficient=0.1, maxTime=T_MAX,
@@ -512,7 +512,7 @@ def test_TrackRecordCallback(backend, polarized):
     pl.runPipeline(tracer.collectStages())
 
     tracks, lengths, codes = track.result(0)
-    assert tracks.shape == (N, LENGTH, 4)
+    assert tracks.shape == (N, LENGTH, 11 if polarizedTrack else 4)
     assert np.all(tracks[:, 0, :3] == light_pos)
     assert tracks[:, 0, 3].min() >= T0 and tracks[:, 0, 3].max() <= T1
     # since we use a pencil beam in x direction, y and z for the first scatter are still deterministic
@@ -522,6 +522,15 @@ def test_TrackRecordCallback(backend, polarized):
     minCode = min(code.value for code in theia.trace.EventResultCode)
     maxCode = max(code.value for code in theia.trace.EventResultCode)
     assert codes.min() >= minCode and codes.max() <= maxCode
+
+    # check polarization
+    if polarizedTrack and polarized:
+        # only check first one. For later steps we don't know the expected state
+        assert np.isclose(tracks[:, 0, 4:8], stokes).all()
+        assert np.isclose(tracks[:, 0, 8:], polRef).all()
+    elif polarizedTrack:
+        # all states should have been saved as unpolarized with zero reference
+        assert np.isclose(tracks[:, 0, 4:], (1.0, *(0.0,) * 6)).all()
 
 
 @pytest.mark.parametrize("polarized", [False, True])

@@ -43,7 +43,7 @@ FLAG_TARGET_INNER = 1 << 11
 FLAG_PHOTON = 1 << 12
 FLAG_KERNEL_HISTOGRAM = 1 << 13
 N_STATS = 20
-TRACK_WORDS = 12
+TRACK_WORDS = 20
 STAT_NAMES = (
     "created", "scattered", "hit", "detected", "volume", "lost", "decayed", "absorbed", "missed",
     "maxIter", "error", "mismatch",

@@ -115,6 +115,14 @@ THX_DEV void onEvent(Lane<V>& L, const Ray& r, int code, uint32_t i) {
             t[4] = r.direction.x; t[5] = r.direction.y; t[6] = r.direction.z;
             t[7] = r.time; t[8] = r.lin_contrib; t[9] = r.log_contrib;
             t[10] = r.wavelength; t[11] = (float)L.dim;
+            if constexpr (V::POL) {
+                t[12] = r.stokes.x; t[13] = r.stokes.y; t[14] = r.stokes.z; t[15] = r.stokes.w;
+                t[16] = r.polRef.x; t[17] = r.polRef.y; t[18] = r.polRef.z;
+            } else { // callback.track.glsl:84-88
+                t[12] = 1.0f; t[13] = 0.0f; t[14] = 0.0f; t[15] = 0.0f;
+                t[16] = 0.0f; t[17] = 0.0f; t[18] = 0.0f;
+            }
+            t[19] = 0.0f;
         }
     }
 }

@@ -108,16 +108,15 @@ class TrackRecordCallback(TraceEventCallback):
     `length` points per photon (reference: trace.py:189-299, shader/callback.track.glsl).
     `result(i)` -> `(tracks[capacity, length, 4] = x, y, z, t; lengths; codes)`: the index of a
     photon's last event and its result code; points beyond a track's length hold garbage, as
-    in the reference. Selects the instrumented kernel variant with the per-event state dump
-    (`THX_FLAG_TRACK`); `polarized=True` (Stokes vector and reference per point) is not built.
+    in the reference. `polarized=True`: 11 values per point -- x, y, z, t, the Stokes vector
+    i, q, u, v and the polarization reference ((1, 0, 0, 0) and 0 with an unpolarized tracer).
+    Selects the instrumented kernel variant with the per-event state dump (`THX_FLAG_TRACK`).
     """
 
     name = "Track Recorder"
 
     def __init__(self, capacity: int, length: int, *, polarized: bool = False, retrieve: bool = True) -> None:
         super().__init__()
-        if polarized:
-            raise NotImplementedError("TrackRecordCallback(polarized=True) has no kernel variant on the HIP backend")
         self._capacity, self._length, self._polarized, self._retrieve = capacity, length, polarized, retrieve
         self._program = None
         self._batch = [0, 0]
@@ -143,10 +142,12 @@ class TrackRecordCallback(TraceEventCallback):
             # MAX_ITER does not progress the track (callback.track.glsl:29-30)
             stop = np.argmax(code < 0, axis=1)
             last = np.where(code[np.arange(n), stop] == int(EventResultCode.MAX_ITER), stop - 1, stop)
-            tracks = np.zeros((self._capacity, self._length, 4), dtype=np.float32)
+            tracks = np.zeros((self._capacity, self._length, 11 if self._polarized else 4), dtype=np.float32)
             m = min(ev, self._length)
             tracks[:n, :m, :3] = dump[:n, :m, 1:4]
             tracks[:n, :m, 3] = dump[:n, :m, 7]
+            if self._polarized:
+                tracks[:n, :m, 4:11] = dump[:n, :m, 12:19]
             lengths = np.zeros(self._capacity, dtype=np.uint32)
             codes = np.zeros(self._capacity, dtype=np.int32)
             lengths[:n] = last
