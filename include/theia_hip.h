@@ -49,7 +49,8 @@ typedef struct {
 
 /* SphericalLightSource: src/theia/light.py:1132-1139; shader/lightsource.spherical.glsl:7-14.
  * PencilLightSource (THX_FLAG_LIGHT_PENCIL): light.py:1065-1073; shader/lightsource.pencil.glsl:4-16
- * -- contribFwd carries its budget, direction / stokes / polRef are read by it only */
+ * -- contribFwd carries its budget, direction / stokes / polRef are read by it and the cone only.
+ * ConeLightSource (THX_FLAG_LIGHT_CONE): light.py:935-945; shader/lightsource.cone.glsl:6-20 */
 typedef struct {
     float position[3];
     float contribFwd;
@@ -58,13 +59,15 @@ typedef struct {
     float direction[3];
     float stokes[4];
     float polRef[3];
+    float cosOpeningAngle;
 } thx_light_params;
 
-/* src/theia/light.py:272-273 (const) / :308-312 (uniform) */
+/* src/theia/light.py:272-273 (const) / :308-312 (uniform) / :393-394 (function) */
 typedef struct {
     float p0; /* const: lambda | uniform: lam_min */
     float p1; /*               | uniform: lam_max */
-    float p2; /*               | uniform: contrib */
+    float p2; /*               | uniform: contrib | function: contrib */
+    uint32_t table[2]; /* FunctionWavelengthSource: device address of its Table1D (inverse CDF) */
 } thx_wavelength_params;
 
 /* src/theia/target.py:105-112; shader/target.sphere.glsl:8-16 */
@@ -141,7 +144,12 @@ typedef struct {
  * every item of an input hit queue of `capacity` entries (uploaded with thx_tracer_write_hits;
  * THX_FLAG_POLARIZED = the queue has the stokes / polRef columns) is fed to the response with
  * idx = its position in the queue and RNG dimension 0 */
-enum { THX_TRACER_VOLUME_FORWARD = 0, THX_TRACER_SCENE_FORWARD = 1, THX_TRACER_HIT_REPLAY = 2 };
+enum { THX_TRACER_VOLUME_FORWARD = 0, THX_TRACER_SCENE_FORWARD = 1, THX_TRACER_HIT_REPLAY = 2, THX_TRACER_LIGHT_SAMPLER = 3 };
+/* THX_TRACER_LIGHT_SAMPLER: LightSampler (light.py:492-689, shader/lightsource.sample.glsl): no
+ * tracing, sample idx + photon_offset (its `baseCount`) of the wavelength and light source selected by
+ * the flags is written to item idx of two queues of `capacity` entries (dispatch.batchSize = its
+ * `count`, volume.medium = its `medium`; THX_FLAG_POLARIZED = POLARIZATION and LIGHT_QUEUE_POLARIZED
+ * of the output); read with thx_tracer_read_samples */
 
 /* compile-time macros of the reference's shaders (trace.py:660-666, 1226-1235) */
 enum {
@@ -156,6 +164,13 @@ enum {
     THX_FLAG_TRACK                 = 1u << 9, /* per-event state dump (parity probe, TrackRecordCallback) */
     THX_FLAG_LIGHT_PENCIL          = 1u << 10, /* PencilLightSource, else SphericalLightSource */
     THX_FLAG_KERNEL_HISTOGRAM      = 1u << 13, /* histogram response smears every hit with a Gaussian kernel */
+    THX_FLAG_LIGHT_HOST            = 1u << 14, /* HostLightSource (light.py:692-772, lightsource.host.glsl): photon k of a
+                                                  batch starts as item k of the queue uploaded with thx_tracer_write_light */
+    THX_FLAG_LIGHT_QUEUE_POLARIZED = 1u << 15, /* LIGHT_QUEUE_POLARIZED: that queue has the stokes / polRef columns */
+    THX_FLAG_WAVELENGTH_HOST       = 1u << 16, /* HostWavelengthSource (light.py:87-150): thx_tracer_write_wavelengths */
+    THX_FLAG_LIGHT_CONE            = 1u << 17, /* ConeLightSource (lightsource.cone.glsl) */
+    THX_FLAG_LIGHT_POLARIZED       = 1u << 18, /* LIGHTSOURCE_POLARIZED of the cone source */
+    THX_FLAG_WAVELENGTH_FUNCTION   = 1u << 19, /* FunctionWavelengthSource (wavelengthsource.function.glsl) */
     THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
                                                   absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;
@@ -180,7 +195,9 @@ typedef struct {
     uint32_t response_kind; /* THX_RESPONSE_* */
     uint32_t hit_capacity;  /* HIT_QUEUE_SIZE macro (record response), response.py:261-266 */
     uint32_t hit_polarized; /* HIT_QUEUE_POLARIZED macro */
-    uint32_t reserved[3];
+    uint32_t light_queue_capacity;      /* LIGHT_QUEUE_SIZE of a HostLightSource (0: none) */
+    uint32_t wavelength_queue_capacity; /* PHOTON_QUEUE_SIZE of a HostWavelengthSource (0: none) */
+    uint32_t reserved[1];
 } thx_tracer_desc;
 
 /* which `response(HitItem)` the tracer is built with:
@@ -275,6 +292,18 @@ size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized);
 size_t thx_time_queue_bytes(uint32_t hit_capacity, uint32_t store_object_id); /* THX_RESPONSE_STORE_TIME queue */
 int thx_tracer_read_hits(thx_tracer* tracer, void* out, size_t nbytes, int clear);
 int thx_tracer_hits_device_ptr(thx_tracer* tracer, uint64_t* dev_addr);
+/* HostLightSource / HostWavelengthSource input (replace hephaistos IOQueue(mode="update",
+ * skipCounter=True) of light.py:120, 735): copy a host queue without counter -- columns of
+ * light_queue_capacity floats posX posY posZ dirX dirY dirZ [stokesI Q U V polX polY polZ]
+ * startTime contrib (lightsource.queue.glsl:10-30), resp. wavelength_queue_capacity floats
+ * wavelength contrib (wavelengthsource.queue.glsl:10-13) -- to the device queue the next run of
+ * pipeline config `cfg` reads */
+int thx_tracer_write_light(thx_tracer* tracer, uint32_t cfg, const void* src, size_t nbytes);
+int thx_tracer_write_wavelengths(thx_tracer* tracer, uint32_t cfg, const void* src, size_t nbytes);
+/* LightSampler output (replaces IOQueue(mode="retrieve") of light.py:607-610): both queues of the
+ * last run, each uint32 count + columns of `capacity` entries (light: 8 or 15 columns) */
+int thx_tracer_read_samples(thx_tracer* tracer, void* light_out, size_t light_nbytes, void* wavelength_out,
+                            size_t wavelength_nbytes);
 /* HitReplay input (replaces hephaistos IOQueue(mode="update") of response.py:357-359): copies a
  * host queue (uint32 count + SoA columns of `capacity` entries, layout of thx_hit_queue_bytes
  * (capacity, polarized)) to the device queue the next THX_TRACER_HIT_REPLAY runs read */

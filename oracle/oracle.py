@@ -27,6 +27,12 @@ FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_TARGET_INNER = 1 << 11
 FLAG_KERNEL_HISTOGRAM = 1 << 13
 FLAG_BRUTE_FORCE = 1 << 7
+FLAG_LIGHT_HOST = 1 << 14
+FLAG_LIGHT_QUEUE_POLARIZED = 1 << 15
+FLAG_WAVELENGTH_HOST = 1 << 16
+FLAG_LIGHT_CONE = 1 << 17
+FLAG_LIGHT_POLARIZED = 1 << 18
+FLAG_WAVELENGTH_FUNCTION = 1 << 19
 TRACK_WORDS = 20
 N_STATS = 20
 
@@ -41,11 +47,11 @@ class PhiloxParams(_P):
 
 class LightParams(_P):
     _fields_ = [("position", C.c_float * 3), ("contribFwd", C.c_float), ("contribBwd", C.c_float), ("t_min", C.c_float), ("t_max", C.c_float),
-                ("direction", C.c_float * 3), ("stokes", C.c_float * 4), ("polRef", C.c_float * 3)]
+                ("direction", C.c_float * 3), ("stokes", C.c_float * 4), ("polRef", C.c_float * 3), ("cosOpeningAngle", C.c_float)]
 
 
 class WavelengthParams(_P):
-    _fields_ = [("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float)]
+    _fields_ = [("p0", C.c_float), ("p1", C.c_float), ("p2", C.c_float), ("table", C.c_uint32 * 2)]
 
 
 class TargetParams(_P):
@@ -243,6 +249,35 @@ def trace_volume(common: Common, trace: VolumeTraceParams, target: TargetParams,
     if rc != 0:
         raise RuntimeError(f"orc_trace_volume failed: {rc}")
     return hist, stats, tr
+
+
+def set_light_queue(queue: np.ndarray | None, capacity: int = 0) -> None:
+    """HostLightSource: float32 SoA queue (no counter) the next traces / samplers read"""
+    fn = lib().orc_set_light_queue
+    fn.argtypes = [C.c_void_p, C.c_uint32]
+    fn.restype = None
+    fn(queue.ctypes.data if queue is not None else None, int(capacity))
+
+
+def set_wavelength_queue(queue: np.ndarray | None, capacity: int = 0) -> None:
+    """HostWavelengthSource: float32 SoA queue (wavelength[cap], contrib[cap])"""
+    fn = lib().orc_set_wavelength_queue
+    fn.argtypes = [C.c_void_p, C.c_uint32]
+    fn.restype = None
+    fn(queue.ctypes.data if queue is not None else None, int(capacity))
+
+
+def sample_light(common: Common, medium: int, count: int, base: int, polarized: bool, capacity: int):
+    """LightSampler: -> (light queue, wavelength queue) as uint32 arrays (count + columns)"""
+    fn = lib().orc_sample_light
+    fn.argtypes = [C.POINTER(Common), C.c_uint64, C.c_uint32, C.c_uint32, C.c_int, C.c_uint32, C.c_void_p, C.c_void_p]
+    fn.restype = C.c_int
+    light = np.zeros(1 + (15 if polarized else 8) * capacity, dtype=np.uint32)
+    lam = np.zeros(1 + 2 * capacity, dtype=np.uint32)
+    rc = fn(C.byref(common), int(medium), int(count), int(base), int(bool(polarized)), int(capacity), light.ctypes.data, lam.ctypes.data)
+    if rc != 0:
+        raise RuntimeError(f"orc_sample_light failed: {rc}")
+    return light, lam
 
 
 def replay(common: Common, queue: np.ndarray, capacity: int, polarized: bool, *, threads: int = 0):

@@ -761,66 +761,174 @@ static vec3 sphericalToCartessian(float phi, float cos_theta) {
     return V3(sin_theta * sinf(phi), sin_theta * cosf(phi), cos_theta);
 }
 
-/* tracer.*.forward.glsl sampleRay; wavelengthsource.const.glsl:10-12,
- * wavelengthsource.uniform.glsl:12-16; lightsource.spherical.glsl:16-34;
- * lightsource.common.glsl:59-86; ray.glsl:38-79,188-211 */
-static Ray sampleRay(Ctx* x, uint64_t medium, uint32_t idx, uint32_t* dim) {
+/* HostLightSource / HostWavelengthSource queues (NULL: not set) */
+static const float* g_light_queue = NULL;
+static uint32_t g_light_capacity = 0;
+static const float* g_lam_queue = NULL;
+static uint32_t g_lam_capacity = 0;
+void orc_set_light_queue(const float* queue, uint32_t capacity) { g_light_queue = queue; g_light_capacity = capacity; }
+void orc_set_wavelength_queue(const float* queue, uint32_t capacity) { g_lam_queue = queue; g_lam_capacity = capacity; }
+
+typedef struct { float wavelength, contrib; } WavelengthSample;
+/* lightsource.common.glsl:12-26 */
+typedef struct {
+    vec3 position, direction;
+    vec4 stokes;
+    vec3 polRef;
+    float startTime, contrib;
+} SourceRay;
+
+/* wavelengthsource.const.glsl:10-12, wavelengthsource.uniform.glsl:12-16,
+ * wavelengthsource.function.glsl:13-16, wavelengthsource.host.glsl:10-13.
+ * `item`: index into a host queue (the reference's idx) */
+static WavelengthSample sampleWavelength(Ctx* x, uint32_t idx, uint32_t item, uint32_t* dim) {
     const orc_common* c = x->c;
-    float wavelength, wcontrib;
-    if (c->flags & ORC_FLAG_WAVELENGTH_UNIFORM) {
+    WavelengthSample w;
+    if (c->flags & ORC_FLAG_WAVELENGTH_HOST) {
+        w.wavelength = g_lam_queue[item];
+        w.contrib = g_lam_queue[(size_t)g_lam_capacity + item];
+    } else if (c->flags & ORC_FLAG_WAVELENGTH_FUNCTION) {
+        uint64_t table = (uint64_t)c->wavelength.table[0] | ((uint64_t)c->wavelength.table[1] << 32);
+        w.wavelength = lookUp(table, rnd(x, idx, dim), 0.0f, &x->cnt);
+        w.contrib = c->wavelength.p2;
+    } else if (c->flags & ORC_FLAG_WAVELENGTH_UNIFORM) {
         float u = rnd(x, idx, dim);
-        wavelength = f_mix(c->wavelength.p0, c->wavelength.p1, u);
-        wcontrib = c->wavelength.p2;
+        w.wavelength = f_mix(c->wavelength.p0, c->wavelength.p1, u);
+        w.contrib = c->wavelength.p2;
     } else {
-        wavelength = c->wavelength.p0;
-        wcontrib = 1.0f;
+        w.wavelength = c->wavelength.p0;
+        w.contrib = 1.0f;
     }
-    MediumConstants constants = lookUpMedium(medium, wavelength, &x->cnt);
-    if (c->flags & ORC_FLAG_LIGHT_PENCIL) { /* lightsource.pencil.glsl:18-35 */
-        float v = rnd(x, idx, dim);
-        Ray r;
-        memset(&r, 0, sizeof(r));
-        r.position = V3(c->light.position[0], c->light.position[1], c->light.position[2]);
-        r.direction = V3(c->light.direction[0], c->light.direction[1], c->light.direction[2]);
-        r.medium = medium;
-        r.wavelength = wavelength;
-        r.time = f_mix(c->light.t_min, c->light.t_max, v);
-        r.lin_contrib = wcontrib * c->light.contribFwd;
-        r.log_contrib = 0.0f;
-        r.constants = constants;
-        if (x->polarized) { /* lightsource.common.glsl:88-112 */
-            r.stokes.x = c->light.stokes[0]; r.stokes.y = c->light.stokes[1];
-            r.stokes.z = c->light.stokes[2]; r.stokes.w = c->light.stokes[3];
-            r.polRef = V3(c->light.polRef[0], c->light.polRef[1], c->light.polRef[2]);
+    return w;
+}
+
+/* lightsource.common.glsl:59-86: unpolarized source ray in a polarized environment */
+static SourceRay unpolarizedSourceRay(Ctx* x, vec3 position, vec3 direction, float startTime, float contrib) {
+    SourceRay r;
+    memset(&r, 0, sizeof(r));
+    r.position = position; r.direction = direction; r.startTime = startTime; r.contrib = contrib;
+    if (x->polarized) {
+        r.stokes.x = 1.0f;
+        r.polRef = createLocalCOSY(direction).c0;
+    }
+    return r;
+}
+/* lightsource.common.glsl:88-112 */
+static SourceRay polarizedSourceRay(Ctx* x, vec3 position, vec3 direction, vec4 stokes, vec3 polRef,
+                                    float startTime, float contrib) {
+    SourceRay r;
+    memset(&r, 0, sizeof(r));
+    r.position = position; r.direction = direction; r.startTime = startTime; r.contrib = contrib;
+    if (x->polarized) { r.stokes = stokes; r.polRef = polRef; }
+    return r;
+}
+
+/* lightsource.host.glsl:12-19, lightsource.cone.glsl:22-72, lightsource.pencil.glsl:18-35,
+ * lightsource.spherical.glsl:16-34 */
+static SourceRay sampleLight(Ctx* x, uint32_t idx, uint32_t item, uint32_t* dim) {
+    const orc_common* c = x->c;
+    vec3 lightPos = V3(c->light.position[0], c->light.position[1], c->light.position[2]);
+    if (c->flags & ORC_FLAG_LIGHT_HOST) { /* LOAD_SAMPLE of lightsource.queue.glsl */
+        const float* q = g_light_queue + item;
+        const size_t cap = g_light_capacity;
+        vec3 pos = V3(q[0], q[cap], q[2 * cap]);
+        vec3 dir = V3(q[3 * cap], q[4 * cap], q[5 * cap]);
+        if (c->flags & ORC_FLAG_LIGHT_QUEUE_POLARIZED) {
+            vec4 stokes; stokes.x = q[6 * cap]; stokes.y = q[7 * cap]; stokes.z = q[8 * cap]; stokes.w = q[9 * cap];
+            vec3 polRef = V3(q[10 * cap], q[11 * cap], q[12 * cap]);
+            return polarizedSourceRay(x, pos, dir, stokes, polRef, q[13 * cap], q[14 * cap]);
         }
-        if (g_photon_steps_per_run) r.lin_contrib = 1.0f; /* tracer.scene.photon.init.glsl:49-53 */
-        return r;
+        return unpolarizedSourceRay(x, pos, dir, q[6 * cap], q[7 * cap]);
     }
-    /* sampleLight */
+    if (c->flags & ORC_FLAG_LIGHT_CONE) {
+        float u0 = rnd(x, idx, dim);
+        float u1 = rnd(x, idx, dim);
+        float phi = TWO_PI_F * u0;
+        float cos_theta = (1.0f - u1) + c->light.cosOpeningAngle * u1;
+        float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+        vec3 localDir = V3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+        mat3 trafo = createLocalCOSY(v_normalize(V3(c->light.direction[0], c->light.direction[1], c->light.direction[2])));
+        vec3 rayDir = m3_mul(trafo, localDir);
+        float v = rnd(x, idx, dim);
+        float startTime = f_mix(c->light.t_min, c->light.t_max, v);
+        if (c->flags & ORC_FLAG_LIGHT_POLARIZED) {
+            vec3 polRef = V3(c->light.polRef[0], c->light.polRef[1], c->light.polRef[2]);
+            polRef = v_sub(polRef, v_scale(rayDir, v_dot(polRef, rayDir)));
+            polRef = v_normalize(polRef);
+            vec4 stokes; stokes.x = c->light.stokes[0]; stokes.y = c->light.stokes[1];
+            stokes.z = c->light.stokes[2]; stokes.w = c->light.stokes[3];
+            return polarizedSourceRay(x, lightPos, rayDir, stokes, polRef, startTime, c->light.contribFwd);
+        }
+        return unpolarizedSourceRay(x, lightPos, rayDir, startTime, c->light.contribFwd);
+    }
+    if (c->flags & ORC_FLAG_LIGHT_PENCIL) {
+        float v = rnd(x, idx, dim);
+        vec4 stokes; stokes.x = c->light.stokes[0]; stokes.y = c->light.stokes[1];
+        stokes.z = c->light.stokes[2]; stokes.w = c->light.stokes[3];
+        return polarizedSourceRay(x, lightPos, V3(c->light.direction[0], c->light.direction[1], c->light.direction[2]),
+                                  stokes, V3(c->light.polRef[0], c->light.polRef[1], c->light.polRef[2]),
+                                  f_mix(c->light.t_min, c->light.t_max, v), c->light.contribFwd);
+    }
     float u0 = rnd(x, idx, dim);
     float u1 = rnd(x, idx, dim);
-    float phi = TWO_PI_F * u0;
-    float cos_theta = 2.0f * u1 - 1.0f;
-    vec3 rayDir = sphericalToCartessian(phi, cos_theta);
+    vec3 rayDir = sphericalToCartessian(TWO_PI_F * u0, 2.0f * u1 - 1.0f);
     float v = rnd(x, idx, dim);
-    float startTime = f_mix(c->light.t_min, c->light.t_max, v);
+    return unpolarizedSourceRay(x, lightPos, rayDir, f_mix(c->light.t_min, c->light.t_max, v), c->light.contribFwd);
+}
 
+/* tracer.*.forward.glsl sampleRay; ray.glsl:38-79, 188-211 */
+static Ray sampleRay(Ctx* x, uint64_t medium, uint32_t idx, uint32_t* dim) {
+    const uint32_t item = idx - x->c->photon_offset; /* position in the batch */
+    WavelengthSample photon = sampleWavelength(x, idx, item, dim);
+    MediumConstants constants = lookUpMedium(medium, photon.wavelength, &x->cnt);
+    SourceRay s = sampleLight(x, idx, item, dim);
     Ray r;
     memset(&r, 0, sizeof(r));
-    r.position = V3(c->light.position[0], c->light.position[1], c->light.position[2]);
-    r.direction = rayDir;
+    r.position = s.position;
+    r.direction = s.direction;
     r.medium = medium;
-    r.wavelength = wavelength;
-    r.time = startTime;
-    r.lin_contrib = wcontrib * c->light.contribFwd;
+    r.wavelength = photon.wavelength;
+    r.time = s.startTime;
+    r.lin_contrib = photon.contrib * s.contrib;
     r.log_contrib = 0.0f;
     r.constants = constants;
-    if (x->polarized) {
-        r.stokes.x = 1.0f; r.stokes.y = 0.0f; r.stokes.z = 0.0f; r.stokes.w = 0.0f;
-        r.polRef = createLocalCOSY(rayDir).c0;
-    }
+    r.stokes = s.stokes;
+    r.polRef = s.polRef;
     if (g_photon_steps_per_run) r.lin_contrib = 1.0f; /* tracer.scene.photon.init.glsl:49-53 */
     return r;
+}
+
+/* lightsource.sample.glsl:52-75 */
+int orc_sample_light(const orc_common* c, uint64_t medium, uint32_t count, uint32_t base, int polarized,
+                     uint32_t capacity, uint32_t* light_out, uint32_t* wavelength_out) {
+    Ctx x;
+    memset(&x, 0, sizeof(x));
+    x.c = c;
+    x.polarized = polarized != 0;
+    if (count > capacity) return -1;
+    for (uint32_t idx = 0; idx < count; ++idx) {
+        uint32_t dim = 0;
+        WavelengthSample photon = sampleWavelength(&x, idx + base, idx + base, &dim);
+        (void)lookUpMedium(medium, photon.wavelength, &x.cnt);
+        SourceRay ray = sampleLight(&x, idx + base, idx + base, &dim);
+        float* col = (float*)(light_out + 1) + idx;
+        const size_t cap = capacity;
+#define PUT(v) do { *col = (v); col += cap; } while (0)
+        PUT(ray.position.x); PUT(ray.position.y); PUT(ray.position.z);
+        PUT(ray.direction.x); PUT(ray.direction.y); PUT(ray.direction.z);
+        if (polarized) {
+            PUT(ray.stokes.x); PUT(ray.stokes.y); PUT(ray.stokes.z); PUT(ray.stokes.w);
+            PUT(ray.polRef.x); PUT(ray.polRef.y); PUT(ray.polRef.z);
+        }
+        PUT(ray.startTime); PUT(ray.contrib);
+#undef PUT
+        float* w = (float*)(wavelength_out + 1) + idx;
+        w[0] = photon.wavelength;
+        w[cap] = photon.contrib;
+    }
+    light_out[0] = count;
+    wavelength_out[0] = count;
+    return 0;
 }
 
 /* ------------------------------------------------------------------------ */

@@ -110,7 +110,9 @@ class OracleBackend:
         t = self._tracers[tracer]
         spec = t.spec
         c = orc.Common()
-        flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER | capi.FLAG_KERNEL_HISTOGRAM))
+        flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER | capi.FLAG_KERNEL_HISTOGRAM |
+                                                     capi.FLAG_LIGHT_HOST | capi.FLAG_LIGHT_QUEUE_POLARIZED | capi.FLAG_WAVELENGTH_HOST |
+                                                     capi.FLAG_LIGHT_CONE | capi.FLAG_LIGHT_POLARIZED | capi.FLAG_WAVELENGTH_FUNCTION))
         photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE
@@ -138,6 +140,10 @@ class OracleBackend:
                 orc.set_hit_queue(t.hits, spec.hit_capacity, spec.hit_polarized)
         if photon:
             orc.set_photon_mode(params.photon_steps_per_run, params.photon_rng_per_run)
+        if spec.flags & capi.FLAG_LIGHT_HOST:
+            orc.set_light_queue(t.light_in[cfg], spec.light_queue_capacity)
+        if spec.flags & capi.FLAG_WAVELENGTH_HOST:
+            orc.set_wavelength_queue(t.lam_in[cfg], spec.wavelength_queue_capacity)
         try:
             hist, stats, track = self._trace(spec, t, c, params, want_track)
         finally:
@@ -146,14 +152,36 @@ class OracleBackend:
                 orc.set_time_queue(None, 0, False)
             if photon:
                 orc.set_photon_mode(0, 0)
+            orc.set_light_queue(None)
+            orc.set_wavelength_queue(None)
         t.raw[cfg] = hist
         t.stats += stats
         t.track = track
+
+    def tracer_write_light(self, tracer: int, cfg: int, data: np.ndarray) -> None:
+        t = self._tracers[tracer]
+        t.light_in = getattr(t, "light_in", [None, None])
+        t.light_in[cfg] = np.array(data, copy=True).view(np.uint8).view(np.float32)
+
+    def tracer_write_wavelengths(self, tracer: int, cfg: int, data: np.ndarray) -> None:
+        t = self._tracers[tracer]
+        t.lam_in = getattr(t, "lam_in", [None, None])
+        t.lam_in[cfg] = np.array(data, copy=True).view(np.uint8).view(np.float32)
+
+    def tracer_read_samples(self, tracer: int, light_out: np.ndarray, wavelength_out: np.ndarray) -> None:
+        t = self._tracers[tracer]
+        light_out.reshape(-1).view(np.uint8)[:] = t.samples[0].view(np.uint8)
+        wavelength_out.reshape(-1).view(np.uint8)[:] = t.samples[1].view(np.uint8)
 
     def tracer_write_hits(self, tracer: int, data: np.ndarray) -> None:
         self._tracers[tracer].replay_in = np.array(data, dtype=np.uint8, copy=True)
 
     def _trace(self, spec, t, c, params, want_track):
+        if spec.kind == capi.TRACER_LIGHT_SAMPLER:
+            medium = int(params.volume.medium[0]) | (int(params.volume.medium[1]) << 32)
+            t.samples = orc.sample_light(c, medium, params.dispatch.batchSize, params.photon_offset,
+                                         bool(spec.flags & capi.FLAG_POLARIZED), spec.capacity)
+            return np.zeros(1, np.float32), np.zeros(orc.N_STATS, np.uint64), None
         if spec.kind == capi.TRACER_HIT_REPLAY:
             c.batch_size = spec.capacity
             hist, stats = orc.replay(c, t.replay_in, spec.capacity, bool(spec.flags & capi.FLAG_POLARIZED), threads=self.threads)

@@ -29,8 +29,9 @@ def test_library_exports_every_declared_symbol():
 
 def test_parameter_block_layouts():
     # scalar layout sizes of the reference UBOs
-    # the light block is the spherical source's UBO (28 B) followed by what only the pencil source reads
-    assert C.sizeof(capi.PhiloxParams) == 24 and C.sizeof(capi.LightParams) == 28 + 40 and capi.LightParams.direction.offset == 28
+    # the light block is the spherical source's UBO (28 B) followed by what only the pencil / cone sources read
+    assert C.sizeof(capi.PhiloxParams) == 24 and C.sizeof(capi.LightParams) == 28 + 40 + 4 and capi.LightParams.direction.offset == 28
+    assert C.sizeof(capi.WavelengthParams) == 12 + 8  # + table address of the function source
     assert C.sizeof(capi.TargetParams) == 36 and C.sizeof(capi.GuideParams) == 20
     assert C.sizeof(capi.PropagateParams) == 36
     assert C.sizeof(capi.VolumeTraceParams) == 48 and C.sizeof(capi.SceneTraceParams) == 48
@@ -51,6 +52,10 @@ def test_parameter_block_layouts():
 
     assert C.sizeof(SphericalLightSource.LightParams) == capi.LightParams.direction.offset
     assert C.sizeof(PencilLightSource.LightParams) == 64  # light.py:1065-1073
+    from theia_amd.light import ConeLightSource, LightSampler
+
+    assert C.sizeof(ConeLightSource.LightParams) == 72  # light.py:935-945
+    assert C.sizeof(LightSampler.SampleParams) == 16  # light.py:538-543
     assert C.sizeof(PhiloxRNG.PhiloxParams) == C.sizeof(capi.PhiloxParams)
     assert C.sizeof(SphereTarget.TargetParams) == C.sizeof(capi.TargetParams)
     assert C.sizeof(SphereTargetGuide.TargetGuideParams) == C.sizeof(capi.GuideParams)

@@ -31,6 +31,8 @@ class TracerSpec:
     response_kind: int = 0   # capi.RESPONSE_*
     hit_capacity: int = 0    # HitRecorder queue size
     hit_polarized: bool = False
+    light_queue_capacity: int = 0       # HostLightSource queue size
+    wavelength_queue_capacity: int = 0  # HostWavelengthSource queue size
 
 
 class HipBackend:
@@ -131,7 +133,8 @@ class HipBackend:
     # -- tracer ------------------------------------------------------------
     def tracer_create(self, spec: TracerSpec, scene: int | None) -> int:
         desc = capi.TracerDesc(spec.kind, spec.flags, spec.path_length, spec.block_size, spec.n_bins, spec.capacity,
-                               spec.response_kind, spec.hit_capacity, int(spec.hit_polarized))
+                               spec.response_kind, spec.hit_capacity, int(spec.hit_polarized), spec.light_queue_capacity,
+                               spec.wavelength_queue_capacity)
         handle = C.c_void_p()
         capi.check(self._lib.thx_tracer_create(self._ctx, C.byref(desc), C.c_void_p(scene) if scene else None, C.byref(handle)))
         return handle.value
@@ -171,6 +174,20 @@ class HipBackend:
     def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True) -> None:
         """copies the HitRecorder queue into `out` (uint8) and resets its counter"""
         capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
+
+    def tracer_write_light(self, tracer: int, cfg: int, data: np.ndarray) -> None:
+        """uploads a HostLightSource queue (uint8, SoA columns without counter) for pipeline config `cfg`"""
+        data = np.ascontiguousarray(data)
+        capi.check(self._lib.thx_tracer_write_light(C.c_void_p(tracer), int(cfg), data.ctypes.data_as(C.c_void_p), data.nbytes))
+
+    def tracer_write_wavelengths(self, tracer: int, cfg: int, data: np.ndarray) -> None:
+        data = np.ascontiguousarray(data)
+        capi.check(self._lib.thx_tracer_write_wavelengths(C.c_void_p(tracer), int(cfg), data.ctypes.data_as(C.c_void_p), data.nbytes))
+
+    def tracer_read_samples(self, tracer: int, light_out: np.ndarray, wavelength_out: np.ndarray) -> None:
+        """copies the two output queues of a light sampler (uint8: count + SoA columns)"""
+        capi.check(self._lib.thx_tracer_read_samples(C.c_void_p(tracer), light_out.ctypes.data_as(C.c_void_p), light_out.nbytes,
+                                                     wavelength_out.ctypes.data_as(C.c_void_p), wavelength_out.nbytes))
 
     def tracer_write_hits(self, tracer: int, data: np.ndarray) -> None:
         """uploads the input queue (uint8, count + SoA columns) of a hit replay"""

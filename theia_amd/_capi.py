@@ -21,11 +21,14 @@ __all__ = [
     "FLAG_POLARIZED", "FLAG_DISABLE_DIRECT", "FLAG_DISABLE_MIS", "FLAG_DISABLE_TRANSMISSION",
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
     "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "FLAG_KERNEL_HISTOGRAM", "EXPORTED_SYMBOLS",
+    "FLAG_LIGHT_HOST", "FLAG_LIGHT_QUEUE_POLARIZED", "FLAG_WAVELENGTH_HOST", "FLAG_LIGHT_CONE", "FLAG_LIGHT_POLARIZED",
+    "FLAG_WAVELENGTH_FUNCTION", "TRACER_LIGHT_SAMPLER",
 ]
 
 TRACER_VOLUME_FORWARD = 0
 TRACER_SCENE_FORWARD = 1
 TRACER_HIT_REPLAY = 2
+TRACER_LIGHT_SAMPLER = 3
 RESPONSE_HISTOGRAM = 0
 RESPONSE_RECORD = 1
 RESPONSE_STORE_TIME = 2
@@ -42,6 +45,12 @@ FLAG_LIGHT_PENCIL = 1 << 10
 FLAG_TARGET_INNER = 1 << 11
 FLAG_PHOTON = 1 << 12
 FLAG_KERNEL_HISTOGRAM = 1 << 13
+FLAG_LIGHT_HOST = 1 << 14
+FLAG_LIGHT_QUEUE_POLARIZED = 1 << 15
+FLAG_WAVELENGTH_HOST = 1 << 16
+FLAG_LIGHT_CONE = 1 << 17
+FLAG_LIGHT_POLARIZED = 1 << 18
+FLAG_WAVELENGTH_FUNCTION = 1 << 19
 N_STATS = 20
 TRACK_WORDS = 20
 STAT_NAMES = (
@@ -73,11 +82,11 @@ class PhiloxParams(_Packed):
 
 class LightParams(_Packed):
     _fields_ = [("position", c_float * 3), ("contribFwd", c_float), ("contribBwd", c_float), ("t_min", c_float), ("t_max", c_float),
-                ("direction", c_float * 3), ("stokes", c_float * 4), ("polRef", c_float * 3)]
+                ("direction", c_float * 3), ("stokes", c_float * 4), ("polRef", c_float * 3), ("cosOpeningAngle", c_float)]
 
 
 class WavelengthParams(_Packed):
-    _fields_ = [("p0", c_float), ("p1", c_float), ("p2", c_float)]
+    _fields_ = [("p0", c_float), ("p1", c_float), ("p2", c_float), ("table", c_uint32 * 2)]
 
 
 class TargetParams(_Packed):
@@ -125,7 +134,8 @@ class TracerDesc(Structure):
     _fields_ = [
         ("kind", c_uint32), ("flags", c_uint32), ("path_length", c_uint32), ("block_size", c_uint32),
         ("n_bins", c_uint32), ("capacity", c_uint32), ("response_kind", c_uint32), ("hit_capacity", c_uint32),
-        ("hit_polarized", c_uint32), ("reserved", c_uint32 * 3),
+        ("hit_polarized", c_uint32), ("light_queue_capacity", c_uint32), ("wavelength_queue_capacity", c_uint32),
+        ("reserved", c_uint32 * 1),
     ]
 
 
@@ -177,6 +187,9 @@ _PROTOS = {
     "thx_tracer_read_hits": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
     "thx_tracer_hits_device_ptr": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_write_hits": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "thx_tracer_write_light": (c_int, [c_void_p, c_uint32, c_void_p, c_size_t]),
+    "thx_tracer_write_wavelengths": (c_int, [c_void_p, c_uint32, c_void_p, c_size_t]),
+    "thx_tracer_read_samples": (c_int, [c_void_p, c_void_p, c_size_t, c_void_p, c_size_t]),
     "thx_tracer_launch_info": (c_int, [c_void_p, c_uint32, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint32)]),
     "thx_tracer_last_kernel_ms": (c_int, [c_void_p, c_uint32, POINTER(c_float)]),
     "thx_tracer_kernel_times": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_uint32)]),

@@ -1,0 +1,91 @@
+"""The handle a tracer / replay / sampler stage owns on the backend (stands where `hp.Program` stood)."""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _backend
+from . import _capi as capi
+
+__all__ = ["_Program"]
+
+
+class _Program:
+    """The compiled-variant handle a tracer owns (stands where hp.Program stood).
+    Created lazily so that building stages does not need a device."""
+
+    def __init__(self, spec: _backend.TracerSpec, scene: Scene | None) -> None:
+        self._spec = spec
+        self._scene = scene
+        self._handle = None
+        self._be = None
+        self.last_batch = 0
+
+    @property
+    def created(self) -> bool:
+        return self._handle is not None
+
+    @property
+    def handle(self) -> int:
+        if self._handle is None:
+            self._be = _backend.get()
+            self._handle = self._be.tracer_create(self._spec, self._scene.handle if self._scene is not None else None)
+        return self._handle
+
+    @property
+    def backend(self):
+        self.handle
+        return self._be
+
+    def run(self, cfg: int, params: capi.RunParams) -> None:
+        self.last_batch = int(params.dispatch.batchSize)
+        self.backend.tracer_run(self.handle, cfg, params)
+
+    def reduce(self, cfg: int, norm: float, d_out: int = 0) -> None:
+        self.backend.tracer_reduce(self.handle, cfg, norm, d_out)
+
+    def read_hist(self, cfg: int) -> np.ndarray:
+        return self.backend.tracer_read_hist(self.handle, cfg, self._spec.n_bins)
+
+    def hist_ptr(self, cfg: int) -> int:
+        return self.backend.tracer_hist_ptr(self.handle, cfg)
+
+    def read_hits(self, out: np.ndarray, clear: bool = True) -> None:
+        self.backend.tracer_read_hits(self.handle, out, clear)
+
+    def write_hits(self, data: np.ndarray) -> None:
+        self.backend.tracer_write_hits(self.handle, data)
+
+    def write_light(self, cfg: int, data: np.ndarray) -> None:
+        self.backend.tracer_write_light(self.handle, cfg, data)
+
+    def write_wavelengths(self, cfg: int, data: np.ndarray) -> None:
+        self.backend.tracer_write_wavelengths(self.handle, cfg, data)
+
+    def read_samples(self, light_out: np.ndarray, wavelength_out: np.ndarray) -> None:
+        self.backend.tracer_read_samples(self.handle, light_out, wavelength_out)
+
+    def read_stats(self) -> np.ndarray:
+        return self.backend.tracer_read_stats(self.handle)
+
+    def reset_stats(self) -> None:
+        self.backend.tracer_reset_stats(self.handle)
+
+    def read_track(self, batch: int) -> np.ndarray:
+        return self.backend.tracer_read_track(self.handle, batch, self._spec.path_length + 3)
+
+    def launch_info(self, batch: int) -> dict:
+        return self.backend.tracer_launch_info(self.handle, batch)
+
+    def last_kernel_ms(self, cfg: int) -> float:
+        return self.backend.tracer_last_kernel_ms(self.handle, cfg)
+
+    def kernel_times(self, n: int = 64) -> np.ndarray:
+        return self.backend.tracer_kernel_times(self.handle, n)
+
+    def __del__(self) -> None:
+        try:
+            if self._handle is not None:
+                self._be.tracer_destroy(self._handle)
+                self._handle = None
+        except Exception:
+            pass

@@ -76,6 +76,9 @@ struct thx_tracer {
     float* track = nullptr;
     uint32_t* hits = nullptr;     // HitRecorder queue (count + SoA columns) or null
     uint32_t* replayIn = nullptr; // THX_TRACER_HIT_REPLAY: the input hit queue
+    uint32_t* lamOut = nullptr;   // THX_TRACER_LIGHT_SAMPLER: wavelength output queue (light output: `hits`)
+    float* lightIn[2] = {nullptr, nullptr}; // HostLightSource queue per pipeline config
+    float* lamIn[2] = {nullptr, nullptr};   // HostWavelengthSource queue per pipeline config
     uint32_t trackEvents = 0;
     uint32_t lastBatch = 0;
     // ring of HIP event pairs bracketing the tracing kernel on its launch stream
@@ -88,6 +91,7 @@ struct thx_tracer {
 // 4-byte columns of a tracer's hit queue (record: response.queue.glsl:6-33, store time:
 // response.time.store.glsl:4-10)
 static size_t hitColumns(const thx_tracer_desc& d) {
+    if (d.kind == THX_TRACER_LIGHT_SAMPLER) return (d.flags & THX_FLAG_POLARIZED) ? 15 : 8; // lightsource.queue.glsl:10-30
     if (d.response_kind == THX_RESPONSE_STORE_TIME) return d.hit_polarized ? 2 : 1;
     return d.hit_polarized ? 20 : 13;
 }
@@ -321,11 +325,17 @@ int thx_scene_query_ms(const thx_scene* scene, float* ms) {
 int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scene, thx_tracer** out) {
     if (!ctx || !desc || !out) return fail(THX_ERR_INVALID, "null argument");
     *out = nullptr;
-    if (desc->kind > THX_TRACER_HIT_REPLAY) return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
-    const bool replay = desc->kind == THX_TRACER_HIT_REPLAY;
+    if (desc->kind > THX_TRACER_LIGHT_SAMPLER) return fail(THX_ERR_UNSUPPORTED, "unknown tracer kind");
+    const bool sampler = desc->kind == THX_TRACER_LIGHT_SAMPLER;
+    const bool replay = desc->kind == THX_TRACER_HIT_REPLAY || sampler; // no tracing kernel
+    if (((desc->flags & THX_FLAG_LIGHT_HOST) != 0) != (desc->light_queue_capacity != 0) ||
+        ((desc->flags & THX_FLAG_WAVELENGTH_HOST) != 0) != (desc->wavelength_queue_capacity != 0))
+        return fail(THX_ERR_INVALID, "host light / wavelength source flags and queue capacities do not match");
+    if (sampler && (((desc->flags & THX_FLAG_LIGHT_HOST) && ((desc->flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) != 0) != ((desc->flags & THX_FLAG_POLARIZED) != 0))))
+        return fail(THX_ERR_INVALID, "mismatch in light queue definition (lightsource.sample.glsl:28-33)");
     if (desc->kind == THX_TRACER_SCENE_FORWARD && !scene)
         return fail(THX_ERR_INVALID, "scene tracer needs a scene");
-    const bool record = desc->response_kind == THX_RESPONSE_RECORD || desc->response_kind == THX_RESPONSE_STORE_TIME;
+    const bool record = !sampler && (desc->response_kind == THX_RESPONSE_RECORD || desc->response_kind == THX_RESPONSE_STORE_TIME);
     if (desc->response_kind > THX_RESPONSE_STORE_TIME) return fail(THX_ERR_INVALID, "unknown response kind");
     if (record && desc->hit_capacity == 0) return fail(THX_ERR_INVALID, "cannot create a hit queue of size 0 (response.py:266-267)");
     if (!record && (desc->n_bins == 0 || desc->n_bins > 8192))
@@ -337,7 +347,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     t->ctx = ctx;
     t->scene = scene;
     t->desc = *desc;
-    if (record) t->desc.n_bins = 1; // the kernels keep their (unused) one-bin histogram
+    if (record || sampler) t->desc.n_bins = 1; // the kernels keep their (unused) one-bin histogram
+    if (sampler) t->desc.hit_capacity = desc->capacity;
     desc = &t->desc;
     const bool pol = (desc->flags & THX_FLAG_POLARIZED) != 0;
     const bool mis = (desc->flags & THX_FLAG_DISABLE_MIS) == 0;
@@ -427,7 +438,26 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         e = hipMalloc((void**)&t->hits, nb);
         if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
     }
-    if (e == hipSuccess && replay) {
+    if (e == hipSuccess && sampler) {
+        const size_t nb = 4 + hitColumns(*desc) * 4 * (size_t)desc->capacity, nl = 4 + 2 * 4 * (size_t)desc->capacity;
+        e = hipMalloc((void**)&t->hits, nb);
+        if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
+        if (e == hipSuccess) e = hipMalloc((void**)&t->lamOut, nl);
+        if (e == hipSuccess) e = hipMemset(t->lamOut, 0, nl);
+    }
+    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
+        if (desc->light_queue_capacity) {
+            const size_t nb = ((desc->flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) ? 15 : 8) * 4 * (size_t)desc->light_queue_capacity;
+            e = hipMalloc((void**)&t->lightIn[i], nb);
+            if (e == hipSuccess) e = hipMemset(t->lightIn[i], 0, nb);
+        }
+        if (e == hipSuccess && desc->wavelength_queue_capacity) {
+            const size_t nb = 2 * 4 * (size_t)desc->wavelength_queue_capacity;
+            e = hipMalloc((void**)&t->lamIn[i], nb);
+            if (e == hipSuccess) e = hipMemset(t->lamIn[i], 0, nb);
+        }
+    }
+    if (e == hipSuccess && desc->kind == THX_TRACER_HIT_REPLAY) {
         const size_t nb = thx_hit_queue_bytes(desc->capacity, pol);
         e = hipMalloc((void**)&t->replayIn, nb);
         if (e == hipSuccess) e = hipMemset(t->replayIn, 0, nb);
@@ -457,12 +487,17 @@ int thx_tracer_destroy(thx_tracer* t) {
     if (t->track) (void)hipFree(t->track);
     if (t->hits) (void)hipFree(t->hits);
     if (t->replayIn) (void)hipFree(t->replayIn);
+    if (t->lamOut) (void)hipFree(t->lamOut);
+    for (int i = 0; i < 2; ++i) {
+        if (t->lightIn[i]) (void)hipFree(t->lightIn[i]);
+        if (t->lamIn[i]) (void)hipFree(t->lamIn[i]);
+    }
     delete t;
     return THX_OK;
 }
 
 static void launchGeometry(const thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* ppw) {
-    if (t->desc.kind == THX_TRACER_HIT_REPLAY) { // one hit per thread until the chip is full, then grid-stride
+    if (t->desc.kind == THX_TRACER_HIT_REPLAY || t->desc.kind == THX_TRACER_LIGHT_SAMPLER) { // one hit per thread until the chip is full, then grid-stride
         const uint64_t need = ((uint64_t)t->desc.capacity + t->block - 1) / t->block;
         *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, need));
         *ppw = 0;
@@ -525,6 +560,12 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.hit_capacity = t->desc.hit_capacity;
     a.hit_polarized = t->desc.hit_polarized;
     a.hit_kind = t->desc.response_kind;
+    a.light_queue = t->lightIn[cfg];
+    a.wavelength_queue = t->lamIn[cfg];
+    a.light_capacity = t->desc.light_queue_capacity;
+    a.wavelength_capacity = t->desc.wavelength_queue_capacity;
+    if ((t->lightIn[cfg] && batch > t->desc.light_queue_capacity) || (t->lamIn[cfg] && batch > t->desc.wavelength_queue_capacity))
+        return fail(THX_ERR_INVALID, "batchSize exceeds the capacity of the host light / wavelength source");
     a.track = t->track;
     if (t->scene) a.scene = t->scene->view;
     uint32_t grid, ppw;
@@ -534,7 +575,13 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     t->lastBatch = batch;
     const uint32_t slot = (uint32_t)(t->launches % thx_tracer::kRing);
     THX_HIP(hipEventRecord(t->evStart[slot], s));
-    if (t->desc.kind == THX_TRACER_HIT_REPLAY)
+    if (t->desc.kind == THX_TRACER_LIGHT_SAMPLER) {
+        if ((uint64_t)batch + params->photon_offset > UINT32_MAX ||
+            (t->lightIn[cfg] && batch + params->photon_offset > t->desc.light_queue_capacity) ||
+            (t->lamIn[cfg] && batch + params->photon_offset > t->desc.wavelength_queue_capacity))
+            return fail(THX_ERR_INVALID, "count + baseCount exceeds the capacity of the host light / wavelength source");
+        THX_HIP(launchSampler(a, (t->desc.flags & THX_FLAG_POLARIZED) != 0, t->hits, t->lamOut, t->desc.capacity, s));
+    } else if (t->desc.kind == THX_TRACER_HIT_REPLAY)
         THX_HIP(launchReplay(a, t->replayIn, t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) != 0, grid, s));
     else
         THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
@@ -638,6 +685,38 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
         THX_HIP(hipMemsetAsync(t->hits, 0, 4, t->ctx->stream));
         THX_HIP(hipStreamSynchronize(t->ctx->stream));
     }
+    return THX_OK;
+}
+
+static int writeQueue(thx_tracer* t, float* dst, size_t have, const void* src, size_t nbytes, const char* what) {
+    if (!dst) return fail(THX_ERR_INVALID, std::string("tracer was created without a ") + what);
+    if (nbytes != have) return fail(THX_ERR_INVALID, std::string("size of the ") + what + " queue does not match its capacity / polarization");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipMemcpyAsync(dst, src, nbytes, hipMemcpyHostToDevice, t->ctx->stream));
+    THX_HIP(hipStreamSynchronize(t->ctx->stream)); // `src` may be reused by the caller
+    return THX_OK;
+}
+
+int thx_tracer_write_light(thx_tracer* t, uint32_t cfg, const void* src, size_t nbytes) {
+    if (!t || !src || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    const size_t have = ((t->desc.flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) ? 15 : 8) * 4 * (size_t)t->desc.light_queue_capacity;
+    return writeQueue(t, t->lightIn[cfg], have, src, nbytes, "host light source");
+}
+
+int thx_tracer_write_wavelengths(thx_tracer* t, uint32_t cfg, const void* src, size_t nbytes) {
+    if (!t || !src || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    return writeQueue(t, t->lamIn[cfg], 2 * 4 * (size_t)t->desc.wavelength_queue_capacity, src, nbytes, "host wavelength source");
+}
+
+int thx_tracer_read_samples(thx_tracer* t, void* light_out, size_t light_nbytes, void* wavelength_out, size_t wavelength_nbytes) {
+    if (!t || !light_out || !wavelength_out) return fail(THX_ERR_INVALID, "null argument");
+    if (t->desc.kind != THX_TRACER_LIGHT_SAMPLER) return fail(THX_ERR_INVALID, "tracer is not a THX_TRACER_LIGHT_SAMPLER");
+    const size_t nb = 4 + hitColumns(t->desc) * 4 * (size_t)t->desc.capacity, nl = 4 + 2 * 4 * (size_t)t->desc.capacity;
+    if (light_nbytes != nb || wavelength_nbytes != nl) return fail(THX_ERR_INVALID, "queue sizes do not match the sampler's capacity / polarization");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipMemcpyAsync(light_out, t->hits, nb, hipMemcpyDeviceToHost, t->ctx->stream));
+    THX_HIP(hipMemcpyAsync(wavelength_out, t->lamOut, nl, hipMemcpyDeviceToHost, t->ctx->stream));
+    THX_HIP(hipStreamSynchronize(t->ctx->stream));
     return THX_OK;
 }
 

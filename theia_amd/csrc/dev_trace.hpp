@@ -47,6 +47,10 @@ struct LaunchArgs {
     uint32_t hit_capacity;     // entries per SoA column of the queue
     uint32_t hit_polarized;    // queue has the stokes / polRef columns (store-time queue: the objectId column)
     uint32_t hit_kind;         // THX_RESPONSE_RECORD or THX_RESPONSE_STORE_TIME
+    const float* light_queue;      // HostLightSource samples (SoA, light_capacity floats per column) or null
+    const float* wavelength_queue; // HostWavelengthSource samples (wavelength[cap], contrib[cap]) or null
+    uint32_t light_capacity;
+    uint32_t wavelength_capacity;
     unsigned long long* stats; // [THX_N_STATS]
     float* track;              // [batch][track_events][THX_TRACK_WORDS] or null
     unsigned long long* prof;  // staged kernel, THX_STAGE_PROFILE builds: [3][16] cycles/rounds/items per stage
@@ -345,58 +349,135 @@ THX_DEV int propagateRayToHit(Ray& r, f3 hitPos, f3 hitNormal, const thx_propaga
 
 // ------------------------------------------------- light / wavelength source
 
-// tracer.*.forward.glsl sampleRay; wavelengthsource.const.glsl:10-12;
-// wavelengthsource.uniform.glsl:12-16; lightsource.spherical.glsl:16-34;
-// lightsource.common.glsl:59-86; ray.glsl:38-79, 188-211
+struct WavelengthSample {
+    float wavelength, contrib;
+};
+// lightsource.common.glsl:12-26
+struct SourceRay {
+    f3 position, direction;
+    f4 stokes;
+    f3 polRef;
+    float startTime, contrib;
+};
+
+// wavelengthsource.const.glsl:10-12, wavelengthsource.uniform.glsl:12-16,
+// wavelengthsource.function.glsl:13-16, wavelengthsource.host.glsl:10-13 (item L.local of the
+// queue: the reference's idx is the position in the batch)
 template <class V>
-THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
+THX_DEV WavelengthSample sampleWavelength(Lane<V>& L) {
     const thx_run_params& P = L.a->p;
-    float wavelength, wcontrib;
-    if (L.a->flags & THX_FLAG_WAVELENGTH_UNIFORM) {
-        float u = draw(L);
-        wavelength = mixf(P.wavelength.p0, P.wavelength.p1, u);
-        wcontrib = P.wavelength.p2;
-    } else {
-        wavelength = P.wavelength.p0;
-        wcontrib = 1.0f;
+    const uint32_t flags = L.a->flags;
+    if (flags & THX_FLAG_WAVELENGTH_HOST) {
+        const float* q = L.a->wavelength_queue + L.local;
+        return WavelengthSample{q[0], q[L.a->wavelength_capacity]};
     }
-    MediumConstants constants = lookUpMedium(medium, wavelength, L.cnt);
-    if (L.a->flags & THX_FLAG_LIGHT_PENCIL) { // lightsource.pencil.glsl:18-35
+    if (flags & THX_FLAG_WAVELENGTH_FUNCTION) {
+        const uint64_t table = (uint64_t)P.wavelength.table[0] | ((uint64_t)P.wavelength.table[1] << 32);
+        return WavelengthSample{lookUp(table, draw(L), 0.0f, L.cnt), P.wavelength.p2};
+    }
+    if (flags & THX_FLAG_WAVELENGTH_UNIFORM) {
+        float u = draw(L);
+        return WavelengthSample{mixf(P.wavelength.p0, P.wavelength.p1, u), P.wavelength.p2};
+    }
+    return WavelengthSample{P.wavelength.p0, 1.0f};
+}
+
+// lightsource.common.glsl:59-86 (unpolarized source in a polarized environment: Stokes (1,0,0,0),
+// any reference perpendicular to the direction) and :88-112
+template <class V>
+THX_DEV SourceRay sourceRay(f3 position, f3 direction, float startTime, float contrib) {
+    SourceRay r;
+    r.position = position; r.direction = direction; r.startTime = startTime; r.contrib = contrib;
+    r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
+    r.polRef = f3{0.0f, 0.0f, 0.0f};
+    if constexpr (V::POL) r.polRef = createLocalCOSY(direction).c0;
+    return r;
+}
+
+// lightsource.host.glsl:12-19 (LOAD_SAMPLE of lightsource.queue.glsl), lightsource.cone.glsl:22-72,
+// lightsource.pencil.glsl:18-35, lightsource.spherical.glsl:16-34
+template <class V>
+THX_DEV SourceRay sampleLight(Lane<V>& L) {
+    const thx_run_params& P = L.a->p;
+    const uint32_t flags = L.a->flags;
+    if (flags & THX_FLAG_LIGHT_HOST) {
+        const float* q = L.a->light_queue + L.local;
+        const size_t cap = L.a->light_capacity;
+        const f3 pos{q[0], q[cap], q[2 * cap]};
+        const f3 dir{q[3 * cap], q[4 * cap], q[5 * cap]};
+        if (flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) {
+            SourceRay r;
+            r.position = pos; r.direction = dir; r.startTime = q[13 * cap]; r.contrib = q[14 * cap];
+            r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
+            r.polRef = f3{0.0f, 0.0f, 0.0f};
+            if constexpr (V::POL) {
+                r.stokes = f4{q[6 * cap], q[7 * cap], q[8 * cap], q[9 * cap]};
+                r.polRef = f3{q[10 * cap], q[11 * cap], q[12 * cap]};
+            }
+            return r;
+        }
+        return sourceRay<V>(pos, dir, q[6 * cap], q[7 * cap]);
+    }
+    if (flags & THX_FLAG_LIGHT_CONE) {
+        float u0 = draw(L);
+        float u1 = draw(L);
+        float phi = TWO_PI * u0;
+        float cos_theta = (1.0f - u1) + P.light.cosOpeningAngle * u1;
+        float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+        f3 localDir{sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
+        m3 trafo = createLocalCOSY(normalize(ld3(P.light.direction)));
+        f3 rayDir = mul(trafo, localDir);
         float v = draw(L);
-        Ray r;
+        SourceRay r = sourceRay<V>(ld3(P.light.position), rayDir, mixf(P.light.t_min, P.light.t_max, v), P.light.contribFwd);
+        if constexpr (V::POL) {
+            if (flags & THX_FLAG_LIGHT_POLARIZED) {
+                f3 polRef = ld3(P.light.polRef);
+                polRef = polRef - rayDir * dot(polRef, rayDir);
+                r.polRef = normalize(polRef);
+                r.stokes = f4{P.light.stokes[0], P.light.stokes[1], P.light.stokes[2], P.light.stokes[3]};
+            }
+        }
+        return r;
+    }
+    if (flags & THX_FLAG_LIGHT_PENCIL) {
+        float v = draw(L);
+        SourceRay r;
         r.position = ld3(P.light.position);
         r.direction = ld3(P.light.direction);
-        r.medium = medium;
-        r.wavelength = wavelength;
-        r.time = mixf(P.light.t_min, P.light.t_max, v);
-        r.lin_contrib = wcontrib * P.light.contribFwd;
-        r.log_contrib = 0.0f;
-        r.constants = constants;
+        r.startTime = mixf(P.light.t_min, P.light.t_max, v);
+        r.contrib = P.light.contribFwd;
         r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
         r.polRef = f3{0.0f, 0.0f, 0.0f};
-        if constexpr (V::POL) { // lightsource.common.glsl:88-112 (polarized source ray)
+        if constexpr (V::POL) {
             r.stokes = f4{P.light.stokes[0], P.light.stokes[1], P.light.stokes[2], P.light.stokes[3]};
             r.polRef = ld3(P.light.polRef);
         }
-        if (L.a->flags & THX_FLAG_PHOTON) r.lin_contrib = 1.0f; // tracer.scene.photon.init.glsl:49-53
         return r;
     }
     float u0 = draw(L);
     float u1 = draw(L);
     f3 rayDir = sphericalToCartessian(TWO_PI * u0, 2.0f * u1 - 1.0f);
     float v = draw(L);
+    return sourceRay<V>(ld3(P.light.position), rayDir, mixf(P.light.t_min, P.light.t_max, v), P.light.contribFwd);
+}
+
+// tracer.*.forward.glsl sampleRay; ray.glsl:38-79, 188-211
+template <class V>
+THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
+    const WavelengthSample photon = sampleWavelength(L);
+    MediumConstants constants = lookUpMedium(medium, photon.wavelength, L.cnt);
+    const SourceRay s = sampleLight(L);
     Ray r;
-    r.position = ld3(P.light.position);
-    r.direction = rayDir;
+    r.position = s.position;
+    r.direction = s.direction;
     r.medium = medium;
-    r.wavelength = wavelength;
-    r.time = mixf(P.light.t_min, P.light.t_max, v);
-    r.lin_contrib = wcontrib * P.light.contribFwd;
+    r.wavelength = photon.wavelength;
+    r.time = s.startTime;
+    r.lin_contrib = photon.contrib * s.contrib;
     r.log_contrib = 0.0f;
     r.constants = constants;
-    r.stokes = f4{1.0f, 0.0f, 0.0f, 0.0f};
-    r.polRef = f3{0.0f, 0.0f, 0.0f};
-    if constexpr (V::POL) r.polRef = createLocalCOSY(rayDir).c0;
+    r.stokes = s.stokes;
+    r.polRef = s.polRef;
     if (L.a->flags & THX_FLAG_PHOTON) r.lin_contrib = 1.0f; // tracer.scene.photon.init.glsl:49-53
     return r;
 }

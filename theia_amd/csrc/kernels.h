@@ -40,6 +40,9 @@ hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_
 hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32_t in_capacity, bool in_polarized,
                         uint32_t grid, hipStream_t stream);
 constexpr uint32_t kReplayBlock = 256;
+// lightsource.sample.glsl: dispatch.batchSize samples into the two output queues
+hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light_out, uint32_t* lam_out, uint32_t capacity,
+                         hipStream_t stream);
 hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,
                          uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
                          float* out_f32, hipStream_t stream);

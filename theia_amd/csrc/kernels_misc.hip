@@ -133,6 +133,54 @@ hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32
     return hipGetLastError();
 }
 
+// LightSampler (lightsource.sample.glsl:52-75): sample idx + base of the wavelength and light source
+// -> item idx of the two output queues (count + structure-of-arrays columns)
+template <bool POL>
+__global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs args, uint32_t* __restrict__ light_out,
+                                                              uint32_t* __restrict__ lam_out, uint32_t capacity) {
+    using V = Variant<POL, true, false, false>;
+    const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t count = args.p.dispatch.batchSize;
+    if (idx >= count) return;
+    Lane<V> L;
+    L.a = &args;
+    L.stackBase = 0;
+    L.cnt.clear();
+    L.idx = idx + args.p.photon_offset;
+    L.local = L.idx;
+    L.dim = 0;
+    const WavelengthSample photon = sampleWavelength(L);
+    const SourceRay ray = sampleLight(L);
+    float* col = reinterpret_cast<float*>(light_out + 1) + idx;
+    auto put = [&](float v) { *col = v; col += capacity; };
+    put(ray.position.x); put(ray.position.y); put(ray.position.z);
+    put(ray.direction.x); put(ray.direction.y); put(ray.direction.z);
+    if constexpr (POL) {
+        put(ray.stokes.x); put(ray.stokes.y); put(ray.stokes.z); put(ray.stokes.w);
+        put(ray.polRef.x); put(ray.polRef.y); put(ray.polRef.z);
+    }
+    put(ray.startTime); put(ray.contrib);
+    float* w = reinterpret_cast<float*>(lam_out + 1) + idx;
+    w[0] = photon.wavelength;
+    w[capacity] = photon.contrib;
+    if (idx == 0) {
+        light_out[0] = count;
+        lam_out[0] = count;
+    }
+}
+
+hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light_out, uint32_t* lam_out, uint32_t capacity,
+                         hipStream_t stream) {
+    const uint32_t count = args.p.dispatch.batchSize;
+    const uint32_t grid = (count + kReplayBlock - 1) / kReplayBlock;
+    if (grid == 0) return hipSuccess;
+    if (polarized)
+        hipLaunchKernelGGL(samplerKernel<true>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity);
+    else
+        hipLaunchKernelGGL(samplerKernel<false>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity);
+    return hipGetLastError();
+}
+
 // random.sink.glsl equivalent: raw words + floats behind random(stream, dim)
 __global__ void rngFillKernel(thx_philox_params p, uint32_t base_stream, uint32_t n_streams,
                               uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,

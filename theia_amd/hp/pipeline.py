@@ -189,7 +189,16 @@ class Pipeline:
         for key, value in params.items():
             stage, sep, param = key.partition("__")
             if not sep:
-                raise ValueError(f'"{key}" is not of the form stage__param')
+                # no stage given: every stage that has a parameter of that name gets it (the
+                # reference's tests rely on it: tests/test_light.py:119 {"data": ..., "count": ...})
+                hit = False
+                for name, st in self._stages:
+                    if key in st.fields or key in st._extra:
+                        grouped.setdefault(name, {})[key] = value
+                        hit = True
+                if not hit:
+                    raise ValueError(f'No stage has a parameter "{key}"')
+                continue
             grouped.setdefault(stage, {})[param] = value
         for stage, kv in grouped.items():
             if stage not in self._byName:

@@ -93,7 +93,7 @@ class QueueView:
                     base = self._data[self._offset + 4 * col * self._capacity:
                                       self._offset + 4 * (col + n) * self._capacity].view(dtype)
                     arr = base if n == 1 else np.lib.stride_tricks.as_strided(
-                        base, shape=(self._capacity, n), strides=(4, 4 * self._capacity), writeable=False)
+                        base, shape=(self._capacity, n), strides=(4, 4 * self._capacity))
                     return arr[self._slice]
             raise KeyError(key)
         if isinstance(key, slice):

@@ -6,16 +6,44 @@ shader/lightsource.spherical.glsl, wavelengthsource.{const,uniform}.glsl).
 """
 from __future__ import annotations
 
-from ctypes import Structure, c_float
+from ctypes import Structure, c_float, c_int64, c_uint32
+from typing import Callable
+from warnings import warn
 
 import numpy as np
 
+from . import _backend
+from . import _capi as capi
 from . import units as u
-from .hp.glsl import vec2, vec3, vec4
-from .hp.pipeline import SourceCodeMixin
+from ._program import _Program
+from .hp.glsl import buffer_reference, vec2, vec3, vec4
+from .hp.pipeline import PipelineStage, SourceCodeMixin
+from .hp.queue import IOQueue
+from .lookup import uploadTables
 
-__all__ = ["WavelengthSource", "ConstWavelengthSource", "UniformWavelengthSource", "LightSource", "SphericalLightSource",
-           "PencilLightSource"]
+__all__ = ["WavelengthSource", "WavelengthSampleItem", "HostWavelengthSource", "StreamingHostWavelengthSource",
+           "ConstWavelengthSource", "UniformWavelengthSource", "FunctionWavelengthSource", "LightSource", "LightSampleItem",
+           "PolarizedLightSampleItem", "LightSampler", "HostLightSource", "StreamingHostLightSource", "ConeLightSource",
+           "SphericalLightSource", "PencilLightSource"]
+
+
+class WavelengthSampleItem(Structure):
+    """one sampled wavelength and its contribution (light.py:79-84)"""
+
+    _fields_ = [("wavelength", c_float), ("contrib", c_float)]
+
+
+class LightSampleItem(Structure):
+    """one sample of a light source (light.py:463-471, shader/lightsource.queue.glsl)"""
+
+    _fields_ = [("position", c_float * 3), ("direction", c_float * 3), ("startTime", c_float), ("contrib", c_float)]
+
+
+class PolarizedLightSampleItem(Structure):
+    """`LightSampleItem` with the Stokes vector and its reference direction (light.py:474-489)"""
+
+    _fields_ = [("position", c_float * 3), ("direction", c_float * 3), ("stokes", c_float * 4),
+                ("polarizationRef", c_float * 3), ("startTime", c_float), ("contrib", c_float)]
 
 
 class WavelengthSource(SourceCodeMixin):
@@ -30,6 +58,131 @@ class WavelengthSource(SourceCodeMixin):
     @property
     def nRNGSamples(self) -> int:
         return self._nRNGSamples
+
+
+class HostWavelengthSource(WavelengthSource):
+    """
+    Wavelength source passing samples from the host to the device (light.py:87-150,
+    shader/wavelengthsource.host.glsl): photon `k` of a batch gets item `k` of
+    `queue.view(i)` (`["wavelength"]`, `["contrib"]`). `updateFn(source, i)` is called before
+    a batch with config `i` is assembled and may refill the queue. The queue is uploaded with
+    every batch (PCIe: 8 B per photon).
+    """
+
+    name = "Host Wavelength Source"
+
+    def __init__(self, capacity: int, *, updateFn: Callable[["HostWavelengthSource", int], None] | None = None,
+                 extra: set = set()) -> None:
+        super().__init__(extra=extra)
+        self._capacity = capacity
+        self._updateFn = updateFn
+        self._queue = IOQueue(WavelengthSampleItem, capacity, mode="update", skipCounter=True)
+
+    capacity = property(lambda self: self._capacity, doc="maximum number of samples that can be drawn per run")
+    queue = property(lambda self: self._queue, doc="queue containing the data for the next batch")
+
+    def update(self, i: int) -> None:
+        if self._updateFn is not None:
+            self._updateFn(self, i)
+        super().update(i)
+
+
+class _StreamMixin:
+    """what the two streaming host sources share (light.py:184-255, 808-880): consecutive batches
+    move through `data`; assigning new data rewinds the stream"""
+
+    _sizeField = ""
+    _label = ""
+
+    def _initStream(self, fields: set, ignoreContrib: bool, data) -> None:
+        self._dataFields = set(fields)
+        if ignoreContrib:
+            self._dataFields.discard("contrib")
+            self.queue.view(0)["contrib"] = 1.0
+            self.queue.view(1)["contrib"] = 1.0
+        self.data = data
+
+    @property
+    def data(self):
+        """data used as streaming source"""
+        return self._data
+
+    @data.setter
+    def data(self, value) -> None:
+        self._offset = 0
+        self._dataSize = 0
+        if value is None:
+            self._data = None
+            return
+        if not self._dataFields.issubset(value.keys()):
+            raise ValueError(f"provided data misses expected fields: {self._dataFields.difference(value.keys())}")
+        self._dataSize = np.size(value[self._sizeField], 0)
+        for field in self._dataFields:
+            if np.size(value[field], 0) != self._dataSize:
+                raise ValueError("fields of provided data differ in size!")
+        self._data = {f: np.asarray(value[f]) for f in self._dataFields}
+
+    @data.deleter
+    def data(self) -> None:
+        self.data = None
+
+    @staticmethod
+    def _updateData(source, i: int) -> None:
+        if source.data is None:
+            warn(f"{source._label}: New data was requested but no source was given!")
+            return
+        if source._offset >= source._dataSize:
+            warn(f"{source._label} ran out of data!")
+            return
+        start = source._offset
+        end = min(source._offset + source.capacity, source._dataSize)
+        source._offset = end
+        view = source.queue.view(i)
+        for field in source._dataFields:
+            view[field][: end - start] = source.data[field][start:end]
+
+
+class StreamingHostWavelengthSource(_StreamMixin, HostWavelengthSource):
+    """Feeds pre-sampled wavelengths batch by batch from `data` (`{"wavelength": ..., "contrib": ...}`;
+    `ignoreContrib=True`: contribution 1). Stage parameter `data`. Reference: light.py:152-255."""
+
+    name = "Streaming Host Wavelength Source"
+    _sizeField = "wavelength"
+    _label = "StreamingHostWavelengthSource"
+
+    def __init__(self, batchSize: int, *, data=None, ignoreContrib: bool = False) -> None:
+        super().__init__(batchSize, updateFn=self._updateData, extra={"data"})
+        self._initStream({"wavelength", "contrib"}, ignoreContrib, data)
+
+
+class FunctionWavelengthSource(WavelengthSource):
+    """
+    Importance-samples wavelengths from `fn(lambda in nm)` on `lambdaRange`: the distribution is
+    integrated and inverted numerically on the host (scipy) into a look-up table of `numSamples`
+    entries the device interpolates (light.py:354-414, shader/wavelengthsource.function.glsl);
+    the contribution is the integral of `fn`. 1 draw.
+    """
+
+    name = "Function Wavelength Source"
+
+    class WavelengthParams(Structure):
+        _fields_ = [("_table", c_int64), ("_contrib", c_float)]
+
+    def __init__(self, fn: Callable[[float], float], *, lambdaRange=(300.0, 700.0) * u.nm, numSamples: int = 1024) -> None:
+        super().__init__(nRNGSamples=1, params={"WavelengthParams": self.WavelengthParams})
+        from scipy.integrate import quad
+        from scipy.stats.sampling import NumericalInversePolynomial
+
+        contrib, _ = quad(fn, *lambdaRange)
+
+        class Dist:
+            def pdf(self, x):
+                return fn(x)
+
+        inv_cdf = NumericalInversePolynomial(Dist(), domain=tuple(lambdaRange))
+        x = inv_cdf.ppf(np.linspace(0.0, 1.0, numSamples))
+        self._tableMemory, [table_adr] = uploadTables([x])
+        self.setParams(_table=table_adr, _contrib=contrib)
 
 
 class ConstWavelengthSource(WavelengthSource):
@@ -152,3 +305,248 @@ class PencilLightSource(LightSource):
                          params={"LightParams": PencilLightSource.LightParams})
         self.setParams(position=position, direction=direction, timeRange=timeRange, budget=budget, stokes=stokes,
                        polarizationRef=polarizationRef)
+
+
+class ConeLightSource(LightSource):
+    """
+    Point source radiating uniformly into the cone around `direction` with `cosOpeningAngle`;
+    optionally polarized with a constant `stokes` vector whose reference `polarizationReference`
+    is made perpendicular to every sampled direction. 3 draws. Parameters and stage parameters
+    as in the reference (light.py:883-1021, shader/lightsource.cone.glsl).
+    """
+
+    name = "Cone Light Source"
+
+    class LightParams(Structure):
+        _fields_ = [("position", vec3), ("direction", vec3), ("cosOpeningAngle", c_float), ("_contribFwd", c_float),
+                    ("_contribBwd", c_float), ("timeRange", vec2), ("polarizationReference", vec3), ("stokes", vec4)]
+
+    def __init__(self, *, position=(0.0, 0.0, 0.0), direction=(1.0, 0.0, 0.0), timeRange=(0.0, 100.0) * u.ns,
+                 cosOpeningAngle: float = 0.5, budget: float = 1.0, polarizationReference=(0.0, 1.0, 0.0),
+                 stokes=(1.0, 0.0, 0.0, 0.0), polarized: bool = True) -> None:
+        super().__init__(supportForward=True, supportBackward=True, nRNGForward=3, nRNGBackward=1,
+                         params={"LightParams": ConeLightSource.LightParams}, extra={"budget"})
+        self._polarized = polarized
+        self.budget = budget
+        self.setParams(position=position, direction=direction, timeRange=timeRange, cosOpeningAngle=cosOpeningAngle,
+                       polarizationReference=polarizationReference, stokes=stokes)
+        if abs(sum(direction[k] * polarizationReference[k] for k in range(3))) > 1.0 - 1e-5:
+            raise ValueError("direction and polarizationReference cannot be parallel!")
+        if self._polarized and cosOpeningAngle <= 0.0:
+            raise ValueError("Opening angles for polarized cone lights must be smaller 90 degrees!")
+
+    polarized = property(lambda self: self._polarized, doc="whether stokes / polarizationReference are used")
+
+    @property
+    def budget(self) -> float:
+        return self._budget
+
+    @budget.setter
+    def budget(self, value: float) -> None:
+        self._budget = value
+
+    def _finishParams(self, i: int) -> None:
+        super()._finishParams(i)
+        self.setParam("_contribFwd", self.budget)
+        # backward: divide by the solid angle of the cone
+        self.setParam("_contribBwd", self.budget / (2.0 * np.pi * (1.0 - self.cosOpeningAngle)))
+
+
+class HostLightSource(LightSource):
+    """
+    Light source passing samples from the host to the device (light.py:692-772,
+    shader/lightsource.host.glsl): photon `k` of a batch starts as item `k` of `queue.view(i)`
+    (`["position"]`, `["direction"]`, `["startTime"]`, `["contrib"]`, with `polarized=True` also
+    `["stokes"]`, `["polarizationRef"]`). Any light source can so be sampled on the host (or by a
+    `LightSampler`) and traced here. `updateFn(source, i)` may refill the queue before a batch
+    with config `i`. The queue is uploaded with every batch (PCIe: 32 / 60 B per photon).
+    """
+
+    name = "Host Light Source"
+
+    def __init__(self, capacity: int, *, polarized: bool = False,
+                 updateFn: Callable[["HostLightSource", int], None] | None = None, extra: set = set()) -> None:
+        super().__init__(supportForward=True, supportBackward=False, extra=extra)
+        self._capacity = capacity
+        self._polarized = polarized
+        self._updateFn = updateFn
+        self._queue = IOQueue(PolarizedLightSampleItem if polarized else LightSampleItem, capacity, mode="update", skipCounter=True)
+
+    capacity = property(lambda self: self._capacity, doc="maximum number of samples that can be drawn per run")
+    polarized = property(lambda self: self._polarized, doc="whether the host also provides polarization information")
+    queue = property(lambda self: self._queue, doc="queue holding the samples for the next batch")
+
+    def update(self, i: int) -> None:
+        if self._updateFn is not None:
+            self._updateFn(self, i)
+        super().update(i)
+
+
+class StreamingHostLightSource(_StreamMixin, HostLightSource):
+    """Feeds light rays batch by batch from `data` (a dict with the fields of the sample item;
+    `ignoreContrib=True`: contribution 1). Stage parameter `data`. Reference: light.py:775-880."""
+
+    name = "Streaming Host Light Source"
+    _sizeField = "startTime"
+    _label = "StreamingHostLightSource"
+
+    def __init__(self, batchSize: int, *, data=None, polarized: bool = False, ignoreContrib: bool = False) -> None:
+        super().__init__(batchSize, polarized=polarized, updateFn=self._updateData, extra={"data"})
+        self._initStream(set(self.queue.view(0).fields), ignoreContrib, data)
+
+
+# ---- what the HIP backend needs to know about a (light source, wavelength source) pair --------
+
+_LIGHTS = (SphericalLightSource, PencilLightSource, ConeLightSource, HostLightSource)
+_WAVELENGTHS = (ConstWavelengthSource, UniformWavelengthSource, FunctionWavelengthSource, HostWavelengthSource)
+
+
+def sourceSpec(source: LightSource, wavelength: WavelengthSource) -> tuple[int, int, int]:
+    """(THX_FLAG_* bits, light queue capacity, wavelength queue capacity) selecting the kernel branches"""
+    flags, lightCap, lamCap = 0, 0, 0
+    if isinstance(source, HostLightSource):
+        flags |= capi.FLAG_LIGHT_HOST | (capi.FLAG_LIGHT_QUEUE_POLARIZED if source.polarized else 0)
+        lightCap = source.capacity
+    elif isinstance(source, ConeLightSource):
+        flags |= capi.FLAG_LIGHT_CONE | (capi.FLAG_LIGHT_POLARIZED if source.polarized else 0)
+    elif isinstance(source, PencilLightSource):
+        flags |= capi.FLAG_LIGHT_PENCIL
+    if isinstance(wavelength, HostWavelengthSource):
+        flags |= capi.FLAG_WAVELENGTH_HOST
+        lamCap = wavelength.capacity
+    elif isinstance(wavelength, FunctionWavelengthSource):
+        flags |= capi.FLAG_WAVELENGTH_FUNCTION
+    elif isinstance(wavelength, UniformWavelengthSource):
+        flags |= capi.FLAG_WAVELENGTH_UNIFORM
+    return flags, lightCap, lamCap
+
+
+def fillSourceParams(P: capi.RunParams, i: int, source: LightSource, wavelength: WavelengthSource) -> None:
+    """copies the sources' parameter blocks of config `i` into the C-ABI run parameters"""
+    if not isinstance(source, HostLightSource):
+        l = source._getParamsBlock("LightParams", i)
+        for k, c in enumerate("xyz"):
+            P.light.position[k] = getattr(l.position, c)
+        P.light.t_min, P.light.t_max = l.timeRange.x, l.timeRange.y
+        if isinstance(source, PencilLightSource):
+            P.light.contribFwd, P.light.contribBwd = l.budget, 0.0
+        else:
+            P.light.contribFwd, P.light.contribBwd = l._contribFwd, l._contribBwd
+        if isinstance(source, (PencilLightSource, ConeLightSource)):
+            ref = l.polarizationRef if isinstance(source, PencilLightSource) else l.polarizationReference
+            for k, c in enumerate("xyz"):
+                P.light.direction[k] = getattr(l.direction, c)
+                P.light.polRef[k] = getattr(ref, c)
+            for k, c in enumerate("xyzw"):
+                P.light.stokes[k] = getattr(l.stokes, c)
+        if isinstance(source, ConeLightSource):
+            P.light.cosOpeningAngle = l.cosOpeningAngle
+    if isinstance(wavelength, HostWavelengthSource):
+        return
+    w = wavelength._getParamsBlock("WavelengthParams", i)
+    if isinstance(wavelength, UniformWavelengthSource):
+        P.wavelength.p0, P.wavelength.p1, P.wavelength.p2 = w.lambdaRange.x, w.lambdaRange.y, w._contrib
+    elif isinstance(wavelength, FunctionWavelengthSource):
+        P.wavelength.p2 = w._contrib
+        P.wavelength.table[0], P.wavelength.table[1] = w._table & 0xFFFFFFFF, (w._table >> 32) & 0xFFFFFFFF
+    else:
+        P.wavelength.p0 = w.wavelength
+
+
+def uploadSourceQueues(program, i: int, source: LightSource, wavelength: WavelengthSource) -> None:
+    """host sources: copy the queues of config `i` to the device before the batch is launched"""
+    if isinstance(source, HostLightSource):
+        program.write_light(i, source.queue.buffer(i))
+    if isinstance(wavelength, HostWavelengthSource):
+        program.write_wavelengths(i, wavelength.queue.buffer(i))
+
+
+class LightSampler(PipelineStage):
+    """
+    Samples a light source and a wavelength source into two queues (light.py:492-689,
+    shader/lightsource.sample.glsl). Parameters as in the reference: `source, wavelengthSource,
+    capacity, *, rng=None, medium=None, polarized=False, retrieve=True, scene=None, batchSize=128,
+    code=None`; stage parameters `count` (default: capacity), `baseCount`, `medium`.
+    `lightQueue.view(i)` / `wavelengthQueue.view(i)` hold the samples of the most recent batch run
+    with config `i`.
+    """
+
+    name = "Light Sampler"
+
+    class SampleParams(Structure):
+        _fields_ = [("count", c_uint32), ("baseCount", c_uint32), ("medium", buffer_reference)]
+
+    def __init__(self, source: LightSource, wavelengthSource: WavelengthSource, capacity: int, *, rng=None,
+                 medium: int | None = None, polarized: bool = False, retrieve: bool = True, scene=None, batchSize: int = 128,
+                 code: bytes | None = None) -> None:
+        needRNG = source.nRNGForward > 0 or wavelengthSource.nRNGSamples > 0
+        if needRNG and rng is None:
+            raise ValueError("Light source requires a RNG but none was given!")
+        super().__init__({"SampleParams": self.SampleParams})
+        if not isinstance(source, _LIGHTS):
+            raise NotImplementedError(f"{type(source).__name__} is not supported as light source by the HIP backend "
+                                      f"(supported: {', '.join(c.__name__ for c in _LIGHTS)})")
+        if not isinstance(wavelengthSource, _WAVELENGTHS):
+            raise NotImplementedError(f"{type(wavelengthSource).__name__} is not supported as wavelength source by the HIP "
+                                      f"backend (supported: {', '.join(c.__name__ for c in _WAVELENGTHS)})")
+        if isinstance(source, HostLightSource) and source.polarized != polarized:
+            # the reference's shader refuses to compile: "mismatch in light queue definition"
+            # (lightsource.sample.glsl:28-33)
+            raise RuntimeError("mismatch in light queue definition: HostLightSource and LightSampler differ in polarization")
+        if medium is None:
+            medium = 0 if scene is None else scene.medium
+        self._batchSize, self._capacity, self._scene, self._source = batchSize, capacity, scene, source
+        self._retrieve, self._polarized, self._rng, self._wavelengthSource = retrieve, polarized, rng, wavelengthSource
+        self._code = b"" if code is None else code
+        self.setParams(count=capacity, baseCount=0, medium=medium)
+        self._lightQueue = IOQueue(PolarizedLightSampleItem if polarized else LightSampleItem, capacity, mode="retrieve")
+        self._lamQueue = IOQueue(WavelengthSampleItem, capacity, mode="retrieve")
+        flags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
+        flags |= capi.FLAG_POLARIZED if polarized else 0
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_LIGHT_SAMPLER, flags, 0, batchSize, 1, capacity,
+                                                     light_queue_capacity=lightCap, wavelength_queue_capacity=lamCap), None)
+
+    batchSize = property(lambda self: self._batchSize, doc="number of samples drawn per work group (API parity)")
+    capacity = property(lambda self: self._capacity, doc="maximum number of samples that can be drawn per run")
+    code = property(lambda self: self._code, doc="kept for API parity; kernels are precompiled")
+    lightQueue = property(lambda self: self._lightQueue, doc="queue storing the light samples")
+    polarized = property(lambda self: self._polarized)
+    retrieve = property(lambda self: self._retrieve)
+    rng = property(lambda self: self._rng)
+    scene = property(lambda self: self._scene)
+    source = property(lambda self: self._source)
+    wavelengthSource = property(lambda self: self._wavelengthSource)
+    wavelengthQueue = property(lambda self: self._lamQueue, doc="queue holding the sampled wavelengths")
+    program = property(lambda self: self._program)
+
+    def collectStages(self) -> list[PipelineStage]:
+        stages = [] if self.rng is None else [self.rng]
+        stages.extend([self.wavelengthSource, self.source, self])
+        return stages
+
+    def _assemble(self, i: int) -> capi.RunParams:
+        P = capi.RunParams()
+        sp = self._getParamsBlock("SampleParams", i)
+        if sp.count > self._capacity:
+            raise ValueError("count must be at most capacity")
+        P.dispatch.batchSize = sp.count
+        P.dispatch.groupCountX = -(self._capacity // -self._batchSize)
+        P.dispatch.groupCountY = P.dispatch.groupCountZ = 1
+        P.photon_offset = sp.baseCount
+        P.volume.medium[0], P.volume.medium[1] = sp.medium.lo, sp.medium.hi
+        if self._rng is not None:
+            r = self._rng._getParamsBlock("PhiloxParams", i)
+            P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
+            for k in range(4):
+                P.philox.offset[k] = r.offset.word[k]
+        fillSourceParams(P, i, self._source, self._wavelengthSource)
+        return P
+
+    def run(self, i: int):
+        def launch() -> None:
+            uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
+            self._program.run(i, self._assemble(i))
+            if self._retrieve:
+                self._program.read_samples(self._lightQueue.buffer(i), self._lamQueue.buffer(i))
+
+        return [launch]

@@ -17,6 +17,7 @@ import numpy as np
 
 from . import units as u
 from . import _capi as capi
+from ._program import _Program
 from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .hp.queue import IOQueue
 
@@ -443,7 +444,6 @@ class HitReplay(PipelineStage):
         self._queue = IOQueue(PolarizedHitItem if polarized else HitItem, capacity, mode="update")
 
         from . import _backend
-        from .trace import _Program  # the tracers' handle type; imported late (trace imports this module)
 
         flags = capi.FLAG_POLARIZED if polarized else 0
         if isinstance(response, HitRecorder):

@@ -19,11 +19,13 @@ from enum import IntEnum
 import numpy as np
 
 from . import _backend
+from ._program import _Program
 from . import _capi as capi
 from . import units as u
 from .hp.glsl import buffer_reference, vec3
 from .hp.pipeline import PipelineStage, SourceCodeMixin
-from .light import (ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
+from .light import (_LIGHTS, _WAVELENGTHS, HostLightSource, HostWavelengthSource, fillSourceParams, sourceSpec, uploadSourceQueues,
+                    ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
                     WavelengthSource)
 from .random import RNG, PhiloxRNG
 from .response import (EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, KernelHistogramHitResponse,
@@ -183,79 +185,6 @@ class EventResultCode(IntEnum):
     ERROR_RAY_BAD = -13
 
 
-class _Program:
-    """The compiled-variant handle a tracer owns (stands where hp.Program stood).
-    Created lazily so that building stages does not need a device."""
-
-    def __init__(self, spec: _backend.TracerSpec, scene: Scene | None) -> None:
-        self._spec = spec
-        self._scene = scene
-        self._handle = None
-        self._be = None
-        self.last_batch = 0
-
-    @property
-    def created(self) -> bool:
-        return self._handle is not None
-
-    @property
-    def handle(self) -> int:
-        if self._handle is None:
-            self._be = _backend.get()
-            self._handle = self._be.tracer_create(self._spec, self._scene.handle if self._scene is not None else None)
-        return self._handle
-
-    @property
-    def backend(self):
-        self.handle
-        return self._be
-
-    def run(self, cfg: int, params: capi.RunParams) -> None:
-        self.last_batch = int(params.dispatch.batchSize)
-        self.backend.tracer_run(self.handle, cfg, params)
-
-    def reduce(self, cfg: int, norm: float, d_out: int = 0) -> None:
-        self.backend.tracer_reduce(self.handle, cfg, norm, d_out)
-
-    def read_hist(self, cfg: int) -> np.ndarray:
-        return self.backend.tracer_read_hist(self.handle, cfg, self._spec.n_bins)
-
-    def hist_ptr(self, cfg: int) -> int:
-        return self.backend.tracer_hist_ptr(self.handle, cfg)
-
-    def read_hits(self, out: np.ndarray, clear: bool = True) -> None:
-        self.backend.tracer_read_hits(self.handle, out, clear)
-
-    def write_hits(self, data: np.ndarray) -> None:
-        self.backend.tracer_write_hits(self.handle, data)
-
-    def read_stats(self) -> np.ndarray:
-        return self.backend.tracer_read_stats(self.handle)
-
-    def reset_stats(self) -> None:
-        self.backend.tracer_reset_stats(self.handle)
-
-    def read_track(self, batch: int) -> np.ndarray:
-        return self.backend.tracer_read_track(self.handle, batch, self._spec.path_length + 3)
-
-    def launch_info(self, batch: int) -> dict:
-        return self.backend.tracer_launch_info(self.handle, batch)
-
-    def last_kernel_ms(self, cfg: int) -> float:
-        return self.backend.tracer_last_kernel_ms(self.handle, cfg)
-
-    def kernel_times(self, n: int = 64) -> np.ndarray:
-        return self.backend.tracer_kernel_times(self.handle, n)
-
-    def __del__(self) -> None:
-        try:
-            if self._handle is not None:
-                self._be.tracer_destroy(self._handle)
-                self._handle = None
-        except Exception:
-            pass
-
-
 def _unsupported(role: str, obj, supported: str):
     return NotImplementedError(
         f"{type(obj).__name__} is not supported as {role} by the HIP backend (supported: {supported}). "
@@ -379,23 +308,7 @@ class Tracer(PipelineStage):
         P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
         for k in range(4):
             P.philox.offset[k] = r.offset.word[k]
-        l = source._getParamsBlock("LightParams", i)
-        P.light.position[0], P.light.position[1], P.light.position[2] = l.position.x, l.position.y, l.position.z
-        P.light.t_min, P.light.t_max = l.timeRange.x, l.timeRange.y
-        if isinstance(source, PencilLightSource):
-            P.light.contribFwd, P.light.contribBwd = l.budget, 0.0
-            for k, c in enumerate("xyz"):
-                P.light.direction[k] = getattr(l.direction, c)
-                P.light.polRef[k] = getattr(l.polarizationRef, c)
-            for k, c in enumerate("xyzw"):
-                P.light.stokes[k] = getattr(l.stokes, c)
-        else:
-            P.light.contribFwd, P.light.contribBwd = l._contribFwd, l._contribBwd
-        w = wavelength._getParamsBlock("WavelengthParams", i)
-        if isinstance(wavelength, UniformWavelengthSource):
-            P.wavelength.p0, P.wavelength.p1, P.wavelength.p2 = w.lambdaRange.x, w.lambdaRange.y, w._contrib
-        else:
-            P.wavelength.p0 = w.wavelength
+        fillSourceParams(P, i, source, wavelength)
         if isinstance(response, HistogramHitResponse):
             rp = response._getParamsBlock("ResponseParams", i)
             P.response.t0, P.response.binSize = rp.t0, rp.binSize
@@ -425,10 +338,10 @@ class Tracer(PipelineStage):
 
     @staticmethod
     def _checkComponents(source, wavelength, response, rng, callback) -> None:
-        if not isinstance(source, (SphericalLightSource, PencilLightSource)):
-            raise _unsupported("light source", source, "SphericalLightSource, PencilLightSource")
-        if not isinstance(wavelength, (ConstWavelengthSource, UniformWavelengthSource)):
-            raise _unsupported("wavelength source", wavelength, "ConstWavelengthSource, UniformWavelengthSource")
+        if not isinstance(source, _LIGHTS):
+            raise _unsupported("light source", source, ", ".join(c.__name__ for c in _LIGHTS))
+        if not isinstance(wavelength, _WAVELENGTHS):
+            raise _unsupported("wavelength source", wavelength, ", ".join(c.__name__ for c in _WAVELENGTHS))
         if not isinstance(response, (HistogramHitResponse, HitRecorder, EmptyResponse, StoreTimeHitResponse)):
             raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder, "
                                "StoreTimeHitResponse(UniformValueResponse()), EmptyResponse")
@@ -498,14 +411,15 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_POLARIZED if polarized else 0
         flags |= capi.FLAG_DISABLE_DIRECT if disableDirectLighting else 0
         flags |= capi.FLAG_DISABLE_MIS if disableTargetSampling else 0
-        flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
         flags |= capi.FLAG_TARGET_INNER if isinstance(target, InnerSphereTarget) else 0
-        flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
+        srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
+        flags |= srcFlags
         flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
         self._code = b"" if code is None else code
-        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response)), None)
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response),
+                                                     light_queue_capacity=lightCap, wavelength_queue_capacity=lamCap), None)
 
     callback = property(lambda self: self._callback, doc="callback called for each tracing event")
     code = property(lambda self: self._code, doc="kept for API parity; kernels are precompiled")
@@ -557,6 +471,7 @@ class VolumeForwardTracer(Tracer):
             # follows reduces and retrieves this tracer's result
             self.callback.bindParams(self._program, i)
             self.response.bindParams(self._program, i)
+            uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
             self._program.run(i, self._assemble(i))
 
         return [launch]
@@ -629,13 +544,14 @@ class SceneForwardTracer(Tracer):
         flags |= capi.FLAG_DISABLE_TRANSMISSION if disableTransmission else 0
         flags |= capi.FLAG_DISABLE_VOLUME_BORDER if disableVolumeBorder else 0
         flags |= capi.FLAG_HIT_USE_TRANSMITTED if useRefractedHitDir else 0
-        flags |= capi.FLAG_WAVELENGTH_UNIFORM if isinstance(wavelengthSource, UniformWavelengthSource) else 0
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
-        flags |= capi.FLAG_LIGHT_PENCIL if isinstance(source, PencilLightSource) else 0
+        srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
+        flags |= srcFlags
         flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
         self._code = b"" if code is None else code
-        self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response)), scene)
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response),
+                                                     light_queue_capacity=lightCap, wavelength_queue_capacity=lamCap), scene)
 
     callback = property(lambda self: self._callback)
     code = property(lambda self: self._code)
@@ -680,6 +596,7 @@ class SceneForwardTracer(Tracer):
             # follows reduces and retrieves this tracer's result
             self.callback.bindParams(self._program, i)
             self.response.bindParams(self._program, i)
+            uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
             self._program.run(i, self._assemble(i))
 
         return [launch]
