@@ -41,7 +41,7 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=10_000_000, help="photons per GPU per step")
-    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config5"])
+    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config5", "bigmesh"])
     ap.add_argument("--polarized", type=int, default=-1, help="override the workload's polarization (0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
@@ -58,6 +58,8 @@ def make_scenario(S, name: str, batch: int, polarized: int, **kw):
         return S.config2_sphere(batch, **pol, **kw)
     if name == "config3":
         return S.config3_cube_torus(batch, **pol, **kw)
+    if name == "bigmesh":  # config 2 with the sphere subdivided to 5.2 M triangles: a BVH (410 MB) beyond every cache
+        return S.config2_sphere(batch, subdivide=6, **pol, **kw)
     return S.config5_suzanne_grid(batch, **pol, **kw)
 
 
@@ -200,6 +202,7 @@ def main() -> None:
                 "config2": "BASELINE config 2: SceneForwardTracer, single sphere.stl (1280 tris) in scattering medium, sphere guide/MIS, maxPathLength 10, unpolarized",
                 "config3": "BASELINE config 3: SceneForwardTracer, BK7 cube + torus detector in sea water, polarized",
                 "config5": "BASELINE config 5: SceneForwardTracer, suzanne x1000 instances + sphere detector, polarized",
+                "bigmesh": "config 2 with the detector sphere subdivided to 5 242 880 triangles (not a BASELINE config: out-of-cache BVH stress)",
             }[args.workload],
             "photons_per_step_per_gpu": B,
             "photons_total": global_batch * K,
@@ -210,7 +213,7 @@ def main() -> None:
         },
         "roofline": {
             "bound": "hbm",
-            "kernel": ("thx::sceneStagedKernel" if info.get("block") == 1024 else "thx::traceKernel (scene forward)")
+            "kernel": ("thx::sceneStagedKernel" if info.get("block") != 256 else "thx::traceKernel (scene forward)")
             if args.workload != "config1" else "thx::traceKernel (volume forward)",
             "achieved": achieved,
             "peak": HBM_PEAK_GBS,

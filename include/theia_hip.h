@@ -236,6 +236,10 @@ typedef struct {
     uint64_t bytes_nodes, bytes_triangles, bytes_instances, bytes_total;
 } thx_scene_info;
 
+/* Threading: every call may be made from any thread (each sets its device); calls on tracers and
+ * scenes of one context are serialised by a per-context mutex, so a pipeline's update / launch /
+ * retrieve threads need no locking of their own. thx_last_error() is per thread. Create and
+ * destroy objects while no other thread uses them. */
 /* ---- context / device (replaces hp.getCurrentDevice, hp.selectDevice) ---- */
 const char* thx_last_error(void);
 int thx_device_count(int* out);

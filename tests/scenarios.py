@@ -34,6 +34,29 @@ def bundled_mesh(name: str) -> Mesh:
     return m
 
 
+def subdivided_sphere(levels: int) -> Mesh:
+    """The bundled icosphere (1280 triangles) with every triangle split in four `levels` times and the
+    new vertices pushed onto the unit sphere: 1280 * 4^levels triangles (stress meshes)."""
+    base = bundled_mesh("sphere")
+    v = np.asarray(base.vertices, dtype=np.float64)[:, :3]
+    f = np.asarray(base.indices, dtype=np.int64)
+    v /= np.linalg.norm(v, axis=1, keepdims=True)
+    for _ in range(levels):
+        edges = np.concatenate([f[:, [0, 1]], f[:, [1, 2]], f[:, [2, 0]]])
+        edges.sort(axis=1)
+        uniq, inv = np.unique(edges, axis=0, return_inverse=True)
+        mid = v[uniq[:, 0]] + v[uniq[:, 1]]
+        mid /= np.linalg.norm(mid, axis=1, keepdims=True)
+        m = len(v) + inv.reshape(3, -1)  # midpoints of edges 01, 12, 20 per face
+        v = np.concatenate([v, mid])
+        f = np.concatenate([np.stack([f[:, 0], m[0], m[2]], 1), np.stack([f[:, 1], m[1], m[0]], 1),
+                            np.stack([f[:, 2], m[2], m[1]], 1), np.stack([m[0], m[1], m[2]], 1)])
+    out = Mesh()
+    out.vertices = np.concatenate([v, v], axis=1).astype(np.float32)  # position + normal
+    out.indices = f.astype(np.uint32)
+    return out
+
+
 class HomogeneousModel(DispersionFreeMedium, HenyeyGreensteinPhaseFunction, MediumModel):
     """examples/01_volume_tracing.ipynb cell 5"""
 
@@ -88,14 +111,14 @@ def config1_volume(batch: int = 100_000, *, polarized: bool = False, stats: bool
 
 def config2_sphere(batch: int = 1 << 20, *, polarized: bool = False, stats: bool = False, track: bool = False,
                    guide: bool = True, mu_a: float = 0.05, mu_s: float = 0.005, g: float = 0.5,
-                   maxPathLength: int = 10, key: int = 0xC0FFEE) -> Scenario:
+                   maxPathLength: int = 10, key: int = 0xC0FFEE, subdivide: int = 0) -> Scenario:
     """BASELINE config 2 = sphere-in-medium (reference tests/test_trace_energy.py:187-337,
     Crosscheck geometry): detector sphere r=5 m at the origin, light 6 m away."""
     model = EnergyTestModel(mu_a, mu_s, g)
     medium = model.createMedium()
     material = Material("det", None, medium, flags="DB")
     store = MaterialStore([material])
-    meshes = MeshStore({"sphere": bundled_mesh("sphere")})
+    meshes = MeshStore({"sphere": subdivided_sphere(subdivide) if subdivide else bundled_mesh("sphere")})
     radius = 5.0 * u.m
     trafo = Transform.TRS(scale=radius, translate=(0.0, 0.0, 0.0))
     target = meshes.createInstance("sphere", "det", trafo, detectorId=0)

@@ -257,12 +257,23 @@ def test_scheduler_watchdog_is_loud(hip_backend, monkeypatch):
     assert np.isfinite(S.run_batches(sc, 1)[0]).all()
 
 
-def test_scene_with_more_instances_than_the_staged_kernel_packs(hip_backend):
-    """4914 instances: the tracer falls back to the lane kernel (12-bit instance ids in the staged
-    kernel's shadow-ray entries) and still follows the oracle photon by photon"""
+@pytest.mark.parametrize("kernel", ["staged", "lane"])
+def test_scene_with_thousands_of_instances(hip_backend, kernel, monkeypatch):
+    """4914 instances (32-bit traversal stacks, a TLAS deeper than any other test's): both kernel
+    forms follow the oracle photon by photon"""
+    if kernel == "lane":
+        monkeypatch.setenv("THX_KERNEL", "lane")
     n = 6000
     res = _both(S.many_cubes, batch=n, stats=True, track=True)
     sc = res[1][0]
     info = sc.tracer.program.launch_info(n)
-    assert info["block"] == 256  # lane kernel geometry
+    assert (info["block"] == 256) == (kernel == "lane")
+    _compare(res, n, code_agree=0.99)
+
+
+def test_mesh_with_a_million_triangles(hip_backend):
+    """config 2 with the sphere subdivided to 1.3 M triangles (BVH 20 levels deep, 100 MB): the
+    staged kernel follows the oracle"""
+    n = 4000
+    res = _both(S.config2_sphere, batch=n, stats=True, track=True, subdivide=5)
     _compare(res, n, code_agree=0.99)

@@ -41,7 +41,7 @@ struct thx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;
     hipDeviceProp_t prop{};
-    std::mutex lock;
+    std::mutex lock; // serialises calls on this context's tracers / scenes (launch bookkeeping, event ring)
 };
 
 struct thx_scene {
@@ -288,6 +288,7 @@ int thx_scene_get_info(const thx_scene* scene, thx_scene_info* out) {
 
 int thx_scene_query(thx_scene* scene, const float* rays7, uint32_t n, float* out6) {
     if (!scene || !rays7 || !out6) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(scene->ctx->lock);
     if (n == 0) return THX_OK;
     thx_ctx* ctx = scene->ctx;
     THX_HIP(hipSetDevice(ctx->device));
@@ -361,10 +362,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         t->stack16 = scene->info.n_nodes < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
     }
-    // kernel form: the staged scene kernel unless the scene exceeds its packed hit ids
-    // (12-bit instance, 20-bit primitive) or THX_KERNEL=lane asks for the lane kernel
-    t->staged = desc->kind == THX_TRACER_SCENE_FORWARD && scene && scene->info.n_instances < 4096 &&
-                scene->info.n_triangles < (1u << 20) && desc->path_length >= 1;
+    // kernel form: the staged scene kernel unless THX_KERNEL=lane asks for the lane kernel
+    // (kept as the simple cross-check of the staged one) or there is no step to stage
+    t->staged = desc->kind == THX_TRACER_SCENE_FORWARD && scene && desc->path_length >= 1;
     if (const char* env = std::getenv("THX_KERNEL")) {
         if (std::strcmp(env, "lane") == 0) t->staged = false;
     }
@@ -521,6 +521,7 @@ static void launchGeometry(const thx_tracer* t, uint32_t batch, uint32_t* grid, 
 
 int thx_tracer_launch_info(thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* block, uint32_t* lds_bytes) {
     if (!t) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     uint32_t g, p;
     launchGeometry(t, batch, &g, &p);
     if (grid) *grid = g;
@@ -531,6 +532,7 @@ int thx_tracer_launch_info(thx_tracer* t, uint32_t batch, uint32_t* grid, uint32
 
 int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, void* stream) {
     if (!t || !params) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
     const uint32_t batch = params->dispatch.batchSize;
     if (batch > t->desc.capacity) return fail(THX_ERR_INVALID, "batchSize cannot be larger than capacity");
@@ -593,6 +595,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
 
 int thx_tracer_reduce(thx_tracer* t, uint32_t cfg, float norm, uint64_t d_out, void* stream) {
     if (!t) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
     thx_ctx* ctx = t->ctx;
     THX_HIP(hipSetDevice(ctx->device));
@@ -604,6 +607,7 @@ int thx_tracer_reduce(thx_tracer* t, uint32_t cfg, float norm, uint64_t d_out, v
 
 int thx_tracer_read_hist(thx_tracer* t, uint32_t cfg, float* out, uint32_t n_bins) {
     if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (cfg > 1 || n_bins != t->desc.n_bins) return fail(THX_ERR_INVALID, "bad config index or bin count");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
@@ -623,6 +627,7 @@ int thx_tracer_hist_device_ptr(thx_tracer* t, uint32_t cfg, uint64_t* out) {
 
 int thx_tracer_read_stats(thx_tracer* t, uint64_t* out, uint32_t n) {
     if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (n > THX_N_STATS) n = THX_N_STATS;
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
@@ -632,6 +637,7 @@ int thx_tracer_read_stats(thx_tracer* t, uint64_t* out, uint32_t n) {
 
 int thx_tracer_read_stage_profile(thx_tracer* t, uint64_t* out48) {
     if (!t || !out48) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemcpy(out48, t->prof, sizeof(uint64_t) * 48, hipMemcpyDeviceToHost));
@@ -642,6 +648,7 @@ int thx_tracer_read_stage_profile(thx_tracer* t, uint64_t* out48) {
 
 int thx_tracer_reset_stats(thx_tracer* t) {
     if (!t) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     THX_HIP(hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS));
@@ -660,6 +667,7 @@ size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized) {
 
 int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
     if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (!t->hits) return fail(THX_ERR_INVALID, "tracer was not created with the record response");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
@@ -699,17 +707,20 @@ static int writeQueue(thx_tracer* t, float* dst, size_t have, const void* src, s
 
 int thx_tracer_write_light(thx_tracer* t, uint32_t cfg, const void* src, size_t nbytes) {
     if (!t || !src || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     const size_t have = ((t->desc.flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) ? 15 : 8) * 4 * (size_t)t->desc.light_queue_capacity;
     return writeQueue(t, t->lightIn[cfg], have, src, nbytes, "host light source");
 }
 
 int thx_tracer_write_wavelengths(thx_tracer* t, uint32_t cfg, const void* src, size_t nbytes) {
     if (!t || !src || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     return writeQueue(t, t->lamIn[cfg], 2 * 4 * (size_t)t->desc.wavelength_queue_capacity, src, nbytes, "host wavelength source");
 }
 
 int thx_tracer_read_samples(thx_tracer* t, void* light_out, size_t light_nbytes, void* wavelength_out, size_t wavelength_nbytes) {
     if (!t || !light_out || !wavelength_out) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (t->desc.kind != THX_TRACER_LIGHT_SAMPLER) return fail(THX_ERR_INVALID, "tracer is not a THX_TRACER_LIGHT_SAMPLER");
     const size_t nb = 4 + hitColumns(t->desc) * 4 * (size_t)t->desc.capacity, nl = 4 + 2 * 4 * (size_t)t->desc.capacity;
     if (light_nbytes != nb || wavelength_nbytes != nl) return fail(THX_ERR_INVALID, "queue sizes do not match the sampler's capacity / polarization");
@@ -722,6 +733,7 @@ int thx_tracer_read_samples(thx_tracer* t, void* light_out, size_t light_nbytes,
 
 int thx_tracer_write_hits(thx_tracer* t, const void* src, size_t nbytes) {
     if (!t || !src) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (!t->replayIn) return fail(THX_ERR_INVALID, "tracer is not a THX_TRACER_HIT_REPLAY");
     const size_t have = thx_hit_queue_bytes(t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) ? 1u : 0u);
     if (nbytes != have) return fail(THX_ERR_INVALID, "queue size does not match the replay's capacity / polarization");
@@ -739,6 +751,7 @@ int thx_tracer_hits_device_ptr(thx_tracer* t, uint64_t* dev_addr) {
 
 int thx_tracer_read_track(thx_tracer* t, float* out, size_t n_floats) {
     if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (!t->track) return fail(THX_ERR_INVALID, "tracer was created without THX_FLAG_TRACK");
     size_t have = (size_t)THX_TRACK_WORDS * t->trackEvents * t->desc.capacity;
     if (n_floats > have) return fail(THX_ERR_INVALID, "track buffer is smaller than requested");
@@ -750,6 +763,7 @@ int thx_tracer_read_track(thx_tracer* t, float* out, size_t n_floats) {
 
 int thx_tracer_last_kernel_ms(thx_tracer* t, uint32_t cfg, float* ms) {
     if (!t || !ms || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (t->lastSlot[cfg] < 0) return fail(THX_ERR_INVALID, "no launch recorded for this config");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipEventSynchronize(t->evStop[t->lastSlot[cfg]]));
@@ -759,6 +773,7 @@ int thx_tracer_last_kernel_ms(thx_tracer* t, uint32_t cfg, float* ms) {
 
 int thx_tracer_kernel_times(thx_tracer* t, float* ms_out, uint32_t n, uint32_t* n_written) {
     if (!t || !ms_out || !n_written) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
     THX_HIP(hipSetDevice(t->ctx->device));
     uint64_t have = std::min<uint64_t>(t->launches, thx_tracer::kRing);
     uint32_t take = (uint32_t)std::min<uint64_t>(have, n);
