@@ -76,14 +76,24 @@ typedef struct {
     float radius;
     float invPos[3];
     float invRad;
-    float hemisphereProb;
+    float hemisphereProb; /* inner sphere / disk / flat: prob = 1 / area */
+    /* DiskTarget / FlatTarget only (THX_FLAG_TARGET_DISK / _FLAT; target.py:252-259, 384-391;
+     * target.disk.glsl:6-13, target.flat.glsl:6-15): position = centre, objToWorld column major */
+    float normal[3];
+    float objToWorld[9];
+    float width, height;
 } thx_target_params;
 
 /* src/theia/target.py:496-501; shader/target_guide.sphere.glsl:7-10 */
 typedef struct {
     float position[3];
     float radius;
-    float prob;
+    float prob; /* sphere: unused by the shader; disk / flat: 1 / area */
+    /* DiskTargetGuide / FlatTargetGuide only (THX_FLAG_GUIDE_DISK / _FLAT; target.py:575-583, 672-679;
+     * target_guide.disk.glsl:6-12, target_guide.flat.glsl:6-13) */
+    float normal[3];
+    float objToWorld[9];
+    float width, height;
 } thx_guide_params;
 
 /* shader/ray.propagate.glsl:18-26 */
@@ -171,6 +181,10 @@ enum {
     THX_FLAG_LIGHT_CONE            = 1u << 17, /* ConeLightSource (lightsource.cone.glsl) */
     THX_FLAG_LIGHT_POLARIZED       = 1u << 18, /* LIGHTSOURCE_POLARIZED of the cone source */
     THX_FLAG_WAVELENGTH_FUNCTION   = 1u << 19, /* FunctionWavelengthSource (wavelengthsource.function.glsl) */
+    THX_FLAG_TARGET_DISK           = 1u << 20, /* volume tracer: DiskTarget (target.disk.glsl) */
+    THX_FLAG_TARGET_FLAT           = 1u << 21, /* volume tracer: FlatTarget (target.flat.glsl) */
+    THX_FLAG_GUIDE_DISK            = 1u << 22, /* scene tracer: DiskTargetGuide (target_guide.disk.glsl), else sphere */
+    THX_FLAG_GUIDE_FLAT            = 1u << 23, /* scene tracer: FlatTargetGuide (target_guide.flat.glsl) */
     THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
                                                   absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;
@@ -330,6 +344,18 @@ int thx_tracer_kernel_times(thx_tracer* tracer, float* ms_out, uint32_t n, uint3
 int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream,
                  uint32_t n_streams, uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
                  float* out_f32);
+
+/* ---- target / guide probes (replace theia.testing.TargetSampler / TargetGuideSampler,
+ * src/theia/testing.py:439-640; shader/target.sample.glsl, target_guide.sample.glsl): stream i draws
+ * an observer in the box and a direction on the unit sphere, then samples and intersects the target
+ * (`flags`: THX_FLAG_TARGET_* / THX_FLAG_GUIDE_*). target_out[i][25] = observer3 direction3
+ * samplePos3 sampleNrm3 sampleProb sampleValid(u32) sampleError(i32) hitPos3 hitNrm3 hitProb
+ * hitValid(u32) hitError(i32) occluded(u32); guide_out[i][13] = observer3 sampleDir3 sampleDist
+ * sampleProb evalDir3 evalDist evalProb ---- */
+int thx_probe_target(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flags, const thx_target_params* target,
+                     const float box_min[3], const float box_max[3], uint32_t n, float* target_out);
+int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flags, const thx_guide_params* guide,
+                    const float box_min[3], const float box_max[3], uint32_t n, float* guide_out);
 
 #ifdef __cplusplus
 }

@@ -33,6 +33,10 @@ FLAG_WAVELENGTH_HOST = 1 << 16
 FLAG_LIGHT_CONE = 1 << 17
 FLAG_LIGHT_POLARIZED = 1 << 18
 FLAG_WAVELENGTH_FUNCTION = 1 << 19
+FLAG_TARGET_DISK = 1 << 20
+FLAG_TARGET_FLAT = 1 << 21
+FLAG_GUIDE_DISK = 1 << 22
+FLAG_GUIDE_FLAT = 1 << 23
 TRACK_WORDS = 20
 N_STATS = 20
 
@@ -55,11 +59,13 @@ class WavelengthParams(_P):
 
 
 class TargetParams(_P):
-    _fields_ = [("position", C.c_float * 3), ("radius", C.c_float), ("invPos", C.c_float * 3), ("invRad", C.c_float), ("hemisphereProb", C.c_float)]
+    _fields_ = [("position", C.c_float * 3), ("radius", C.c_float), ("invPos", C.c_float * 3), ("invRad", C.c_float), ("hemisphereProb", C.c_float),
+                ("normal", C.c_float * 3), ("objToWorld", C.c_float * 9), ("width", C.c_float), ("height", C.c_float)]
 
 
 class GuideParams(_P):
-    _fields_ = [("position", C.c_float * 3), ("radius", C.c_float), ("prob", C.c_float)]
+    _fields_ = [("position", C.c_float * 3), ("radius", C.c_float), ("prob", C.c_float),
+                ("normal", C.c_float * 3), ("objToWorld", C.c_float * 9), ("width", C.c_float), ("height", C.c_float)]
 
 
 class PropagateParams(_P):
@@ -249,6 +255,28 @@ def trace_volume(common: Common, trace: VolumeTraceParams, target: TargetParams,
     if rc != 0:
         raise RuntimeError(f"orc_trace_volume failed: {rc}")
     return hist, stats, tr
+
+
+def probe_target(philox: PhiloxParams, flags: int, target: TargetParams, box_min, box_max, n: int) -> np.ndarray:
+    """theia.testing.TargetSampler: [n][25] words (see theia_oracle.h)"""
+    fn = lib().orc_probe_target
+    fn.argtypes = [C.POINTER(PhiloxParams), C.c_uint32, C.POINTER(TargetParams), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
+    fn.restype = None
+    out = np.zeros((int(n), 25), dtype=np.float32)
+    lo, hi = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max)
+    fn(C.byref(philox), int(flags), C.byref(target), lo, hi, int(n), out.ctypes.data)
+    return out
+
+
+def probe_guide(philox: PhiloxParams, flags: int, guide: GuideParams, box_min, box_max, n: int) -> np.ndarray:
+    """theia.testing.TargetGuideSampler: [n][13] floats"""
+    fn = lib().orc_probe_guide
+    fn.argtypes = [C.POINTER(PhiloxParams), C.c_uint32, C.POINTER(GuideParams), C.POINTER(C.c_float), C.POINTER(C.c_float), C.c_uint32, C.c_void_p]
+    fn.restype = None
+    out = np.zeros((int(n), 13), dtype=np.float32)
+    lo, hi = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max)
+    fn(C.byref(philox), int(flags), C.byref(guide), lo, hi, int(n), out.ctypes.data)
+    return out
 
 
 def set_light_queue(queue: np.ndarray | None, capacity: int = 0) -> None:

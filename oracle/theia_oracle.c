@@ -51,6 +51,13 @@ static inline vec3 v_cross(vec3 a, vec3 b) {
 static inline vec3 m3_mul(mat3 m, vec3 v) {
     return v_add(v_add(v_scale(m.c0, v.x), v_scale(m.c1, v.y)), v_scale(m.c2, v.z));
 }
+static inline mat3 m3_transpose(mat3 m) {
+    mat3 t;
+    t.c0.x = m.c0.x; t.c0.y = m.c1.x; t.c0.z = m.c2.x;
+    t.c1.x = m.c0.y; t.c1.y = m.c1.y; t.c1.z = m.c2.y;
+    t.c2.x = m.c0.z; t.c2.y = m.c1.z; t.c2.z = m.c2.z;
+    return t;
+}
 static inline float f_clamp(float x, float lo, float hi) { return fminf(fmaxf(x, lo), hi); }
 static inline float f_mix(float a, float b, float t) { return a * (1.0f - t) + b * t; }
 static inline float get3(vec3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
@@ -942,7 +949,7 @@ typedef struct {
     float prob;
     int valid;
     vec3 offset;
-    float invRad; /* worldToObj = mat3(invRad) */
+    mat3 worldToObj; /* spheres: mat3(invRad) */
 } TargetSample;
 
 /* math.sphere.glsl:14-39; returns nearest t (x component) */
@@ -964,11 +971,17 @@ static float intersectSphereNear(vec3 center, float radius, vec3 origin, vec3 di
     return rx;
 }
 
+static mat3 diag3(float d) {
+    mat3 m;
+    m.c0 = V3(d, 0, 0); m.c1 = V3(0, d, 0); m.c2 = V3(0, 0, d);
+    return m;
+}
+
 static TargetSample targetMiss(void) { /* target.common.glsl:79-91 */
     TargetSample s;
     memset(&s, 0, sizeof(s));
     s.dist = INFINITY;
-    s.invRad = 1.0f;
+    s.worldToObj = diag3(1.0f);
     return s;
 }
 
@@ -991,6 +1004,88 @@ static float intersectSphereFar(vec3 center, float radius, vec3 origin, vec3 dir
 }
 
 static int g_target_inner = 0; /* set per trace from ORC_FLAG_TARGET_INNER */
+static int g_target_flat = 0;  /* 1: DiskTarget, 2: FlatTarget (ORC_FLAG_TARGET_DISK / _FLAT) */
+
+/* util.sample.glsl:31-56: concentric mapping of the unit square onto the unit disk */
+static vec3 sampleUnitDisk(float u0, float u1) {
+    float rx = 2.0f * u0 - 1.0f, ry = 2.0f * u1 - 1.0f;
+    if (rx == 0.0f && ry == 0.0f) return V3(0, 0, 0);
+    float phi, r;
+    if (fabsf(rx) > fabsf(ry)) {
+        r = rx;
+        phi = 0.78539816339744830962f * (ry / rx);
+    } else {
+        r = ry;
+        phi = 1.57079632679489661923f - 0.78539816339744830962f * (rx / ry);
+    }
+    return V3(r * cosf(phi), r * sinf(phi), 0.0f);
+}
+
+static mat3 targetObjToWorld(const float m[9]) { /* column major */
+    mat3 o;
+    o.c0 = V3(m[0], m[1], m[2]); o.c1 = V3(m[3], m[4], m[5]); o.c2 = V3(m[6], m[7], m[8]);
+    return o;
+}
+static float f_sign(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+/* target.disk.glsl:15-41 / target.flat.glsl:17-45 */
+static TargetSample sampleTargetPlane(Ctx* x, const orc_target_params* tp, vec3 observer, uint32_t idx, uint32_t* dim) {
+    float u0 = rnd(x, idx, dim);
+    float u1 = rnd(x, idx, dim);
+    vec3 localPos = g_target_flat == 1 ? v_scale(sampleUnitDisk(u0, u1), tp->radius)
+                                       : V3(tp->width * (u0 - 0.5f), tp->height * (u1 - 0.5f), 0.0f);
+    mat3 o2w = targetObjToWorld(tp->objToWorld);
+    vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
+    vec3 pos = v_add(m3_mul(o2w, localPos), center);
+    vec3 normal = V3(tp->normal[0], tp->normal[1], tp->normal[2]);
+    float side = f_sign(v_dot(normal, v_sub(observer, pos)));
+    normal = v_scale(normal, side);
+    TargetSample s;
+    memset(&s, 0, sizeof(s));
+    s.position = pos; s.normal = normal; s.dist = v_distance(observer, pos);
+    s.objPosition = localPos; s.objNormal = V3(0.0f, 0.0f, side);
+    s.prob = tp->hemisphereProb; s.valid = v_dot(normal, normal) != 0.0f;
+    s.worldToObj = m3_transpose(o2w);
+    s.offset = v_scale(m3_mul(s.worldToObj, center), -1.0f);
+    return s;
+}
+/* target.disk.glsl:43-66 / target.flat.glsl:47-72 */
+static TargetSample intersectTargetPlane(const orc_target_params* tp, vec3 observer, vec3 direction) {
+    mat3 o2w = targetObjToWorld(tp->objToWorld);
+    mat3 w2o = m3_transpose(o2w);
+    vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
+    vec3 localObs = m3_mul(w2o, v_sub(observer, center));
+    vec3 localDir = m3_mul(w2o, direction);
+    float t = -localObs.z / localDir.z;
+    vec3 localPos = v_add(localObs, v_scale(localDir, t));
+    int valid;
+    if (g_target_flat == 1) valid = t > 0.0f && sqrtf(localPos.x * localPos.x + localPos.y * localPos.y) <= tp->radius;
+    else valid = t > 0.0f && 2.0f * fabsf(localPos.x) <= tp->width && 2.0f * fabsf(localPos.y) <= tp->height;
+    vec3 pos = v_add(m3_mul(o2w, localPos), center);
+    float side = signBit(localObs.z);
+    TargetSample s;
+    memset(&s, 0, sizeof(s));
+    s.position = pos; s.normal = v_scale(V3(tp->normal[0], tp->normal[1], tp->normal[2]), side);
+    /* DEVIATION from target.disk.glsl:60 / target.flat.glsl:66, which report the distance to the plane
+     * even when the outline is missed or the plane lies behind the ray: the tracers take
+     * min(hit.dist, free path) (tracer.volume.forward.glsl:167), so the reference stops every ray at
+     * the infinite plane and walks rays that point away from it BACKWARDS onto it (negative distance,
+     * earlier time, exp(+mu_e d) contribution). No test or example of the reference traces with these
+     * targets. A miss is a miss here: infinite distance, like createTargetSampleMiss(). */
+    s.dist = valid ? t : INFINITY;
+    s.objPosition = localPos; s.objNormal = V3(0.0f, 0.0f, side);
+    s.prob = tp->hemisphereProb * (valid ? 1.0f : 0.0f); s.valid = valid;
+    s.worldToObj = w2o;
+    s.offset = v_scale(m3_mul(w2o, center), -1.0f);
+    return s;
+}
+/* isOccludedByTarget: target.sphere.glsl:80-83 (inside), target.sphere.inner.glsl:59-61 (outside),
+ * target.disk.glsl:68-71 / target.flat.glsl:74-77 (never) */
+static int isOccludedByTarget(const orc_target_params* tg, vec3 observer) {
+    if (g_target_flat) return 0;
+    float d = v_distance(observer, V3(tg->position[0], tg->position[1], tg->position[2]));
+    return g_target_inner ? d >= tg->radius : d <= tg->radius;
+}
 
 /* target.sphere.inner.glsl:36-57 */
 static TargetSample intersectTargetInner(const orc_target_params* tp, vec3 observer, vec3 direction) {
@@ -1005,12 +1100,13 @@ static TargetSample intersectTargetInner(const orc_target_params* tp, vec3 obser
     s.objPosition = v_scale(nrm, -1.0f); s.objNormal = nrm;
     s.prob = tp->hemisphereProb; s.valid = hit;
     s.offset = V3(tp->invPos[0], tp->invPos[1], tp->invPos[2]);
-    s.invRad = tp->invRad;
+    s.worldToObj = diag3(tp->invRad);
     return s;
 }
 
 /* target.sphere.glsl:45-78 */
 static TargetSample intersectTarget(const orc_target_params* tp, vec3 observer, vec3 direction) {
+    if (g_target_flat) return intersectTargetPlane(tp, observer, direction);
     if (g_target_inner) return intersectTargetInner(tp, observer, direction);
     vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
     float t = intersectSphereNear(center, tp->radius, observer, direction);
@@ -1028,13 +1124,14 @@ static TargetSample intersectTarget(const orc_target_params* tp, vec3 observer, 
     s.objPosition = nrm; s.objNormal = nrm;
     s.prob = prob; s.valid = valid;
     s.offset = V3(tp->invPos[0], tp->invPos[1], tp->invPos[2]);
-    s.invRad = tp->invRad;
+    s.worldToObj = diag3(tp->invRad);
     return s;
 }
 
 /* target.sphere.glsl:18-43 */
 static TargetSample sampleTarget(Ctx* x, const orc_target_params* tp, vec3 observer, uint32_t idx,
                                  uint32_t* dim) {
+    if (g_target_flat) return sampleTargetPlane(x, tp, observer, idx, dim);
     vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
     if (g_target_inner) { /* target.sphere.inner.glsl:18-34: uniform over the sphere */
         float v0 = rnd(x, idx, dim);
@@ -1047,7 +1144,7 @@ static TargetSample sampleTarget(Ctx* x, const orc_target_params* tp, vec3 obser
         s.objPosition = normal; s.objNormal = v_scale(normal, -1.0f);
         s.prob = tp->hemisphereProb; s.valid = 1;
         s.offset = V3(tp->invPos[0], tp->invPos[1], tp->invPos[2]);
-        s.invRad = tp->invRad;
+        s.worldToObj = diag3(tp->invRad);
         return s;
     }
     vec3 dir = v_normalize(v_sub(observer, center));
@@ -1068,14 +1165,8 @@ static TargetSample sampleTarget(Ctx* x, const orc_target_params* tp, vec3 obser
     s.objPosition = normal; s.objNormal = normal;
     s.prob = prob; s.valid = valid;
     s.offset = V3(tp->invPos[0], tp->invPos[1], tp->invPos[2]);
-    s.invRad = tp->invRad;
+    s.worldToObj = diag3(tp->invRad);
     return s;
-}
-
-static mat3 diag3(float d) {
-    mat3 m;
-    m.c0 = V3(d, 0, 0); m.c1 = V3(0, d, 0); m.c2 = V3(0, 0, d);
-    return m;
 }
 
 /* tracer.volume.forward.glsl:51-82 */
@@ -1087,7 +1178,7 @@ static void vol_createResponse(Ctx* x, const orc_volume_trace_params* tp, Ray ra
     if (code < 0) return;
     ray.lin_contrib *= weight;
     HitItem item = createHit(x, &ray, hit->objPosition, hit->objNormal, tp->objectId,
-                             diag3(hit->invRad));
+                             hit->worldToObj);
     if (item.contrib > 0.0f) response(x, &item);
 }
 
@@ -1138,7 +1229,7 @@ static int vol_trace(Ctx* x, const orc_volume_trace_params* tp, const orc_target
     if (hitValid && allowResponse) {
         alignRayToHit(x, ray, hit.normal);
         HitItem item = createHit(x, ray, hit.objPosition, hit.objNormal, tp->objectId,
-                                 diag3(hit.invRad));
+                                 hit.worldToObj);
         if (item.contrib > 0.0f) response(x, &item);
         return RESULT_CODE_RAY_DETECTED;
     } else if (hitValid) {
@@ -1159,8 +1250,7 @@ static void vol_photonMain(Ctx* x, const orc_volume_trace_params* tp, const orc_
     x->cur_idx = idx; x->cur_dim = &dim;
     Ray ray = sampleRay(x, x->global_medium, idx, &dim);
     onEvent(x, &ray, RESULT_CODE_RAY_CREATED, local_idx, 0, dim);
-    vec3 center = V3(tg->position[0], tg->position[1], tg->position[2]);
-    if (g_target_inner ? (v_distance(ray.position, center) >= tg->radius) : (v_distance(ray.position, center) <= tg->radius)) {
+    if (isOccludedByTarget(tg, ray.position)) {
         onEvent(x, &ray, ERROR_CODE_TRACE_ABORT, local_idx, 0, dim);
         return;
     }
@@ -1178,7 +1268,7 @@ static void vol_photonMain(Ctx* x, const orc_volume_trace_params* tp, const orc_
         if (result >= 0) {
             if (hitValid) {
                 alignRayToHit(x, &ray, hit.normal);
-                HitItem item = createHit(x, &ray, hit.objPosition, hit.objNormal, tp->objectId, diag3(hit.invRad));
+                HitItem item = createHit(x, &ray, hit.objPosition, hit.objNormal, tp->objectId, hit.worldToObj);
                 if (item.contrib > 0.0f) response(x, &item);
                 result = RESULT_CODE_RAY_ABSORBED;
             } else {
@@ -1223,9 +1313,7 @@ static void vol_traceMain(Ctx* x, const orc_volume_trace_params* tp, const orc_t
     Ray ray = sampleRay(x, x->global_medium, idx, &dim);
     onEvent(x, &ray, RESULT_CODE_RAY_CREATED, local_idx, 0, dim);
     /* target.sphere.glsl:80-83 */
-    vec3 center = V3(tg->position[0], tg->position[1], tg->position[2]);
-    /* isOccludedByTarget: target.sphere.glsl:80-83 (inside) / target.sphere.inner.glsl:59-61 (outside) */
-    if (g_target_inner ? (v_distance(ray.position, center) >= tg->radius) : (v_distance(ray.position, center) <= tg->radius)) {
+    if (isOccludedByTarget(tg, ray.position)) {
         onEvent(x, &ray, ERROR_CODE_TRACE_ABORT, local_idx, 0, dim);
         return;
     }
@@ -1735,9 +1823,57 @@ static void guideCone(const orc_guide_params* g, vec3 observer, float* d_out, ve
     *d_out = d; *cosMin = cm; *prob = p;
 }
 
+static int g_guide_flat = 0; /* 1: DiskTargetGuide, 2: FlatTargetGuide (ORC_FLAG_GUIDE_DISK / _FLAT) */
+
+/* target_guide.common.glsl:10-32 */
+static GuideSample guideSampleFromPoint(vec3 observer, vec3 targetPos, vec3 targetNrm, float targetProb) {
+    vec3 dir = v_sub(targetPos, observer);
+    float d2 = v_dot(dir, dir);
+    dir = v_normalize(dir);
+    float cosNormal = v_dot(dir, targetNrm);
+    float prob = targetProb * d2 / fabsf(cosNormal);
+    if (isinf(prob)) prob = 0.0f;
+    prob *= (float)(cosNormal < 0.0f);
+    GuideSample s;
+    s.dir = dir; s.dist = v_distance(targetPos, observer); s.prob = prob;
+    return s;
+}
+/* target_guide.common.glsl:34-51 */
+static GuideSample guideSampleFromDir(vec3 dir, float dist, vec3 targetNrm, float targetProb) {
+    float cosNormal = v_dot(dir, targetNrm);
+    float prob = targetProb * dist * dist / fabsf(cosNormal);
+    if (isinf(prob)) prob = 0.0f;
+    prob *= (float)(cosNormal < 0.0f);
+    GuideSample s;
+    s.dir = dir; s.dist = dist; s.prob = prob;
+    return s;
+}
+/* target_guide.disk.glsl:15-23 / target_guide.flat.glsl:17-29 */
+static GuideSample sampleGuidePlane(Ctx* x, const orc_guide_params* g, vec3 observer, uint32_t idx, uint32_t* dim) {
+    float u0 = rnd(x, idx, dim);
+    float u1 = rnd(x, idx, dim);
+    vec3 localPos = g_guide_flat == 1 ? v_scale(sampleUnitDisk(u0, u1), g->radius)
+                                      : V3(g->width * (u0 - 0.5f), g->height * (u1 - 0.5f), 0.0f);
+    vec3 pos = v_add(m3_mul(targetObjToWorld(g->objToWorld), localPos), V3(g->position[0], g->position[1], g->position[2]));
+    return guideSampleFromPoint(observer, pos, V3(g->normal[0], g->normal[1], g->normal[2]), g->prob);
+}
+/* target_guide.disk.glsl:25-44 / target_guide.flat.glsl:31-48 */
+static GuideSample evalGuidePlane(const orc_guide_params* g, vec3 observer, vec3 direction) {
+    mat3 w2o = m3_transpose(targetObjToWorld(g->objToWorld));
+    vec3 localObs = m3_mul(w2o, v_sub(observer, V3(g->position[0], g->position[1], g->position[2])));
+    vec3 localDir = m3_mul(w2o, direction);
+    float t = -localObs.z / localDir.z;
+    vec3 localHit = v_add(localObs, v_scale(localDir, t));
+    int valid = t > 0.0f && !isinf(t) && !isnan(t);
+    if (g_guide_flat == 1) valid = valid && sqrtf(localHit.x * localHit.x + localHit.y * localHit.y) <= g->radius;
+    else valid = valid && 2.0f * fabsf(localHit.x) <= g->width && 2.0f * fabsf(localHit.y) <= g->height;
+    return guideSampleFromDir(direction, t, V3(g->normal[0], g->normal[1], g->normal[2]), g->prob * (valid ? 1.0f : 0.0f));
+}
+
 /* target_guide.sphere.glsl:15-51 */
 static GuideSample sampleTargetGuide(Ctx* x, const orc_guide_params* g, vec3 observer,
                                      uint32_t idx, uint32_t* dim) {
+    if (g_guide_flat) return sampleGuidePlane(x, g, observer, idx, dim);
     float d, cosMin, prob;
     vec3 viewDir;
     guideCone(g, observer, &d, &viewDir, &cosMin, &prob);
@@ -1753,6 +1889,7 @@ static GuideSample sampleTargetGuide(Ctx* x, const orc_guide_params* g, vec3 obs
 }
 /* target_guide.sphere.glsl:53-81 */
 static GuideSample evalTargetGuide(const orc_guide_params* g, vec3 observer, vec3 direction) {
+    if (g_guide_flat) return evalGuidePlane(g, observer, direction);
     float d, cosMin, prob;
     vec3 viewDir;
     guideCone(g, observer, &d, &viewDir, &cosMin, &prob);
@@ -2050,6 +2187,7 @@ int orc_trace_volume(const orc_common* c, const orc_volume_trace_params* t,
     x.polarized = (c->flags & ORC_FLAG_POLARIZED) != 0;
     x.use_global_medium = 1;
     g_target_inner = (c->flags & ORC_FLAG_TARGET_INNER) != 0;
+    g_target_flat = (c->flags & ORC_FLAG_TARGET_DISK) ? 1 : ((c->flags & ORC_FLAG_TARGET_FLAT) ? 2 : 0);
     x.global_medium = (uint64_t)t->medium[0] | ((uint64_t)t->medium[1] << 32);
     x.prop = t->propagation;
     VolArgs a = {t, target};
@@ -2094,10 +2232,88 @@ int orc_replay(const orc_common* c, const uint32_t* queue, uint32_t capacity, in
     return run_blocks(c, &x, replay_item, &a, n_threads, hist_out, stats, NULL, 0);
 }
 
+/* target.sample.glsl:19-83 */
+static void putSample(float* o, vec3 observer, const TargetSample* ts, int checkDir, vec3 direction) {
+    mat3 m = ts->worldToObj;
+    float expD = v_distance(ts->position, observer);
+    vec3 expPos = v_add(m3_mul(m, ts->position), ts->offset);
+    vec3 expNrm = v_normalize(m3_mul(m, ts->normal));
+    int error = 0;
+    error += (int)(fabsf(expD - ts->dist) > 1e-5f);
+    error += (int)(v_length(v_sub(expPos, ts->objPosition)) > 1e-5f) << 1;
+    error += (int)(v_length(v_sub(expNrm, ts->objNormal)) > 1e-5f) << 2;
+    if (checkDir) {
+        vec3 sampleDir = v_normalize(v_sub(ts->position, observer));
+        error += (int)(v_length(v_sub(sampleDir, direction)) > 1e-5f) << 3;
+    }
+    o[0] = ts->position.x; o[1] = ts->position.y; o[2] = ts->position.z;
+    o[3] = ts->normal.x; o[4] = ts->normal.y; o[5] = ts->normal.z;
+    o[6] = ts->prob;
+    uint32_t valid = ts->valid ? 1u : 0u;
+    memcpy(&o[7], &valid, 4);
+    int32_t e = error;
+    memcpy(&o[8], &e, 4);
+}
+static void probeObserver(Ctx* x, uint32_t i, uint32_t* dim, const float lo[3], const float hi[3], vec3* observer, vec3* direction) {
+    float a = rnd(x, i, dim), b = rnd(x, i, dim), c = rnd(x, i, dim);
+    *observer = V3(f_mix(lo[0], hi[0], a), f_mix(lo[1], hi[1], b), f_mix(lo[2], hi[2], c));
+    float u0 = rnd(x, i, dim), u1 = rnd(x, i, dim);
+    *direction = sphericalToCartessian(TWO_PI_F * u0, 2.0f * u1 - 1.0f); /* util.sample.glsl:84-88 */
+}
+void orc_probe_target(const orc_philox_params* philox, uint32_t flags, const orc_target_params* target,
+                      const float box_min[3], const float box_max[3], uint32_t n, float* out) {
+    orc_common c;
+    memset(&c, 0, sizeof(c));
+    c.philox = *philox;
+    Ctx x;
+    memset(&x, 0, sizeof(x));
+    x.c = &c;
+    g_target_inner = (flags & ORC_FLAG_TARGET_INNER) != 0;
+    g_target_flat = (flags & ORC_FLAG_TARGET_DISK) ? 1 : ((flags & ORC_FLAG_TARGET_FLAT) ? 2 : 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t dim = 0;
+        vec3 observer, direction;
+        probeObserver(&x, i, &dim, box_min, box_max, &observer, &direction);
+        TargetSample s = sampleTarget(&x, target, observer, i, &dim);
+        TargetSample h = intersectTarget(target, observer, direction);
+        float* o = out + (size_t)i * 25;
+        o[0] = observer.x; o[1] = observer.y; o[2] = observer.z;
+        o[3] = direction.x; o[4] = direction.y; o[5] = direction.z;
+        putSample(o + 6, observer, &s, 0, direction);
+        putSample(o + 15, observer, &h, 1, direction);
+        uint32_t occ = isOccludedByTarget(target, observer) ? 1u : 0u;
+        memcpy(&o[24], &occ, 4);
+    }
+    g_target_inner = 0; g_target_flat = 0;
+}
+void orc_probe_guide(const orc_philox_params* philox, uint32_t flags, const orc_guide_params* guide,
+                     const float box_min[3], const float box_max[3], uint32_t n, float* out) {
+    orc_common c;
+    memset(&c, 0, sizeof(c));
+    c.philox = *philox;
+    Ctx x;
+    memset(&x, 0, sizeof(x));
+    x.c = &c;
+    g_guide_flat = (flags & ORC_FLAG_GUIDE_DISK) ? 1 : ((flags & ORC_FLAG_GUIDE_FLAT) ? 2 : 0);
+    for (uint32_t i = 0; i < n; ++i) {
+        uint32_t dim = 0;
+        vec3 observer, direction;
+        probeObserver(&x, i, &dim, box_min, box_max, &observer, &direction);
+        GuideSample s = sampleTargetGuide(&x, guide, observer, i, &dim);
+        GuideSample e = evalTargetGuide(guide, observer, direction);
+        float* o = out + (size_t)i * 13;
+        o[0] = observer.x; o[1] = observer.y; o[2] = observer.z;
+        o[3] = s.dir.x; o[4] = s.dir.y; o[5] = s.dir.z; o[6] = s.dist; o[7] = s.prob;
+        o[8] = e.dir.x; o[9] = e.dir.y; o[10] = e.dir.z; o[11] = e.dist; o[12] = e.prob;
+    }
+    g_guide_flat = 0;
+}
+
 int orc_trace_scene(const orc_common* c, const orc_scene_trace_params* t,
                     const orc_guide_params* guide, const orc_scene* scene, int n_threads,
                     float* hist_out, uint64_t stats[20], float* track) {
     Ctx x;
+    g_guide_flat = (c->flags & ORC_FLAG_GUIDE_DISK) ? 1 : ((c->flags & ORC_FLAG_GUIDE_FLAT) ? 2 : 0);
     memset(&x, 0, sizeof(x));
     x.c = c;
     x.polarized = (c->flags & ORC_FLAG_POLARIZED) != 0;

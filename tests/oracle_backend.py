@@ -112,7 +112,8 @@ class OracleBackend:
         c = orc.Common()
         flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER | capi.FLAG_KERNEL_HISTOGRAM |
                                                      capi.FLAG_LIGHT_HOST | capi.FLAG_LIGHT_QUEUE_POLARIZED | capi.FLAG_WAVELENGTH_HOST |
-                                                     capi.FLAG_LIGHT_CONE | capi.FLAG_LIGHT_POLARIZED | capi.FLAG_WAVELENGTH_FUNCTION))
+                                                     capi.FLAG_LIGHT_CONE | capi.FLAG_LIGHT_POLARIZED | capi.FLAG_WAVELENGTH_FUNCTION |
+                                                     capi.FLAG_TARGET_DISK | capi.FLAG_TARGET_FLAT | capi.FLAG_GUIDE_DISK | capi.FLAG_GUIDE_FLAT))
         photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE
@@ -157,6 +158,18 @@ class OracleBackend:
         t.raw[cfg] = hist
         t.stats += stats
         t.track = track
+
+    def probe_target(self, philox, flags, target, box_min, box_max, n):
+        ph, tg = orc.PhiloxParams(), orc.TargetParams()
+        _copy(ph, philox)
+        _copy(tg, target)
+        return orc.probe_target(ph, flags, tg, box_min, box_max, n)
+
+    def probe_guide(self, philox, flags, guide, box_min, box_max, n):
+        ph, g = orc.PhiloxParams(), orc.GuideParams()
+        _copy(ph, philox)
+        _copy(g, guide)
+        return orc.probe_guide(ph, flags, g, box_min, box_max, n)
 
     def tracer_write_light(self, tracer: int, cfg: int, data: np.ndarray) -> None:
         t = self._tracers[tracer]

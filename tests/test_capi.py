@@ -32,7 +32,8 @@ def test_parameter_block_layouts():
     # the light block is the spherical source's UBO (28 B) followed by what only the pencil / cone sources read
     assert C.sizeof(capi.PhiloxParams) == 24 and C.sizeof(capi.LightParams) == 28 + 40 + 4 and capi.LightParams.direction.offset == 28
     assert C.sizeof(capi.WavelengthParams) == 12 + 8  # + table address of the function source
-    assert C.sizeof(capi.TargetParams) == 36 and C.sizeof(capi.GuideParams) == 20
+    # sphere blocks (36 B / 20 B) followed by what only the disk / flat variants read (normal, objToWorld, width, height)
+    assert C.sizeof(capi.TargetParams) == 36 + 56 and C.sizeof(capi.GuideParams) == 20 + 56 and capi.TargetParams.normal.offset == 36
     assert C.sizeof(capi.PropagateParams) == 36
     assert C.sizeof(capi.VolumeTraceParams) == 48 and C.sizeof(capi.SceneTraceParams) == 48
     assert capi.SceneTraceParams.sceneMedium.offset == 4  # uvec2 right behind the int
@@ -57,8 +58,12 @@ def test_parameter_block_layouts():
     assert C.sizeof(ConeLightSource.LightParams) == 72  # light.py:935-945
     assert C.sizeof(LightSampler.SampleParams) == 16  # light.py:538-543
     assert C.sizeof(PhiloxRNG.PhiloxParams) == C.sizeof(capi.PhiloxParams)
-    assert C.sizeof(SphereTarget.TargetParams) == C.sizeof(capi.TargetParams)
-    assert C.sizeof(SphereTargetGuide.TargetGuideParams) == C.sizeof(capi.GuideParams)
+    assert C.sizeof(SphereTarget.TargetParams) == capi.TargetParams.normal.offset
+    assert C.sizeof(SphereTargetGuide.TargetGuideParams) == capi.GuideParams.normal.offset
+    from theia_amd.target import DiskTarget, DiskTargetGuide, FlatTarget, FlatTargetGuide
+
+    assert C.sizeof(DiskTarget.TargetParams) == 68 and C.sizeof(FlatTarget.TargetParams) == 72  # target.py:252-259, 384-391
+    assert C.sizeof(DiskTargetGuide.TargetGuideParams) == 68 and C.sizeof(FlatTargetGuide.TargetGuideParams) == 72
     assert C.sizeof(VolumeForwardTracer.TraceParams) == C.sizeof(capi.VolumeTraceParams)
     assert C.sizeof(SceneForwardTracer.TraceParams) == C.sizeof(capi.SceneTraceParams)
 

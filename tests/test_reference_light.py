@@ -1,33 +1,34 @@
 """
-The reference's own tests of the light and wavelength sources the forward tracers can be fed
-from (/root/reference/tests/test_light.py:23-71 `test_hostLightSource`, :74-141 `test_streaming`,
-:144-151 `test_HostSamplerMismatch`, :154-169 `test_constWavelength`, :172-194
-`test_uniformWavelength`, :197-230 `test_functionWavelength`, :233-278 `test_coneLightSource_fwd`,
-:339-372 `test_pencilLightSource`, :375-411 `test_sphericalLightSource_fwd`), restated with their
-original bodies against the `theia` / `hephaistos` alias packages. They observe the sources
-through `LightSampler`; every case runs on the CPU oracle (`-m "not gpu"`) and, through the C
-ABI, on the HIP sampler kernel (`-m gpu`). The last tests feed a tracer from host queues and
-compare it with the same tracer sampling the source itself.
+What the reference's tests check about the light and wavelength sources a forward tracer can be
+fed from, restated in this suite's own form with the same sizes, seeds, expectations and
+tolerances (/root/reference/tests/test_light.py: :23-71 host sources, :74-141 streaming sources,
+:144-151 sampler / host queue mismatch, :154-169 const, :172-194 uniform and :197-230 function
+wavelengths, :233-278 cone, :339-372 pencil, :375-411 spherical source, forward mode). The sources
+are observed through `LightSampler`; every case runs on the CPU oracle (`-m "not gpu"`) and,
+through the C ABI, on the HIP sampler kernel (`-m gpu`). The last tests feed a tracer from host
+queues.
 
-Not restated: the `*_bwd` tests (backward tracers are out of scope), the Cherenkov / muon /
-cascade sources.
+Not restated: the backward-mode cases (backward tracers are out of scope) and the Cherenkov /
+muon / cascade sources.
 """
 import numpy as np
 import pytest
 
 import hephaistos.pipeline as pl
-import theia.light
+import theia.light as TL
 import theia.material
 import theia.response
 import theia.trace
 import theia.units as u
-from hephaistos.pipeline import Pipeline, PipelineScheduler, runPipeline
 from hephaistos.queue import dumpQueue
 from theia.random import PhiloxRNG
 from theia.target import SphereTarget
 from theia.testing import WaterTestModel
 
 BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+SEED = 0xC0FFEE  # tests/conftest.py:73-76 of the reference: a fresh default_rng per test
+KEY = 0xC0110FFC0FFEE
+N = 32 * 256
 
 
 @pytest.fixture(params=BACKENDS)
@@ -48,355 +49,178 @@ def backend(request):
         be.close()
 
 
-@pytest.fixture
-def rng():
-    # tests/conftest.py:73-76 of the reference
-    return np.random.default_rng(0xC0FFEE)
+def unit_sq(v):
+    return np.square(v).sum(-1)
+
+
+def sampled(light, photons, n=N, *, rng=None, polarized=False):
+    """runs a LightSampler once; returns (light samples, wavelength samples)"""
+    sampler = TL.LightSampler(light, photons, n, rng=rng, polarized=polarized)
+    pl.runPipeline(sampler.collectStages())
+    return sampler.lightQueue.view(0), sampler.wavelengthQueue.view(0)
+
+
+def random_rays(gen, n, polarized, *, swapped=False):
+    """positions in a 10 m cube and directions from two angles, drawn in the order of the reference's
+    tests (`swapped`: the direction components as test_streaming builds them)"""
+    pos = np.stack([(gen.random(n) * 10.0 - 5.0) * u.m for _ in range(3)], axis=-1)
+    cos_t = 2.0 * gen.random(n) - 1.0
+    sin_t = np.sqrt(1.0 - cos_t**2)
+    phi = gen.random(n) * 2.0 * np.pi
+    if swapped:
+        d = np.stack([sin_t * np.cos(phi), cos_t * np.cos(phi), np.sin(phi)], axis=-1)
+    else:
+        d = np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t], axis=-1)
+    return pos, d
 
 
 @pytest.mark.parametrize("polarized", [True, False])
-def test_hostLightSource(backend, rng, polarized: bool):
-    N = 32 * 256
-
-    # create light & sampler
-    photon = theia.light.HostWavelengthSource(N)
-    light = theia.light.HostLightSource(N, polarized=polarized)
-    sampler = theia.light.LightSampler(light, photon, N, polarized=polarized)
-
-    # fill input buffer
-    rays = light.queue.view(0)
-    photons = photon.queue.view(0)
-    x = (rng.random(N) * 10.0 - 5.0) * u.m
-    y = (rng.random(N) * 10.0 - 5.0) * u.m
-    z = (rng.random(N) * 10.0 - 5.0) * u.m
-    cos_theta = 2.0 * rng.random(N) - 1.0
-    sin_theta = np.sqrt(1.0 - cos_theta**2)
-    phi = rng.random(N) * 2.0 * np.pi
-    rays["position"] = np.stack([x, y, z], axis=-1)
-    rays["direction"] = np.stack(
-        [sin_theta * np.cos(phi), sin_theta * np.sin(phi), cos_theta],
-        axis=-1,
-    )
-    lam = (rng.random((N,)) * 600.0 + 200.0) * u.nm
-    photons["wavelength"] = lam
-    photons["contrib"] = rng.random((N,)) + 5.0
-    rays["startTime"] = rng.random((N,)) * 50.0 * u.ns
-    rays["contrib"] = rng.random((N,)) + 1.0
-    if polarized:
-        # We dont care about valid values
-        rays["stokes"] = rng.random((N, 4))
-        rays["polarizationRef"] = rng.random((N, 3))
-
-    # run
-    runPipeline([photon, light, sampler])
-    lightResult = sampler.lightQueue.view(0)
-    phResult = sampler.wavelengthQueue.view(0)
-
-    # check result
-    assert lightResult.count == N
-    assert np.allclose(lightResult["position"], rays["position"])
-    assert np.allclose(lightResult["direction"], rays["direction"])
-    assert np.allclose(lightResult["startTime"], rays["startTime"])
-    assert np.allclose(lightResult["contrib"], rays["contrib"])
-    assert np.allclose(phResult["contrib"], photons["contrib"])
-    assert np.allclose(phResult["wavelength"], lam)
-    if polarized:
-        assert np.allclose(lightResult["stokes"], rays["stokes"])
-        assert np.allclose(lightResult["polarizationRef"], rays["polarizationRef"])
+def test_host_sources_pass_their_queues_through(backend, polarized):
+    gen = np.random.default_rng(SEED)
+    lam_src, ray_src = TL.HostWavelengthSource(N), TL.HostLightSource(N, polarized=polarized)
+    rays, lams = ray_src.queue.view(0), lam_src.queue.view(0)
+    rays["position"], rays["direction"] = random_rays(gen, N, polarized)
+    lams["wavelength"] = (gen.random(N) * 600.0 + 200.0) * u.nm
+    lams["contrib"] = gen.random(N) + 5.0
+    rays["startTime"] = gen.random(N) * 50.0 * u.ns
+    rays["contrib"] = gen.random(N) + 1.0
+    if polarized:  # any values will do
+        rays["stokes"], rays["polarizationRef"] = gen.random((N, 4)), gen.random((N, 3))
+    got, got_lam = sampled(ray_src, lam_src, polarized=polarized)
+    assert got.count == N
+    for f in rays.fields:
+        assert np.allclose(got[f], rays[f]), f
+    for f in lams.fields:
+        assert np.allclose(got_lam[f], lams[f]), f
 
 
 @pytest.mark.parametrize("polarized", [False, True])
-def test_streaming(backend, rng, polarized: bool):
-    N = 5 * 512
-    batchSize = 1024
+def test_streaming_sources_walk_through_their_data(backend, polarized):
+    """two data sets of 2560 rays in batches of 1024 / 1024 / 512; the second set arrives with the
+    fourth task and rewinds the stream"""
+    total, batch = 5 * 512, 1024
+    gen = np.random.default_rng(SEED)
 
-    # create input data
-    def createData():
-        data = {}
-        data["contrib"] = 10.0 * rng.random(N)
-        data["wavelength"] = 200.0 + 500.0 * rng.random(N)
-        x = (rng.random(N) * 10.0 - 5.0) * u.m
-        y = (rng.random(N) * 10.0 - 5.0) * u.m
-        z = (rng.random(N) * 10.0 - 5.0) * u.m
-        cos_theta = 2.0 * rng.random(N) - 1.0
-        sin_theta = np.sqrt(1.0 - cos_theta**2)
-        phi = rng.random(N) * 2.0 * np.pi
-        data["position"] = np.stack([x, y, z], axis=-1)
-        dx = sin_theta * np.cos(phi)
-        dy = cos_theta * np.cos(phi)
-        dz = np.sin(phi)
-        data["direction"] = np.stack([dx, dy, dz], axis=-1)
-        data["startTime"] = 50.0 * rng.random(N)
+    def make():
+        d = {"contrib": 10.0 * gen.random(total), "wavelength": 200.0 + 500.0 * gen.random(total)}
+        d["position"], d["direction"] = random_rays(gen, total, polarized, swapped=True)
+        d["startTime"] = 50.0 * gen.random(total)
         if polarized:
-            # We dont care about valid values
-            data["stokes"] = rng.random((N, 4))
-            data["polarizationRef"] = rng.random((N, 3))
-        return data
+            d["stokes"], d["polarizationRef"] = gen.random((total, 4)), gen.random((total, 3))
+        return d
 
-    # create two data sets
-    data1 = createData()
-    data2 = createData()
-
-    # create light and sampler
-    photon = theia.light.StreamingHostWavelengthSource(
-        batchSize, data=data1, ignoreContrib=True
-    )
-    light = theia.light.StreamingHostLightSource(
-        batchSize, data=data1, polarized=polarized
-    )
-    sampler = theia.light.LightSampler(light, photon, batchSize, polarized=polarized)
-    # create pipeline + scheduler
-    lam = []
-    ray = []
-
-    def process(config: int, batch: int, args: None) -> None:
-        lam.append(dumpQueue(sampler.wavelengthQueue.view(config)))
-        ray.append(dumpQueue(sampler.lightQueue.view(config)))
-
-    pipeline = Pipeline(sampler.collectStages())
-    scheduler = PipelineScheduler(pipeline, processFn=process)
-    # create tasks to process all data
-    tasks = [{}, {}, {"count": 512}, {"data": data2, "count": 1024}, {}, {"count": 512}]
-    scheduler.schedule(tasks)
+    first, second = make(), make()
+    lam_src = TL.StreamingHostWavelengthSource(batch, data=first, ignoreContrib=True)
+    ray_src = TL.StreamingHostLightSource(batch, data=first, polarized=polarized)
+    sampler = TL.LightSampler(ray_src, lam_src, batch, polarized=polarized)
+    seen = []
+    scheduler = pl.PipelineScheduler(pl.Pipeline(sampler.collectStages()),
+                                     processFn=lambda cfg, k, args: seen.append((dumpQueue(sampler.lightQueue.view(cfg)),
+                                                                                 dumpQueue(sampler.wavelengthQueue.view(cfg)))))
+    scheduler.schedule([{}, {}, {"count": 512}, {"data": second, "count": 1024}, {}, {"count": 512}])
     scheduler.wait()
-
-    # reassemble results
-    fields = sampler.lightQueue.view(0).fields
-    sampled1 = {f: np.concatenate([ray[i][f] for i in range(3)]) for f in fields}
-    sampled1["wavelength"] = np.concatenate([lam[i]["wavelength"] for i in range(3)])
-    sampled2 = {f: np.concatenate([ray[i][f] for i in range(3, 6)]) for f in fields}
-    sampled2["wavelength"] = np.concatenate([lam[i]["wavelength"] for i in range(3, 6)])
-    # check results
-    for l in lam:
-        assert np.all(l["contrib"] == 1.0)
-    for field, values in sampled1.items():
-        assert np.allclose(data1[field], values)
-    for field, values in sampled2.items():
-        assert np.allclose(data2[field], values)
+    assert len(seen) == 6
+    for data, part in ((first, seen[:3]), (second, seen[3:])):
+        for f in sampler.lightQueue.view(0).fields:
+            assert np.allclose(np.concatenate([r[f] for r, _ in part]), data[f]), f
+        assert np.allclose(np.concatenate([w["wavelength"] for _, w in part]), data["wavelength"])
+    assert all(np.all(w["contrib"] == 1.0) for _, w in seen)  # ignoreContrib
 
 
-def test_HostSamplerMismatch():
-    photon = theia.light.ConstWavelengthSource()
-    with pytest.raises(RuntimeError):
-        light = theia.light.HostLightSource(128, polarized=True)
-        theia.light.LightSampler(light, photon, 128, polarized=False)
-    with pytest.raises(RuntimeError):
-        light = theia.light.HostLightSource(128, polarized=False)
-        theia.light.LightSampler(light, photon, 128, polarized=True)
+def test_sampler_refuses_a_host_queue_of_other_polarization():
+    for a, b in ((True, False), (False, True)):
+        with pytest.raises(RuntimeError):
+            TL.LightSampler(TL.HostLightSource(128, polarized=a), TL.ConstWavelengthSource(), 128, polarized=b)
 
 
-def test_constWavelength(backend):
-    N = 32 * 256
+def test_const_wavelength(backend):
     lam = 450.0 * u.nm
-
-    # create pipeline
-    philox = PhiloxRNG(key=0xC0110FFC0FFEE)
-    photons = theia.light.ConstWavelengthSource(lam)
-    light = theia.light.PencilLightSource(timeRange=(0.0, 0.0))
-    sampler = theia.light.LightSampler(light, photons, N, rng=philox)
-    # run
-    runPipeline([photons, light, sampler])
-    result = sampler.wavelengthQueue.view(0)
-
-    # check result
-    assert np.all(result["contrib"] == 1.0)
-    assert np.all(result["wavelength"] == lam)
+    _, got = sampled(TL.PencilLightSource(timeRange=(0.0, 0.0)), TL.ConstWavelengthSource(lam), rng=PhiloxRNG(key=KEY))
+    assert np.all(got["contrib"] == 1.0) and np.all(got["wavelength"] == lam)
 
 
 @pytest.mark.parametrize("normalize", [True, False])
-def test_uniformWavelength(backend, normalize: bool):
-    N = 32 * 256
-    lamRange, dLam = (350.0, 750.0) * u.nm, 400.0 * u.nm
-    timeRange = (0.0, 0.0) * u.ns
-    # contrib = L/p(t,lam); p(t, lam) = 1.0 / (|dLam|*|dt|)
-    contrib = 1.0 if normalize else dLam
-
-    # create pipeline
-    philox = PhiloxRNG(key=0xC0110FFC0FFEE)
-    photons = theia.light.UniformWavelengthSource(
-        lambdaRange=lamRange, normalize=normalize
-    )
-    light = theia.light.PencilLightSource(timeRange=timeRange)
-    sampler = theia.light.LightSampler(light, photons, N, rng=philox)
-    # run
-    runPipeline([philox, photons, light, sampler])
-    result = sampler.wavelengthQueue.view(0)
-
-    # check result
-    assert np.all(result["contrib"] == contrib)
-    assert np.abs(np.min(result["wavelength"]) - lamRange[0]) < 1.0
-    assert np.abs(np.max(result["wavelength"]) - lamRange[1]) < 1.0
+def test_uniform_wavelength(backend, normalize):
+    lo, hi = (350.0, 750.0) * u.nm
+    photons = TL.UniformWavelengthSource(lambdaRange=(lo, hi), normalize=normalize)
+    _, got = sampled(TL.PencilLightSource(timeRange=(0.0, 0.0) * u.ns), photons, rng=PhiloxRNG(key=KEY))
+    assert np.all(got["contrib"] == (1.0 if normalize else hi - lo))  # L / p(lambda)
+    assert abs(got["wavelength"].min() - lo) < 1.0 and abs(got["wavelength"].max() - hi) < 1.0
 
 
-def test_functionWavelength(backend):
-    N = 256 * 1024  # a bit more for the histogram
-    lamRange = (300.0, 700.0) * u.nm
+def test_function_wavelength(backend):
+    """importance sampling of -x ln x (x = lambda / 1000): constant contribution = its integral,
+    the histogram of the samples follows the antiderivative"""
+    n, (lo, hi) = 256 * 1024, (300.0, 700.0) * u.nm
+    pdf = lambda lam: -(lam / 1000) * np.log(lam / 1000)
+    cdf = lambda lam: 250.0 * (lam / 1000) ** 2 * (1.0 - 2.0 * np.log(lam / 1000))
+    photons = TL.FunctionWavelengthSource(pdf, lambdaRange=(lo, hi))
+    _, got = sampled(TL.PencilLightSource(timeRange=(0.0, 0.0)), photons, n, rng=PhiloxRNG(key=SEED))
+    integral = cdf(hi) - cdf(lo)
+    assert np.allclose(got["contrib"], integral)
+    assert abs(got["wavelength"].min() - lo) < 1.0 and abs(got["wavelength"].max() - hi) < 1.0
+    counts, edges = np.histogram(got["wavelength"], bins=40)
+    assert np.abs(counts / n - np.diff(cdf(edges)) / integral).max() < 9e-4
 
-    def fn(lam: float) -> float:
-        # something fancy just for testing
-        x = lam / 1000
-        return -x * np.log(x)
 
-    def Fn(lam: float) -> float:
-        # anti-derivative needed for testing
-        x = lam / 1000
-        return 250.0 * x**2 * (1.0 - 2.0 * np.log(x))
-
-    # create pipeline
-    philox = PhiloxRNG(key=0xC0FFEE)
-    photons = theia.light.FunctionWavelengthSource(fn, lambdaRange=lamRange)
-    light = theia.light.PencilLightSource(timeRange=(0.0, 0.0))
-    sampler = theia.light.LightSampler(light, photons, N, rng=philox)
-    # run
-    runPipeline([philox, photons, light, sampler])
-    result = sampler.wavelengthQueue.view(0)
-
-    # check result
-    exp_contrib = Fn(lamRange[1]) - Fn(lamRange[0])
-    assert np.allclose(result["contrib"], exp_contrib)
-    assert np.abs(np.min(result["wavelength"]) - lamRange[0]) < 1.0
-    assert np.abs(np.max(result["wavelength"]) - lamRange[1]) < 1.0
-    # check distribution via histogram
-    hist, edges = np.histogram(result["wavelength"], bins=40)
-    hist = hist / N
-    F = Fn(edges)
-    exp_hist = (F[1:] - F[:-1]) / exp_contrib
-    assert np.abs(hist - exp_hist).max() < 9e-4
+SOURCE = dict(position=(14.0, -2.0, 3.0) * u.m, timeRange=(10.0, 10.0) * u.ns, budget=12.0)
+AXIS, STOKES, REF = (0.8, 0.36, 0.48), (1.0, 0.9, 0.1, -0.5), (0.0, 0.48, -0.36)
 
 
 @pytest.mark.parametrize("polarized", [True, False])
-def test_coneLightSource_fwd(backend, polarized: bool):
-    N = 32 * 256
-    position = (14.0, -2.0, 3.0) * u.m
-    direction = (0.8, 0.36, 0.48)
-    opening = 0.33
-    stokes = (1.0, 0.9, 0.1, -0.5)
-    polRefIn = (0.0, 0.48, -0.36)
-    budget = 12.0
-
-    # create pipeline
-    philox = PhiloxRNG(key=0xC0110FFC0FFEE)
-    photons = theia.light.ConstWavelengthSource(wavelength=100.0 * u.nm)
-    light = theia.light.ConeLightSource(
-        position=position,
-        direction=direction,
-        timeRange=(10.0, 10.0) * u.ns,
-        cosOpeningAngle=opening,
-        budget=budget,
-        stokes=stokes,
-        polarizationReference=polRefIn,
-        polarized=polarized,
-    )
-    sampler = theia.light.LightSampler(
-        light, photons, N, rng=philox, polarized=polarized
-    )
-    # run
-    runPipeline([philox, photons, light, sampler])
-    result = sampler.lightQueue.view(0)
-
-    # check result
-    assert result.count == N
-    assert np.allclose(result["position"], position)
-    assert (result["direction"] * direction).sum(-1).min() >= opening
-    assert np.abs(np.square(result["direction"]).sum(-1) - 1.0).max() < 1e-5
-    assert np.all(result["contrib"] == budget)
+def test_cone_source(backend, polarized):
+    cos_open = 0.33
+    light = TL.ConeLightSource(direction=AXIS, cosOpeningAngle=cos_open, stokes=STOKES, polarizationReference=REF,
+                               polarized=polarized, **SOURCE)
+    got, _ = sampled(light, TL.ConstWavelengthSource(wavelength=100.0 * u.nm), rng=PhiloxRNG(key=KEY), polarized=polarized)
+    assert got.count == N and np.allclose(got["position"], SOURCE["position"])
+    d = got["direction"]
+    assert (d * AXIS).sum(-1).min() >= cos_open and np.abs(unit_sq(d) - 1.0).max() < 1e-5
+    assert np.all(got["contrib"] == SOURCE["budget"])
     if polarized:
-        assert np.allclose(result["stokes"], stokes)
-        polRef = result["polarizationRef"]
-        assert np.abs(np.square(polRef).sum(-1) - 1.0).max() < 1e-5
-        # polRef is steepened to be perpendicular to ray dir
-        # assert no rotation along ray direction happened, as this would make
-        # the stokes vec wrong
-        # no rotation happened if the parallelogram has zero volume
-        vol = (np.cross(result["direction"], polRefIn) * polRef).sum(-1)
-        assert np.abs(vol).max() < 1e-5
+        ref = got["polarizationRef"]
+        assert np.allclose(got["stokes"], STOKES) and np.abs(unit_sq(ref) - 1.0).max() < 1e-5
+        # the reference is only tilted into the plane perpendicular to the ray, not rotated about
+        # it: ray, given reference and sampled reference stay coplanar
+        assert np.abs((np.cross(d, REF) * ref).sum(-1)).max() < 1e-5
 
 
 @pytest.mark.parametrize("polarized", [True, False])
-def test_pencilLightSource(backend, polarized: bool):
-    N = 32 * 256
-    position = (14.0, -2.0, 3.0) * u.m
-    direction = (0.8, 0.36, 0.48)  # unit
-    stokes = (1.0, 0.9, 0.1, -0.5)
-    polRef = (0.0, 0.48, -0.36)
-    budget = 12.0
-    # create pipeline
-    philox = PhiloxRNG(key=0xC0110FFC0FFEE)
-    photons = theia.light.ConstWavelengthSource(wavelength=100.0 * u.nm)
-    light = theia.light.PencilLightSource(
-        position=position,
-        direction=direction,
-        timeRange=(10.0, 10.0) * u.ns,
-        budget=budget,
-        stokes=stokes,
-        polarizationRef=polRef,
-    )
-    sampler = theia.light.LightSampler(
-        light, photons, N, rng=philox, polarized=polarized
-    )
-    # run
-    runPipeline([philox, photons, light, sampler])
-    result = sampler.lightQueue.view(0)
-
-    # check result
-    assert result.count == N
-    assert np.allclose(result["position"], position)
-    assert np.allclose(result["direction"], direction)
-    assert np.all(result["contrib"] == budget)
+def test_pencil_source(backend, polarized):
+    light = TL.PencilLightSource(direction=AXIS, stokes=STOKES, polarizationRef=REF, **SOURCE)
+    got, _ = sampled(light, TL.ConstWavelengthSource(wavelength=100.0 * u.nm), rng=PhiloxRNG(key=KEY), polarized=polarized)
+    assert got.count == N
+    assert np.allclose(got["position"], SOURCE["position"]) and np.allclose(got["direction"], AXIS)
+    assert np.all(got["contrib"] == SOURCE["budget"])
     if polarized:
-        assert np.allclose(result["stokes"], stokes)
-        assert np.allclose(result["polarizationRef"], polRef)
+        assert np.allclose(got["stokes"], STOKES) and np.allclose(got["polarizationRef"], REF)
 
 
 @pytest.mark.parametrize("polarized", [True, False])
-def test_sphericalLightSource_fwd(backend, polarized: bool):
-    N = 32 * 256
-    position = (14.0, -2.0, 3.0) * u.m
-    budget = 12.0
-
-    # create pipeline
-    philox = PhiloxRNG(key=0xC0110FFC0FFEE)
-    photons = theia.light.ConstWavelengthSource(wavelength=100.0 * u.nm)
-    light = theia.light.SphericalLightSource(
-        position=position,
-        timeRange=(10.0, 10.0) * u.ns,
-        budget=budget,
-    )
-    sampler = theia.light.LightSampler(
-        light, photons, N, rng=philox, polarized=polarized
-    )
-    # run
-    runPipeline([philox, photons, light, sampler])
-    result = sampler.lightQueue.view(0)
-
-    # transform input to numpy array for testing
-    position = np.array(position, dtype=np.float32)
-    # check result
-    assert result.count == N
-    assert np.all(result["position"] == position)
-    assert np.allclose(np.sqrt(np.square(result["direction"]).sum(-1)), 1.0)
-    # uniform direction should average to zero
-    assert np.abs(np.mean(result["direction"], axis=0)).max() < 0.01  # low statistics
-    # check contribution
-    assert np.allclose(result["contrib"], budget)
-
-    if polarized:
-        assert np.allclose(result["stokes"], (1.0, 0.0, 0.0, 0.0))
-        polRef = result["polarizationRef"]
-        assert np.abs((polRef * result["direction"]).sum(-1)).max() < 1e-5
-        assert (np.square(polRef).sum(-1) - 1.0).max() < 1e-5
+def test_spherical_source(backend, polarized):
+    light = TL.SphericalLightSource(**SOURCE)
+    got, _ = sampled(light, TL.ConstWavelengthSource(wavelength=100.0 * u.nm), rng=PhiloxRNG(key=KEY), polarized=polarized)
+    d = got["direction"]
+    assert got.count == N and np.all(got["position"] == np.float32(SOURCE["position"]))
+    assert np.allclose(np.sqrt(unit_sq(d)), 1.0)
+    assert np.abs(d.mean(0)).max() < 0.01  # isotropic within the statistics
+    assert np.allclose(got["contrib"], SOURCE["budget"])
+    if polarized:  # unpolarized light: any reference perpendicular to the ray
+        ref = got["polarizationRef"]
+        assert np.allclose(got["stokes"], (1.0, 0.0, 0.0, 0.0))
+        assert np.abs((ref * d).sum(-1)).max() < 1e-5 and (unit_sq(ref) - 1.0).max() < 1e-5
 
 
 # ---- the host sources feeding a tracer ---------------------------------------------------------
 
 
-def _volume_tracer(N, source, photons, polarized, key=0xC01DC0FFEE):
+def _volume_tracer(n, source, photons, polarized, key=0xC01DC0FFEE):
     water = WaterTestModel().createMedium()
     store = theia.material.MaterialStore([], media=[water])
     rng = PhiloxRNG(key=key)
     recorder = theia.response.HitRecorder(polarized=polarized)
     tracer = theia.trace.VolumeForwardTracer(
-        N, source, SphereTarget(position=(5.0, 2.0, -8.0) * u.m, radius=4.0 * u.m), photons, recorder, rng,
+        n, source, SphereTarget(position=(5.0, 2.0, -8.0) * u.m, radius=4.0 * u.m), photons, recorder, rng,
         medium=store.media["water"], nScattering=5, polarized=polarized, maxTime=1.0 * u.us,
     )
     rng.autoAdvance = tracer.nRNGSamples
@@ -407,36 +231,30 @@ def _volume_tracer(N, source, photons, polarized, key=0xC01DC0FFEE):
 def test_tracer_fed_from_host_queues_matches_the_sampled_source(backend, polarized):
     """Samples a cone source + uniform wavelengths with the LightSampler, feeds the samples back
     through HostLightSource / HostWavelengthSource and compares the hits with the tracer that
-    samples the same sources itself. The host sources draw no random numbers, so the streams of
-    the two tracers are aligned by hand: the direct tracer uses 4 dimensions (1 wavelength +
-    3 light) the fed one does not -- the fed tracer's Philox offset cannot express that, so
-    only the statistics of the hits are compared (same number of hits to 3 sigma, same mean
-    arrival time to 3 sigma)."""
-    N = 32 * 256
-    light = theia.light.ConeLightSource(position=(-1.0, -7.0, 0.0) * u.m, direction=(0.6, 0.8, 0.0), cosOpeningAngle=0.2,
-                                        timeRange=(10.0, 20.0) * u.ns, budget=1000.0, polarized=polarized,
-                                        stokes=(1.0, 0.3, 0.2, 0.1), polarizationReference=(0.0, 0.0, 1.0))
-    photons = theia.light.UniformWavelengthSource(lambdaRange=(400.0, 600.0) * u.nm)
-    # direct
+    samples the same sources itself. The host sources draw no random numbers, so the two tracers
+    use different random streams from the first scatter on: the hits are compared statistically
+    (same number to 3 sigma, same mean arrival time to 3 sigma, same summed contribution to 10 %)."""
+    light = TL.ConeLightSource(position=(-1.0, -7.0, 0.0) * u.m, direction=(0.6, 0.8, 0.0), cosOpeningAngle=0.2,
+                               timeRange=(10.0, 20.0) * u.ns, budget=1000.0, polarized=polarized,
+                               stokes=(1.0, 0.3, 0.2, 0.1), polarizationReference=(0.0, 0.0, 1.0))
+    photons = TL.UniformWavelengthSource(lambdaRange=(400.0, 600.0) * u.nm)
     tracer, recorder, _store = _volume_tracer(N, light, photons, polarized)
     pl.runPipeline(tracer.collectStages())
-    direct = recorder.queue.view(0)
-    direct = {f: np.array(direct[f][: direct.count]) for f in ("time", "contrib")}
-    # sampled, then fed
-    sampler = theia.light.LightSampler(light, photons, N, rng=PhiloxRNG(key=0xABCDEF), polarized=polarized)
-    runPipeline(sampler.collectStages())
-    hostLight = theia.light.HostLightSource(N, polarized=polarized)
-    hostLam = theia.light.HostWavelengthSource(N)
-    src, dst = sampler.lightQueue.view(0), hostLight.queue.view(0)
+    q = recorder.queue.view(0)
+    direct = {f: np.array(q[f][: q.count]) for f in ("time", "contrib")}
+    sampler = TL.LightSampler(light, photons, N, rng=PhiloxRNG(key=0xABCDEF), polarized=polarized)
+    pl.runPipeline(sampler.collectStages())
+    host_light, host_lam = TL.HostLightSource(N, polarized=polarized), TL.HostWavelengthSource(N)
+    src, dst = sampler.lightQueue.view(0), host_light.queue.view(0)
     for f in dst.fields:
         dst[f] = src[f]
-    hostLam.queue.view(0)["wavelength"] = sampler.wavelengthQueue.view(0)["wavelength"]
-    hostLam.queue.view(0)["contrib"] = sampler.wavelengthQueue.view(0)["contrib"]
-    tracer2, recorder2, _store2 = _volume_tracer(N, hostLight, hostLam, polarized)
-    assert tracer2.nRNGSamples == tracer.nRNGSamples - 4
+    for f in ("wavelength", "contrib"):
+        host_lam.queue.view(0)[f] = sampler.wavelengthQueue.view(0)[f]
+    tracer2, recorder2, _store2 = _volume_tracer(N, host_light, host_lam, polarized)
+    assert tracer2.nRNGSamples == tracer.nRNGSamples - 4  # 1 wavelength + 3 light draws fewer
     pl.runPipeline(tracer2.collectStages())
-    fed = recorder2.queue.view(0)
-    fed = {f: np.array(fed[f][: fed.count]) for f in ("time", "contrib")}
+    q = recorder2.queue.view(0)
+    fed = {f: np.array(q[f][: q.count]) for f in ("time", "contrib")}
     n1, n2 = len(direct["time"]), len(fed["time"])
     assert n1 > 1000 and abs(n1 - n2) < 3.0 * np.sqrt(n1 + n2)
     sem = np.hypot(direct["time"].std() / np.sqrt(n1), fed["time"].std() / np.sqrt(n2))
@@ -446,40 +264,36 @@ def test_tracer_fed_from_host_queues_matches_the_sampled_source(backend, polariz
 
 @pytest.mark.gpu
 @pytest.mark.parametrize("polarized", [False, True])
-def test_host_fed_tracer_hip_matches_oracle(polarized, rng):
+def test_host_fed_tracer_hip_matches_oracle(polarized):
     """same host queues through the oracle and the HIP volume tracer: the recorded hits agree
     hit by hit (matched by time)"""
     from oracle_backend import OracleBackend
     from theia_amd import _backend
 
-    N = 20_000
-    cos_theta = 2.0 * rng.random(N) - 1.0
-    sin_theta = np.sqrt(1.0 - cos_theta**2)
-    phi = rng.random(N) * 2.0 * np.pi
+    n, gen = 20_000, np.random.default_rng(SEED)
+    cos_t = 2.0 * gen.random(n) - 1.0
+    sin_t, phi = np.sqrt(1.0 - cos_t**2), gen.random(n) * 2.0 * np.pi
     data = {
-        "position": np.tile(np.array([-1.0, -7.0, 0.0]), (N, 1)) + rng.random((N, 3)),
-        "direction": np.stack([sin_theta * np.cos(phi), sin_theta * np.sin(phi), cos_theta], axis=-1),
-        "startTime": rng.random(N) * 10.0,
-        "contrib": rng.random(N) + 0.5,
+        "position": np.tile(np.array([-1.0, -7.0, 0.0]), (n, 1)) + gen.random((n, 3)),
+        "direction": np.stack([sin_t * np.cos(phi), sin_t * np.sin(phi), cos_t], axis=-1),
+        "startTime": gen.random(n) * 10.0,
+        "contrib": gen.random(n) + 0.5,
     }
     if polarized:
-        data["stokes"] = np.tile(np.array([1.0, 0.2, -0.1, 0.3]), (N, 1))
+        data["stokes"] = np.tile(np.array([1.0, 0.2, -0.1, 0.3]), (n, 1))
         ref = np.cross(data["direction"], np.array([0.0, 0.0, 1.0]))
         data["polarizationRef"] = ref / np.linalg.norm(ref, axis=-1, keepdims=True)
-    lam = 400.0 + 200.0 * rng.random(N)
-    out = {}
-    prev = _backend._backend
+    lam = 400.0 + 200.0 * gen.random(n)
+    out, prev = {}, _backend._backend
     for name in ("oracle", "hip"):
         be = OracleBackend(threads=8) if name == "oracle" else _backend.HipBackend()
         _backend._backend = be
         try:
-            hostLight = theia.light.HostLightSource(N, polarized=polarized)
-            hostLam = theia.light.HostWavelengthSource(N)
+            host_light, host_lam = TL.HostLightSource(n, polarized=polarized), TL.HostWavelengthSource(n)
             for f, v in data.items():
-                hostLight.queue.view(0)[f] = v
-            hostLam.queue.view(0)["wavelength"] = lam
-            hostLam.queue.view(0)["contrib"] = 1.0
-            tracer, recorder, _store = _volume_tracer(N, hostLight, hostLam, polarized)
+                host_light.queue.view(0)[f] = v
+            host_lam.queue.view(0)["wavelength"], host_lam.queue.view(0)["contrib"] = lam, 1.0
+            tracer, recorder, _store = _volume_tracer(n, host_light, host_lam, polarized)
             pl.runPipeline(tracer.collectStages())
             q = recorder.queue.view(0)
             order = np.argsort(q["time"][: q.count])
@@ -491,7 +305,6 @@ def test_host_fed_tracer_hip_matches_oracle(polarized, rng):
     a, b = out["oracle"], out["hip"]
     assert len(a["time"]) > 500
     assert abs(len(a["time"]) - len(b["time"])) <= max(2, len(a["time"]) // 500)
-    # match by time
     idx = np.clip(np.searchsorted(b["time"], a["time"]), 1, len(b["time"]) - 1)
     idx = np.where(np.abs(b["time"][idx - 1] - a["time"]) < np.abs(b["time"][idx] - a["time"]), idx - 1, idx)
     close = np.abs(b["time"][idx] - a["time"]) < 1e-3

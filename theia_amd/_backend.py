@@ -175,6 +175,20 @@ class HipBackend:
         """copies the HitRecorder queue into `out` (uint8) and resets its counter"""
         capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
 
+    def probe_target(self, philox: capi.PhiloxParams, flags: int, target: capi.TargetParams, box_min, box_max, n: int) -> np.ndarray:
+        """theia.testing.TargetSampler: [n][25] words (include/theia_hip.h)"""
+        out = np.zeros((int(n), 25), dtype=np.float32)
+        lo, hi = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max)
+        capi.check(self._lib.thx_probe_target(self._ctx, C.byref(philox), int(flags), C.byref(target), lo, hi, int(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
+    def probe_guide(self, philox: capi.PhiloxParams, flags: int, guide: capi.GuideParams, box_min, box_max, n: int) -> np.ndarray:
+        """theia.testing.TargetGuideSampler: [n][13] floats"""
+        out = np.zeros((int(n), 13), dtype=np.float32)
+        lo, hi = (C.c_float * 3)(*box_min), (C.c_float * 3)(*box_max)
+        capi.check(self._lib.thx_probe_guide(self._ctx, C.byref(philox), int(flags), C.byref(guide), lo, hi, int(n), out.ctypes.data_as(C.c_void_p)))
+        return out
+
     def tracer_write_light(self, tracer: int, cfg: int, data: np.ndarray) -> None:
         """uploads a HostLightSource queue (uint8, SoA columns without counter) for pipeline config `cfg`"""
         data = np.ascontiguousarray(data)

@@ -786,6 +786,41 @@ int thx_tracer_kernel_times(thx_tracer* t, float* ms_out, uint32_t n, uint32_t* 
     return THX_OK;
 }
 
+static int probe(thx_ctx* ctx, bool guide, const thx_philox_params* philox, uint32_t flags, const thx_target_params* target,
+                 const thx_guide_params* g, const float* lo, const float* hi, uint32_t n, float* out) {
+    if (!ctx || !philox || !lo || !hi || !out) return fail(THX_ERR_INVALID, "null argument");
+    if (n == 0) return THX_OK;
+    std::lock_guard<std::mutex> guard(ctx->lock);
+    THX_HIP(hipSetDevice(ctx->device));
+    const size_t words = guide ? 13 : 25;
+    float* d = nullptr;
+    THX_HIP(hipMalloc((void**)&d, 4 * words * (size_t)n));
+    LaunchArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.p.philox = *philox;
+    a.flags = flags;
+    if (target) a.p.target = *target;
+    if (g) a.p.guide = *g;
+    hipError_t e = launchProbe(guide, a, lo, hi, n, d, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out, d, 4 * words * (size_t)n, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hipFail(e, "probe");
+    return THX_OK;
+}
+
+int thx_probe_target(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flags, const thx_target_params* target,
+                     const float box_min[3], const float box_max[3], uint32_t n, float* target_out) {
+    if (!target) return fail(THX_ERR_INVALID, "null argument");
+    return probe(ctx, false, philox, flags, target, nullptr, box_min, box_max, n, target_out);
+}
+
+int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flags, const thx_guide_params* guide,
+                    const float box_min[3], const float box_max[3], uint32_t n, float* guide_out) {
+    if (!guide) return fail(THX_ERR_INVALID, "null argument");
+    return probe(ctx, true, philox, flags, nullptr, guide, box_min, box_max, n, guide_out);
+}
+
 int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream, uint32_t n_streams,
                  uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32, float* out_f32) {
     if (!ctx || !p) return fail(THX_ERR_INVALID, "null argument");

@@ -30,6 +30,7 @@ struct m3 { // columns
 };
 
 THX_DEV f3 mk3(float x, float y, float z) { return f3{x, y, z}; }
+THX_DEV m3 transpose(m3 m) { return m3{f3{m.c0.x, m.c1.x, m.c2.x}, f3{m.c0.y, m.c1.y, m.c2.y}, f3{m.c0.z, m.c1.z, m.c2.z}}; }
 THX_DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
 // Pointers made from the 64-bit device addresses users hand in (medium / material / geometry
 // records, tables) carry the global address space: plain pointers would compile to FLAT loads,

@@ -619,7 +619,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     float sampledDist = dist;
                     bool mis_target = false;
                     if constexpr (V::MIS) {
-                        GuideSample gs = evalTargetGuide(args.p.guide, rayA.position, dir);
+                        GuideSample gs = evalTargetGuide(args.p.guide, rayA.position, dir, args.flags);
                         mis_target = (mA.flags & F_ALLOW) != 0u && gs.prob > 0.0f;
                         if (mis_target) {
                             mis_target = gs.dist > dist;
@@ -669,7 +669,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 f3 dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
                 GuideSample ts = sampleTargetGuide(L, ray.position);
                 float pTT = ts.prob;
-                GuideSample ps = evalTargetGuide(args.p.guide, ray.position, dirPhase);
+                GuideSample ps = evalTargetGuide(args.p.guide, ray.position, dirPhase, args.flags);
                 float pTP = ps.prob;
                 float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
                 float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);

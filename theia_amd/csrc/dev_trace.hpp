@@ -514,14 +514,16 @@ struct TargetSample {
     f3 position, normal;
     float dist, prob;
     bool valid;
-    f3 objPosition; // unit sphere of the target's frame; read by the HitRecorder response only
+    // the hit in the target's own frame (target.common.glsl:4-18); read by the HitRecorder response
+    // and the probe only
+    f3 objPosition, objNormal, offset;
+    m3 worldToObj;
 };
-// target.sphere.glsl:36-41, 68-73 / target.sphere.inner.glsl:26-32, 50-56: the object-space
-// normal is the world normal, world->object is the uniform scale 1/radius
+THX_DEV m3 diag3(float d) { return m3{f3{d, 0.0f, 0.0f}, f3{0.0f, d, 0.0f}, f3{0.0f, 0.0f, d}}; }
 THX_DEV HitFrame targetFrame(const thx_run_params& p, const TargetSample& hit) {
-    const float ir = p.target.invRad;
-    return HitFrame{hit.objPosition, hit.normal, m3{f3{ir, 0.0f, 0.0f}, f3{0.0f, ir, 0.0f}, f3{0.0f, 0.0f, ir}}, p.volume.objectId};
+    return HitFrame{hit.objPosition, hit.objNormal, hit.worldToObj, p.volume.objectId};
 }
+THX_DEV bool targetIsPlane(uint32_t flags) { return (flags & (THX_FLAG_TARGET_DISK | THX_FLAG_TARGET_FLAT)) != 0u; }
 
 // math.sphere.glsl:14-39 (nearest root)
 THX_DEV float intersectSphereNear(f3 center, float radius, f3 origin, f3 direction) {
@@ -559,18 +561,71 @@ THX_DEV float intersectSphereFar(f3 center, float radius, f3 origin, f3 directio
     return ry;
 }
 
+// util.sample.glsl:31-56: concentric mapping of the unit square onto the unit disk
+THX_DEV f3 sampleUnitDisk(float u0, float u1) {
+    float rx = 2.0f * u0 - 1.0f, ry = 2.0f * u1 - 1.0f;
+    if (rx == 0.0f && ry == 0.0f) return f3{0.0f, 0.0f, 0.0f};
+    float phi, r;
+    if (fabsf(rx) > fabsf(ry)) {
+        r = rx;
+        phi = 0.78539816339744830962f * (ry / rx);
+    } else {
+        r = ry;
+        phi = 1.57079632679489661923f - 0.78539816339744830962f * (rx / ry);
+    }
+    return f3{r * thx_cos(phi), r * thx_sin(phi), 0.0f};
+}
+THX_DEV m3 ldm3(const float* m) { // column major
+    return m3{f3{m[0], m[1], m[2]}, f3{m[3], m[4], m[5]}, f3{m[6], m[7], m[8]}};
+}
+THX_DEV float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
+// target.disk.glsl:43-66 / target.flat.glsl:47-72
+THX_DEV TargetSample intersectTargetPlane(const thx_target_params& tp, f3 observer, f3 direction, bool disk) {
+    const m3 o2w = ldm3(tp.objToWorld);
+    const m3 w2o = transpose(o2w);
+    const f3 center = ld3(tp.position);
+    f3 localObs = mul(w2o, observer - center);
+    f3 localDir = mul(w2o, direction);
+    float t = -localObs.z / localDir.z;
+    f3 localPos = localObs + localDir * t;
+    bool valid = t > 0.0f;
+    if (disk) valid = valid && sqrtf(localPos.x * localPos.x + localPos.y * localPos.y) <= tp.radius;
+    else valid = valid && 2.0f * fabsf(localPos.x) <= tp.width && 2.0f * fabsf(localPos.y) <= tp.height;
+    const float side = signBit(localObs.z);
+    TargetSample s;
+    s.position = mul(o2w, localPos) + center;
+    s.normal = ld3(tp.normal) * side;
+    // DEVIATION from target.disk.glsl:60 / target.flat.glsl:66, which report the distance to the plane
+    // even when the outline is missed or the plane lies behind the ray: the tracers take
+    // min(hit.dist, free path) (tracer.volume.forward.glsl:167), so the reference stops every ray at
+    // the infinite plane and walks rays pointing away from it backwards onto it (negative distance).
+    // A miss is a miss here: infinite distance, like createTargetSampleMiss() (oracle: same).
+    s.dist = valid ? t : INFINITY;
+    s.prob = tp.hemisphereProb * (valid ? 1.0f : 0.0f);
+    s.valid = valid;
+    s.objPosition = localPos;
+    s.objNormal = f3{0.0f, 0.0f, side};
+    s.worldToObj = w2o;
+    s.offset = mul(w2o, center) * -1.0f;
+    return s;
+}
+
 // target.sphere.glsl:45-78 (objPosition = objNormal = normal, worldToObj = 1/r);
 // inner: target.sphere.inner.glsl:36-57 (seen from inside: far root, normal towards the centre)
-THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f3 direction, bool inner) {
+THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f3 direction, uint32_t flags) {
+    if (targetIsPlane(flags)) return intersectTargetPlane(tp, observer, direction, (flags & THX_FLAG_TARGET_DISK) != 0u);
     f3 center = ld3(tp.position);
     TargetSample s;
-    if (inner) {
+    s.offset = ld3(tp.invPos);
+    s.worldToObj = diag3(tp.invRad);
+    if (flags & THX_FLAG_TARGET_INNER) {
         float t = intersectSphereFar(center, tp.radius, observer, direction);
         f3 pos = observer + direction * t;
         f3 nrm = normalize(center - pos);
         s.position = pos; s.normal = nrm; s.dist = t; s.prob = tp.hemisphereProb;
         s.valid = (t > 0.0f) && !isinf(t);
-        s.objPosition = nrm * -1.0f;
+        s.objPosition = nrm * -1.0f; s.objNormal = nrm;
         return s;
     }
     float t = intersectSphereNear(center, tp.radius, observer, direction);
@@ -578,7 +633,8 @@ THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f
     if (!hit) { // target.common.glsl:79-91
         s.position = f3{0, 0, 0};
         s.normal = f3{0, 0, 0};
-        s.objPosition = f3{0, 0, 0};
+        s.objPosition = f3{0, 0, 0}; s.objNormal = f3{0, 0, 0};
+        s.offset = f3{0, 0, 0}; s.worldToObj = diag3(1.0f);
         s.dist = INFINITY;
         s.prob = 0.0f;
         s.valid = false;
@@ -592,23 +648,43 @@ THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f
     bool valid = !isinf(prob);
     if (!valid) prob = 0.0f;
     s.position = pos; s.normal = nrm; s.dist = t; s.prob = prob; s.valid = valid;
-    s.objPosition = nrm;
+    s.objPosition = nrm; s.objNormal = nrm;
     return s;
 }
 
-// target.sphere.glsl:18-43; inner: target.sphere.inner.glsl:18-34 (uniform over the sphere)
+// target.sphere.glsl:18-43; inner: target.sphere.inner.glsl:18-34 (uniform over the sphere);
+// target.disk.glsl:15-41 / target.flat.glsl:17-45
 template <class V>
-THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 observer, bool inner) {
+THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 observer, uint32_t flags) {
     f3 center = ld3(tp.position);
-    if (inner) {
+    TargetSample s;
+    if (targetIsPlane(flags)) {
+        float u0 = draw(L);
+        float u1 = draw(L);
+        f3 localPos = (flags & THX_FLAG_TARGET_DISK) ? sampleUnitDisk(u0, u1) * tp.radius
+                                                     : f3{tp.width * (u0 - 0.5f), tp.height * (u1 - 0.5f), 0.0f};
+        const m3 o2w = ldm3(tp.objToWorld);
+        f3 pos = mul(o2w, localPos) + center;
+        f3 normal = ld3(tp.normal);
+        const float side = signf(dot(normal, observer - pos));
+        normal = normal * side;
+        s.position = pos; s.normal = normal; s.dist = distance(observer, pos);
+        s.prob = tp.hemisphereProb; s.valid = dot(normal, normal) != 0.0f;
+        s.objPosition = localPos; s.objNormal = f3{0.0f, 0.0f, side};
+        s.worldToObj = transpose(o2w);
+        s.offset = mul(s.worldToObj, center) * -1.0f;
+        return s;
+    }
+    s.offset = ld3(tp.invPos);
+    s.worldToObj = diag3(tp.invRad);
+    if (flags & THX_FLAG_TARGET_INNER) {
         float v0 = draw(L);
         float v1 = draw(L);
         f3 normal = sphericalToCartessian(TWO_PI * v0, 2.0f * v1 - 1.0f); // util.sample.glsl:84-88
         f3 pos = normal * tp.radius + center;
-        TargetSample s;
         s.position = pos; s.normal = normal * -1.0f; s.dist = distance(observer, pos);
         s.prob = tp.hemisphereProb; s.valid = true;
-        s.objPosition = normal;
+        s.objPosition = normal; s.objNormal = normal * -1.0f;
         return s;
     }
     f3 dir = normalize(observer - center);
@@ -623,11 +699,18 @@ THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 ob
     float prob = tp.hemisphereProb / (1.0f - cosOpening);
     bool valid = !isinf(prob);
     if (!valid) prob = 0.0f;
-    TargetSample s;
     s.position = pos; s.normal = normal; s.dist = distance(pos, observer); s.prob = prob;
     s.valid = valid;
-    s.objPosition = normal;
+    s.objPosition = normal; s.objNormal = normal;
     return s;
+}
+
+// isOccludedByTarget: target.sphere.glsl:80-83 (inside), target.sphere.inner.glsl:59-61 (outside),
+// target.disk.glsl:68-71 / target.flat.glsl:74-77 (never)
+THX_DEV bool isOccludedByTarget(const thx_target_params& tp, f3 observer, uint32_t flags) {
+    if (targetIsPlane(flags)) return false;
+    const float d = distance(observer, ld3(tp.position));
+    return (flags & THX_FLAG_TARGET_INNER) ? (d >= tp.radius) : (d <= tp.radius);
 }
 
 // tracer.volume.forward.glsl:51-82 (ray by value)
@@ -661,9 +744,8 @@ THX_DEV void volSampleTargetMIS(Lane<V>& L, const Ray& ray, uint64_t med) {
     float u0 = draw(L);
     float u1 = draw(L);
     f3 dirPhase = scatter(med, dir, u0, u1, pPP, L.cnt);
-    const bool inner = (L.a->flags & THX_FLAG_TARGET_INNER) != 0;
-    TargetSample phaseHit = intersectTarget(tg, obs, dirPhase, inner);
-    TargetSample targetHit = sampleTarget(L, tg, obs, inner);
+    TargetSample phaseHit = intersectTarget(tg, obs, dirPhase, L.a->flags);
+    TargetSample targetHit = sampleTarget(L, tg, obs, L.a->flags);
     f3 dirTarget = normalize(targetHit.position - obs);
     float pTT = targetHit.prob * jacobian_dAdW(obs, targetHit.position, targetHit.normal);
     float pPT = scatterProb(med, dir, dirTarget, L.cnt);
@@ -681,7 +763,7 @@ THX_DEV int volTrace(Lane<V>& L, Ray& ray, uint64_t med, bool allowResponse) {
     L.cnt.add(ST_STEPS);
     float u = draw(L);
     float dist = sampleScatterLength(ray, prop, u);
-    TargetSample hit = intersectTarget(L.a->p.target, ray.position, ray.direction, (L.a->flags & THX_FLAG_TARGET_INNER) != 0);
+    TargetSample hit = intersectTarget(L.a->p.target, ray.position, ray.direction, L.a->flags);
     bool hitValid = hit.valid && (hit.dist <= dist);
     dist = fminf(hit.dist, dist);
     int result = propagateRay(ray, dist, prop);
@@ -711,14 +793,13 @@ THX_DEV bool volStep(Lane<V>& L, Ray& ray, uint32_t& step) {
         ray = sampleRay(L, med);
         onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
         // isOccludedByTarget: target.sphere.glsl:80-83 (inside), target.sphere.inner.glsl:59-61 (outside)
-        const float dTarget = distance(ray.position, ld3(A.p.target.position));
-        if ((A.flags & THX_FLAG_TARGET_INNER) ? (dTarget >= A.p.target.radius) : (dTarget <= A.p.target.radius)) {
+        if (isOccludedByTarget(A.p.target, ray.position, A.flags)) {
             onEvent(L, ray, ERROR_CODE_TRACE_ABORT, 0);
             return false;
         }
         if constexpr (V::MIS) {
             if (!disable_direct) {
-                TargetSample directHit = intersectTarget(A.p.target, ray.position, ray.direction, (A.flags & THX_FLAG_TARGET_INNER) != 0);
+                TargetSample directHit = intersectTarget(A.p.target, ray.position, ray.direction, A.flags);
                 volCreateResponse(L, ray, directHit, ray.direction, 1.0f, false, med);
             }
         }
@@ -750,12 +831,10 @@ THX_DEV bool volPhotonStep(Lane<V>& L, Ray& ray, uint32_t& step) {
     const LaunchArgs& A = *L.a;
     const uint64_t med = (uint64_t)A.p.volume.medium[0] | ((uint64_t)A.p.volume.medium[1] << 32);
     const thx_propagate_params& prop = A.p.volume.propagation;
-    const bool inner = (A.flags & THX_FLAG_TARGET_INNER) != 0;
     if (step == 0) {
         ray = sampleRay(L, med); // contribution 1: survival chance
         onEvent(L, ray, RESULT_CODE_RAY_CREATED, 0);
-        const float dTarget = distance(ray.position, ld3(A.p.target.position));
-        if (inner ? (dTarget >= A.p.target.radius) : (dTarget <= A.p.target.radius)) {
+        if (isOccludedByTarget(A.p.target, ray.position, A.flags)) {
             onEvent(L, ray, ERROR_CODE_TRACE_ABORT, 0);
             return false;
         }
@@ -769,7 +848,7 @@ THX_DEV bool volPhotonStep(Lane<V>& L, Ray& ray, uint32_t& step) {
     L.cnt.add(ST_STEPS);
     // trace()
     float dist = sampleScatterLength(ray, prop, draw(L));
-    TargetSample hit = intersectTarget(A.p.target, ray.position, ray.direction, inner);
+    TargetSample hit = intersectTarget(A.p.target, ray.position, ray.direction, A.flags);
     const bool hitValid = hit.valid && (hit.dist <= dist);
     dist = fminf(hit.dist, dist);
     int result = propagateRay(ray, dist, prop);
@@ -1253,10 +1332,51 @@ THX_DEV void guideCone(const thx_guide_params& g, f3 observer, float& d, f3& vie
     prob = 1.0f / (TWO_PI * cosMin);
     prob *= (d > g.radius) ? 1.0f : 0.0f;
 }
-// target_guide.sphere.glsl:15-51
+// target_guide.common.glsl:10-32
+THX_DEV GuideSample guideSampleFromPoint(f3 observer, f3 targetPos, f3 targetNrm, float targetProb) {
+    f3 dir = targetPos - observer;
+    const float d2 = dot(dir, dir);
+    dir = normalize(dir);
+    const float cosNormal = dot(dir, targetNrm);
+    float prob = targetProb * d2 / fabsf(cosNormal);
+    if (isinf(prob)) prob = 0.0f;
+    prob *= (cosNormal < 0.0f) ? 1.0f : 0.0f;
+    return GuideSample{dir, distance(targetPos, observer), prob};
+}
+// target_guide.common.glsl:34-51
+THX_DEV GuideSample guideSampleFromDir(f3 dir, float dist, f3 targetNrm, float targetProb) {
+    const float cosNormal = dot(dir, targetNrm);
+    float prob = targetProb * dist * dist / fabsf(cosNormal);
+    if (isinf(prob)) prob = 0.0f;
+    prob *= (cosNormal < 0.0f) ? 1.0f : 0.0f;
+    return GuideSample{dir, dist, prob};
+}
+THX_DEV bool guideIsPlane(uint32_t flags) { return (flags & (THX_FLAG_GUIDE_DISK | THX_FLAG_GUIDE_FLAT)) != 0u; }
+// target_guide.disk.glsl:25-44 / target_guide.flat.glsl:31-48
+THX_DEV GuideSample evalGuidePlane(const thx_guide_params& g, f3 observer, f3 direction, bool disk) {
+    const m3 w2o = transpose(ldm3(g.objToWorld));
+    f3 localObs = mul(w2o, observer - ld3(g.position));
+    f3 localDir = mul(w2o, direction);
+    float t = -localObs.z / localDir.z; // +/- inf or NaN if localDir.z = 0
+    f3 localHit = localObs + localDir * t;
+    bool valid = t > 0.0f && !isinf(t) && !isnan(t);
+    if (disk) valid = valid && sqrtf(localHit.x * localHit.x + localHit.y * localHit.y) <= g.radius;
+    else valid = valid && 2.0f * fabsf(localHit.x) <= g.width && 2.0f * fabsf(localHit.y) <= g.height;
+    return guideSampleFromDir(direction, t, ld3(g.normal), g.prob * (valid ? 1.0f : 0.0f));
+}
+
+// target_guide.sphere.glsl:15-51; target_guide.disk.glsl:15-23 / target_guide.flat.glsl:17-29
 template <class V>
 THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
     const thx_guide_params& g = L.a->p.guide;
+    if (guideIsPlane(L.a->flags)) {
+        float u0 = draw(L);
+        float u1 = draw(L);
+        f3 localPos = (L.a->flags & THX_FLAG_GUIDE_DISK) ? sampleUnitDisk(u0, u1) * g.radius
+                                                         : f3{g.width * (u0 - 0.5f), g.height * (u1 - 0.5f), 0.0f};
+        f3 pos = mul(ldm3(g.objToWorld), localPos) + ld3(g.position);
+        return guideSampleFromPoint(observer, pos, ld3(g.normal), g.prob);
+    }
     float d, cosMin, prob;
     f3 viewDir;
     guideCone(g, observer, d, viewDir, cosMin, prob);
@@ -1271,7 +1391,8 @@ THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
     return s;
 }
 // target_guide.sphere.glsl:53-81
-THX_DEV GuideSample evalTargetGuide(const thx_guide_params& g, f3 observer, f3 direction) {
+THX_DEV GuideSample evalTargetGuide(const thx_guide_params& g, f3 observer, f3 direction, uint32_t flags) {
+    if (guideIsPlane(flags)) return evalGuidePlane(g, observer, direction, (flags & THX_FLAG_GUIDE_DISK) != 0u);
     float d, cosMin, prob;
     f3 viewDir;
     guideCone(g, observer, d, viewDir, cosMin, prob);
@@ -1396,7 +1517,7 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
         dist = sampleScatterLength(ray, prop, draw(L));
         sampledDist = dist;
         if constexpr (V::MIS) {
-            GuideSample gs = evalTargetGuide(A.p.guide, ray.position, dir);
+            GuideSample gs = evalTargetGuide(A.p.guide, ray.position, dir, A.flags);
             mis_target = allowResponse && gs.prob > 0.0f;
             if (mis_target) {
                 mis_target = gs.dist > dist;
@@ -1461,7 +1582,7 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
                     dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
                     GuideSample ts = sampleTargetGuide(L, ray.position);
                     float pTT = ts.prob;
-                    GuideSample ps = evalTargetGuide(A.p.guide, ray.position, dirPhase);
+                    GuideSample ps = evalTargetGuide(A.p.guide, ray.position, dirPhase, A.flags);
                     float pTP = ps.prob;
                     float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
                     wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);

@@ -43,6 +43,9 @@ constexpr uint32_t kReplayBlock = 256;
 // lightsource.sample.glsl: dispatch.batchSize samples into the two output queues
 hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light_out, uint32_t* lam_out, uint32_t capacity,
                          hipStream_t stream);
+// target.sample.glsl / target_guide.sample.glsl probes: out[n][25] resp. out[n][13]
+hipError_t launchProbe(bool guide, const LaunchArgs& args, const float* lo, const float* hi, uint32_t n, float* out,
+                       hipStream_t stream);
 hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,
                          uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
                          float* out_f32, hipStream_t stream);

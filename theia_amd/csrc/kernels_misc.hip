@@ -181,6 +181,76 @@ hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light
     return hipGetLastError();
 }
 
+// theia.testing.TargetSampler / TargetGuideSampler (target.sample.glsl, target_guide.sample.glsl)
+template <class V>
+THX_DEV void probeObserver(Lane<V>& L, const float* lo, const float* hi, f3& observer, f3& direction) {
+    float a = draw(L), b = draw(L), c = draw(L);
+    observer = f3{mixf(lo[0], hi[0], a), mixf(lo[1], hi[1], b), mixf(lo[2], hi[2], c)};
+    float u0 = draw(L), u1 = draw(L);
+    direction = sphericalToCartessian(TWO_PI * u0, 2.0f * u1 - 1.0f); // util.sample.glsl:84-88
+}
+// target.sample.glsl:19-47 checkSample / checkIntersect
+THX_DEV void putTargetSample(float* o, f3 observer, const TargetSample& ts, bool checkDir, f3 direction) {
+    const float expD = distance(ts.position, observer);
+    const f3 expPos = mul(ts.worldToObj, ts.position) + ts.offset;
+    const f3 expNrm = normalize(mul(ts.worldToObj, ts.normal));
+    int error = 0;
+    error += (int)(fabsf(expD - ts.dist) > 1e-5f);
+    error += (int)(length(expPos - ts.objPosition) > 1e-5f) << 1;
+    error += (int)(length(expNrm - ts.objNormal) > 1e-5f) << 2;
+    if (checkDir) error += (int)(length(normalize(ts.position - observer) - direction) > 1e-5f) << 3;
+    o[0] = ts.position.x; o[1] = ts.position.y; o[2] = ts.position.z;
+    o[3] = ts.normal.x; o[4] = ts.normal.y; o[5] = ts.normal.z;
+    o[6] = ts.prob;
+    o[7] = __uint_as_float(ts.valid ? 1u : 0u);
+    o[8] = __int_as_float(error);
+}
+struct ProbeBox { float lo[3], hi[3]; };
+__global__ void probeTargetKernel(const LaunchArgs args, ProbeBox box, uint32_t n, float* out) {
+    using V = Variant<false, true, false, false>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Lane<V> L;
+    L.a = &args; L.stackBase = 0; L.cnt.clear();
+    L.idx = i; L.local = i; L.dim = 0;
+    f3 observer, direction;
+    probeObserver(L, box.lo, box.hi, observer, direction);
+    const TargetSample s = sampleTarget(L, args.p.target, observer, args.flags);
+    const TargetSample h = intersectTarget(args.p.target, observer, direction, args.flags);
+    float* o = out + (size_t)i * 25;
+    o[0] = observer.x; o[1] = observer.y; o[2] = observer.z;
+    o[3] = direction.x; o[4] = direction.y; o[5] = direction.z;
+    putTargetSample(o + 6, observer, s, false, direction);
+    putTargetSample(o + 15, observer, h, true, direction);
+    o[24] = __uint_as_float(isOccludedByTarget(args.p.target, observer, args.flags) ? 1u : 0u);
+}
+__global__ void probeGuideKernel(const LaunchArgs args, ProbeBox box, uint32_t n, float* out) {
+    using V = Variant<false, true, false, false>;
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    Lane<V> L;
+    L.a = &args; L.stackBase = 0; L.cnt.clear();
+    L.idx = i; L.local = i; L.dim = 0;
+    f3 observer, direction;
+    probeObserver(L, box.lo, box.hi, observer, direction);
+    const GuideSample s = sampleTargetGuide(L, observer);
+    const GuideSample e = evalTargetGuide(args.p.guide, observer, direction, args.flags);
+    float* o = out + (size_t)i * 13;
+    o[0] = observer.x; o[1] = observer.y; o[2] = observer.z;
+    o[3] = s.dir.x; o[4] = s.dir.y; o[5] = s.dir.z; o[6] = s.dist; o[7] = s.prob;
+    o[8] = e.dir.x; o[9] = e.dir.y; o[10] = e.dir.z; o[11] = e.dist; o[12] = e.prob;
+}
+hipError_t launchProbe(bool guide, const LaunchArgs& args, const float* lo, const float* hi, uint32_t n, float* out,
+                       hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    ProbeBox box;
+    for (int k = 0; k < 3; ++k) { box.lo[k] = lo[k]; box.hi[k] = hi[k]; }
+    const uint32_t grid = (n + 255u) / 256u;
+    if (guide) hipLaunchKernelGGL(probeGuideKernel, dim3(grid), dim3(256), 0, stream, args, box, n, out);
+    else hipLaunchKernelGGL(probeTargetKernel, dim3(grid), dim3(256), 0, stream, args, box, n, out);
+    return hipGetLastError();
+}
+
 // random.sink.glsl equivalent: raw words + floats behind random(stream, dim)
 __global__ void rngFillKernel(thx_philox_params p, uint32_t base_stream, uint32_t n_streams,
                               uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,

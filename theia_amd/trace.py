@@ -31,7 +31,8 @@ from .random import RNG, PhiloxRNG
 from .response import (EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, KernelHistogramHitResponse,
                        StoreTimeHitResponse, TraceConfig)
 from .scene import RectBBox, Scene
-from .target import InnerSphereTarget, SphereTarget, SphereTargetGuide, Target, TargetGuide
+from .target import (_GUIDES, _TARGETS, InnerSphereTarget, SphereTarget, SphereTargetGuide, Target, TargetGuide, fillGuideParams,
+                     fillTargetParams, guideFlags, targetFlags)
 
 __all__ = [
     "EmptyEventCallback", "EventResultCode", "EventStatisticCallback", "SceneForwardTracer", "Tracer",
@@ -383,8 +384,8 @@ class VolumeForwardTracer(Tracer):
         if traceBBox is None:
             traceBBox = RectBBox((-1.0 * u.km,) * 3, (1.0 * u.km,) * 3)
         self._checkComponents(source, wavelengthSource, response, rng, callback)
-        if not isinstance(target, (SphereTarget, InnerSphereTarget)):
-            raise _unsupported("target", target, "SphereTarget, InnerSphereTarget")
+        if not isinstance(target, _TARGETS):
+            raise _unsupported("target", target, ", ".join(c.__name__ for c in _TARGETS))
         # hits: one per scatter (+ one MIS sample each) + the direct one
         maxHitsPerThread = nScattering
         if not disableTargetSampling:
@@ -413,7 +414,7 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_DISABLE_MIS if disableTargetSampling else 0
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
-        flags |= capi.FLAG_TARGET_INNER if isinstance(target, InnerSphereTarget) else 0
+        flags |= targetFlags(target)
         srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
         flags |= srcFlags
         flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
@@ -453,12 +454,7 @@ class VolumeForwardTracer(Tracer):
         P.volume.medium[0], P.volume.medium[1] = t.medium.lo, t.medium.hi
         P.volume.objectId = t.objectId
         self._fillPropagation(P.volume.propagation, t, "lowerBBoxCorner", "upperBBoxCorner")
-        g = self._target._getParamsBlock("TargetParams", i)
-        for k, c in enumerate("xyz"):
-            P.target.position[k] = getattr(g.position, c)
-            P.target.invPos[k] = getattr(g._invPos, c)
-        P.target.radius, P.target.invRad = g.radius, g._invRad
-        P.target.hemisphereProb = g._prob if isinstance(self._target, InnerSphereTarget) else g._hemisphereProb
+        fillTargetParams(P.target, self._target, i)
         return P
 
     def run(self, i: int):
@@ -508,8 +504,8 @@ class SceneForwardTracer(Tracer):
         if callback is None:
             callback = EmptyEventCallback()
         self._checkComponents(source, wavelengthSource, response, rng, callback)
-        if targetGuide is not None and not isinstance(targetGuide, SphereTargetGuide):
-            raise _unsupported("target guide", targetGuide, "SphereTargetGuide, None")
+        if targetGuide is not None and not isinstance(targetGuide, _GUIDES):
+            raise _unsupported("target guide", targetGuide, ", ".join(c.__name__ for c in _GUIDES) + ", None")
         if targetGuide is not None and response.nRNGSamples > 0:
             raise NotImplementedError("responses that draw random numbers (StoreTimeHitResponse) are not available together "
                                       "with a target guide on the HIP backend")
@@ -540,7 +536,7 @@ class SceneForwardTracer(Tracer):
         flags = 0
         flags |= capi.FLAG_POLARIZED if polarized else 0
         flags |= capi.FLAG_DISABLE_DIRECT if disableDirectLighting else 0
-        flags |= capi.FLAG_DISABLE_MIS if targetGuide is None else 0
+        flags |= capi.FLAG_DISABLE_MIS if targetGuide is None else guideFlags(targetGuide)
         flags |= capi.FLAG_DISABLE_TRANSMISSION if disableTransmission else 0
         flags |= capi.FLAG_DISABLE_VOLUME_BORDER if disableVolumeBorder else 0
         flags |= capi.FLAG_HIT_USE_TRANSMITTED if useRefractedHitDir else 0
@@ -580,10 +576,7 @@ class SceneForwardTracer(Tracer):
         P.scene.sceneMedium[0], P.scene.sceneMedium[1] = t.sourceMedium.lo, t.sourceMedium.hi
         self._fillPropagation(P.scene.propagation, t, "_lowerBBoxCorner", "_upperBBoxCorner")
         if self._targetGuide is not None:
-            g = self._targetGuide._getParamsBlock("TargetGuideParams", i)
-            for k, c in enumerate("xyz"):
-                P.guide.position[k] = getattr(g.position, c)
-            P.guide.radius, P.guide.prob = g.radius, g._prob
+            fillGuideParams(P.guide, self._targetGuide, i)
         return P
 
     def run(self, i: int):
