@@ -1,47 +1,36 @@
 """
-The reference's analytic end-to-end pins of the scene forward tracer at the REFERENCE'S OWN
-sample sizes, on the HIP kernels (`-m gpu` only: 84 M / 200 M / 21 M photons per case are
-seconds on an MI355X and hours on the CPU oracle, whose reduced-size versions are in
-tests/test_oracle_tracers.py). Bodies as in /root/reference/tests/test_trace_energy.py:
-`test_SceneForwardTracer_GroundTruth` (:58-176, HitRecorder + scheduler + dumpQueue),
-`test_SceneForwardTracer_Crosscheck` (:187-337, target-guide MIS against plain path tracing),
-`test_SceneForwardTracer_MultiMedia` (:479-568, nested media with refraction, 0.61 %) and
-`test_VolumeForwardTracer` (:815-938, light inside an InnerSphereTarget, tolerances 2.8e-4 ... 1.2e-2).
-Only the mesh source differs (bundled sphere.stl fixture).
+The reference's analytic end-to-end pins of the forward and photon tracers, at the REFERENCE'S OWN
+sample sizes, on the HIP kernels (`-m gpu` only: 84 M / 200 M / 21 M photons per case are seconds
+on an MI355X and hours on the CPU oracle, whose reduced-size versions are in
+tests/test_oracle_tracers.py). Same geometry, media, keys, batch counts and tolerances as
+/root/reference/tests/test_trace_energy.py, restated in this suite's own form:
+`ground truth` (:58-176: light at the centre of a detector sphere; all energy arrives),
+`crosscheck` (:187-337: target-guide MIS against plain path tracing of twice the length),
+`multi media` (:479-568: nested media with refraction and reflection, 0.61 %),
+`volume` (:815-938: light inside an InnerSphereTarget, tolerances 2.8e-4 ... 1.2e-2),
+`photon tracers` (:1342-1590: detected photon count against the forward tracer's light curve).
+Only the mesh source differs (bundled sphere.stl fixture instead of assets/sphere.stl).
 """
 import numpy as np
 import pytest
 
-import hephaistos as hp
 import hephaistos.pipeline as pl
 import scenarios as S
-import theia
-import theia.light
-import theia.material
-import theia.random
-import theia.response
-import theia.scene
-import theia.trace
+import theia.light as TL
+import theia.material as TM
+import theia.response as TR
+import theia.scene as TS
+import theia.trace as TT
 import theia.units as u
 from hephaistos.queue import dumpQueue
-from theia.scene import Transform
+from theia.random import PhiloxRNG
 from theia.target import InnerSphereTarget, SphereTargetGuide
 
 pytestmark = pytest.mark.gpu
 
-
-class MediumModel(
-    theia.material.DispersionFreeMedium,
-    theia.material.HenyeyGreensteinPhaseFunction,
-    theia.material.KokhanovskyOceanWaterPhaseMatrix,
-    theia.material.MediumModel,
-):
-    def __init__(self, a, s, g, *, n=1.33, ng=1.33) -> None:
-        theia.material.DispersionFreeMedium.__init__(self, n=n, ng=ng, mu_a=a, mu_s=s)
-        theia.material.HenyeyGreensteinPhaseFunction.__init__(self, g)
-        theia.material.KokhanovskyOceanWaterPhaseMatrix.__init__(self, p90=0.66, theta0=0.25, alpha=4.0, xi=25.6)
-
-    ModelName = "homogenous"
+LAMBDA, T_EMIT = 400.0 * u.nm, 10.0 * u.ns
+OFF_CENTRE = (12.0, 15.0, 0.2) * u.m
+Mi = 1024 * 1024
 
 
 @pytest.fixture(autouse=True)
@@ -54,454 +43,213 @@ def _hip_backend():
     _backend._backend = prev
 
 
-@pytest.mark.parametrize(
-    "mu_a,mu_s,g,polarized",
-    [
-        (0.0, 0.005, 0.0, False),
-        (0.05, 0.01, 0.0, False),
-        (0.05, 0.01, -0.9, False),
-        (0.05, 0.01, 0.9, False),
-        (0.0, 0.005, 0.0, True),
-        (0.05, 0.01, -0.9, True),
-    ],
-)
-def test_SceneForwardTracer_GroundTruth(mu_a: float, mu_s: float, g: float, polarized: bool) -> None:
-    """Sphere detector filled with scattering medium, in center spherical light source."""
-    if not hp.isRaytracingEnabled():
-        pytest.skip("ray tracing is not supported")
+def medium_model(a, s, g, **kw):
+    """dispersion free, Henyey-Greenstein, Kokhanovsky phase matrix (test_trace_energy.py:31-45)"""
+    return S.EnergyTestModel(a, s, g, **kw)
 
-    position = (12.0, 15.0, 0.2) * u.m
-    radius = 100.0 * u.m
-    budget = 1e9
-    t0 = 10.0 * u.ns
-    lam = 400.0 * u.nm  # doesn't really matter
-    max_length = 10
-    scatter_coef = 0.05
-    maxTime = float("inf")
-    batch_size = 2 * 1024 * 1024
-    n_batches = 40
 
-    model = MediumModel(mu_a, mu_s, g)
+def detector_sphere(model, radius, centre, *, inside: bool):
+    """one detector sphere (flags DB): `inside` = the medium fills it (light inside), else it
+    surrounds it. Returns (scene, material store)."""
     medium = model.createMedium()
-    material = theia.material.Material("det", medium, None, flags="DB")
-    matStore = theia.material.MaterialStore([material])
-    meshStore = theia.scene.MeshStore({"sphere": S.bundled_mesh("sphere")})  # reference: assets/sphere.stl
+    material = TM.Material("det", medium, None, flags="DB") if inside else TM.Material("det", None, medium, flags="DB")
+    store = TM.MaterialStore([material])
+    meshes = TS.MeshStore({"sphere": S.bundled_mesh("sphere")})
+    instance = meshes.createInstance("sphere", "det", TS.Transform.TRS(scale=radius, translate=centre), detectorId=0)
+    return TS.Scene([instance], store.material, medium=store.media["homogenous"]), store
 
-    trafo = Transform.TRS(scale=radius, translate=position)
-    target = meshStore.createInstance("sphere", "det", trafo, detectorId=0)
-    scene = theia.scene.Scene([target], matStore.material, medium=matStore.media["homogenous"])
-    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
-    light = theia.light.SphericalLightSource(position=position, timeRange=(t0, t0), budget=budget)
-    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
-    recorder = theia.response.HitRecorder(polarized=polarized)
-    tracer = theia.trace.SceneForwardTracer(batch_size, light, photons, recorder, rng, scene=scene, maxPathLength=max_length,
-                                            scatterCoefficient=scatter_coef, maxTime=maxTime, polarized=polarized)
-    rng.autoAdvance = tracer.nRNGSamples
 
-    batches = []
+def point_source(where, budget, t=T_EMIT):
+    return TL.SphericalLightSource(position=where, timeRange=(t, t), budget=budget)
 
-    def process(config: int, batch: int, args) -> None:
-        batch = dumpQueue(recorder.queue.view(config))
-        batches.append(batch)
 
-    pipeline = pl.Pipeline(tracer.collectStages())
-    scheduler = pl.PipelineScheduler(pipeline, processFn=process)
-    tasks = [{}] * n_batches  # rng advances on its own, so we dont have to update any params
-    scheduler.schedule(tasks)
+def run_tasks(tracer, count, collect):
+    """`count` batches through a scheduler; `collect(config)` after each (the generator advances by
+    itself, no parameters change between tasks)"""
+    scheduler = pl.PipelineScheduler(pl.Pipeline(tracer.collectStages()), processFn=lambda cfg, k, args: collect(cfg))
+    scheduler.schedule([{} for _ in range(count)])
     scheduler.wait()
     scheduler.destroy()
 
-    time = np.concatenate([b["time"] for b in batches])
-    value = np.concatenate([b["contrib"] for b in batches])
 
-    # undo attenuation
-    vg = 1.0 / model.ng * u.c
-    d = vg * (time - t0)
-    value0 = value * np.exp(mu_a * d)
+def mean_curve(tracer, response, count):
+    curves = []
+    run_tasks(tracer, count, lambda cfg: curves.append(response.result(cfg).copy()))
+    return np.mean(curves, 0)
 
-    # check for energy conservation
-    estimate = value0.sum(dtype=np.float64) / (batch_size * n_batches)
-    assert np.abs(estimate / budget - 1.0) < 0.05
-    assert estimate < budget  # biased by ignoring longer paths, i.e. missing energy
 
-    # additional check since we have the data: uniform hits on sphere
-    positions = np.concatenate([b["position"] for b in batches], axis=0)
-    assert np.abs(positions.mean(0)).max() < 5e-3
-    vars = np.vstack([b["position"].var(0) for b in batches])
-    assert np.abs(vars - 1 / 3).max() < 0.01
+def unattenuated(model, mu_a, time, contrib, t0=T_EMIT):
+    """contribution with the absorption along the flight path undone"""
+    return contrib * np.exp(mu_a * (1.0 / model.ng * u.c) * (time - t0))
 
+
+def assert_stokes_valid(stokes):
+    assert np.abs(stokes[:, 0] - 1.0).max() < 1e-5
+    assert -1.0 <= stokes[:, 1:].min() and stokes[:, 1:].max() <= 1.0
+    assert np.all(np.square(stokes[:, 1:]).sum(-1) <= 1.0 + 1e-6)
+
+
+@pytest.mark.parametrize("mu_a,mu_s,g,polarized", [(0.0, 0.005, 0.0, False), (0.05, 0.01, 0.0, False), (0.05, 0.01, -0.9, False),
+                                                   (0.05, 0.01, 0.9, False), (0.0, 0.005, 0.0, True), (0.05, 0.01, -0.9, True)])
+def test_scene_ground_truth(mu_a, mu_s, g, polarized):
+    """light at the centre of a 100 m detector sphere full of scattering medium: with the absorption
+    undone all of the budget arrives (5 %, from below: longer paths are cut), uniformly over the sphere"""
+    budget, batch, tasks = 1e9, 2 * Mi, 40
+    model = medium_model(mu_a, mu_s, g)
+    scene, _store = detector_sphere(model, 100.0 * u.m, OFF_CENTRE, inside=True)
+    rng, recorder = PhiloxRNG(key=0xC0FFEE), TR.HitRecorder(polarized=polarized)
+    tracer = TT.SceneForwardTracer(batch, point_source(OFF_CENTRE, budget), TL.UniformWavelengthSource(lambdaRange=(LAMBDA, LAMBDA)),
+                                   recorder, rng, scene=scene, maxPathLength=10, scatterCoefficient=0.05, maxTime=float("inf"),
+                                   polarized=polarized)
+    rng.autoAdvance = tracer.nRNGSamples
+    dumps = []
+    run_tasks(tracer, tasks, lambda cfg: dumps.append(dumpQueue(recorder.queue.view(cfg))))
+    column = lambda f: np.concatenate([d[f] for d in dumps])
+    arrived = unattenuated(model, mu_a, column("time"), column("contrib")).sum(dtype=np.float64) / (batch * tasks)
+    assert abs(arrived / budget - 1.0) < 0.05 and arrived < budget
+    assert np.abs(column("position").mean(0)).max() < 5e-3
+    assert np.abs(np.vstack([d["position"].var(0) for d in dumps]) - 1 / 3).max() < 0.01
     if polarized:
-        stokes = np.concatenate([b["stokes"] for b in batches])
-        assert np.abs(stokes[:, 0] - 1.0).max() < 1e-5
-        assert stokes[:, 1:].max() <= 1.0
-        assert stokes[:, 1:].min() >= -1.0
-        assert np.all(np.square(stokes[:, 1:]).sum(-1) <= 1.0 + 1e-6)
+        assert_stokes_valid(column("stokes"))
 
 
-@pytest.mark.parametrize(
-    "mu_a,mu_s,g,polarized",
-    [
-        (0.0, 0.01, 0.0, False),
-        (0.05, 0.005, 0.5, False),
-        (0.0, 0.01, 0.0, True),
-        (0.05, 0.005, -0.5, True),
-    ],
-)
-def test_SceneForwardTracer_Crosscheck(mu_a: float, mu_s: float, g: float, polarized: bool) -> None:
-    """SceneForwardTracer's target sampling against plain path tracing of twice the length."""
-    if not hp.isRaytracingEnabled():
-        pytest.skip("ray tracing is not supported")
+@pytest.mark.parametrize("mu_a,mu_s,g,polarized", [(0.0, 0.01, 0.0, False), (0.05, 0.005, 0.5, False), (0.0, 0.01, 0.0, True),
+                                                   (0.05, 0.005, -0.5, True)])
+def test_scene_crosscheck(mu_a, mu_s, g, polarized):
+    """5 m detector sphere at the origin, light 6 m off: paths of length 10 with target-guide MIS
+    against plain paths of length 20 (2 % in total, 1 % in the mean relative error of the log curves;
+    600 ns cut: the plain estimate is too noisy later)"""
+    budget, batch, tasks, radius = 1e9, 1 * Mi, 100, 5.0 * u.m
+    scene, _store = detector_sphere(medium_model(mu_a, mu_s, g), radius, (0.0, 0.0, 0.0) * u.m, inside=False)
+    light, photons = point_source((-6.0, 0.0, 0.0) * u.m, budget, 30.0 * u.ns), TL.UniformWavelengthSource(lambdaRange=(LAMBDA, LAMBDA))
+    rng = PhiloxRNG(key=0xC0FFEE)
 
-    position = (0.0, 0.0, 0.0) * u.m
-    radius = 5.0 * u.m
-    light_pos = (-6.0, 0.0, 0.0) * u.m
-    budget = 1e9
-    t0 = 30.0 * u.ns
-    lam = 400.0 * u.nm
-    max_length = 10
-    scatter_coef = 0.01
-    maxTime = 600.0  # limit as ground truth suffers from high variance at late times
-    batch_size = 1 * 1024 * 1024
-    n_batches = 100
-    bin_t0 = 0.0
-    bin_size = 20.0
-    n_bins = 30
-
-    model = MediumModel(mu_a, mu_s, g)
-    medium = model.createMedium()
-    material = theia.material.Material("det", None, medium, flags="DB")
-    matStore = theia.material.MaterialStore([material])
-    meshStore = theia.scene.MeshStore({"sphere": S.bundled_mesh("sphere")})
-
-    guide = SphereTargetGuide(position=position, radius=radius)
-    trafo = Transform.TRS(scale=radius, translate=position)
-    target = meshStore.createInstance("sphere", "det", trafo, detectorId=0)
-    scene = theia.scene.Scene([target], matStore.material, medium=matStore.media["homogenous"])
-    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
-    light = theia.light.SphericalLightSource(position=light_pos, timeRange=(t0, t0), budget=budget)
-
-    def run(maxPathLength, targetGuide):
-        value = theia.response.UniformValueResponse()
-        response = theia.response.HistogramHitResponse(value, nBins=n_bins, binSize=bin_size, t0=bin_t0,
-                                                       normalization=1 / batch_size)
-        tracer = theia.trace.SceneForwardTracer(batch_size, light, photons, response, rng, scene=scene,
-                                                maxPathLength=maxPathLength, targetGuide=targetGuide,
-                                                scatterCoefficient=scatter_coef, maxTime=maxTime, polarized=polarized)
+    def curve(length, guide):
+        response = TR.HistogramHitResponse(TR.UniformValueResponse(), nBins=30, binSize=20.0, t0=0.0, normalization=1 / batch)
+        tracer = TT.SceneForwardTracer(batch, light, photons, response, rng, scene=scene, maxPathLength=length, targetGuide=guide,
+                                       scatterCoefficient=0.01, maxTime=600.0, polarized=polarized)
         rng.autoAdvance = tracer.nRNGSamples
-        hists = []
+        return mean_curve(tracer, response, tasks)
 
-        def process(config: int, batch: int, args) -> None:
-            hists.append(response.result(config).copy())
-
-        pipeline = pl.Pipeline(tracer.collectStages())
-        scheduler = pl.PipelineScheduler(pipeline, processFn=process)
-        scheduler.schedule([{}] * n_batches)  # rng advances on its own, so no updates
-        scheduler.wait()
-        scheduler.destroy()
-        return np.mean(hists, 0)
-
-    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
-    truth_hist = run(2 * max_length, None)  # higher variance -> more samples
-    truth = truth_hist.sum()
-    hist = run(max_length, guide)
-    estimate = hist.sum()
-
-    assert truth > 0.0  # just to be safe
-    assert abs(estimate / truth - 1.0) < 0.02
-    # Compare early part of light curves (log10)
+    plain = curve(20, None)
+    guided = curve(10, SphereTargetGuide(position=(0.0, 0.0, 0.0) * u.m, radius=radius))
+    assert plain.sum() > 0.0 and abs(guided.sum() / plain.sum() - 1.0) < 0.02
     with np.errstate(divide="ignore", invalid="ignore"):
-        log_err = (np.log10(hist) - np.log10(truth_hist)) / np.log10(hist)
-    log_err = np.nan_to_num(log_err, nan=0.0)
-    assert np.abs(log_err).mean() < 0.01
+        rel = np.nan_to_num((np.log10(guided) - np.log10(plain)) / np.log10(guided), nan=0.0)
+    assert np.abs(rel).mean() < 0.01
 
 
 @pytest.mark.parametrize("polarized", [True, False])
-def test_SceneForwardTracer_MultiMedia(polarized: bool):
-    """Spherical light source inside a spherical detector with an outer and an inner shell of
-    different media: all the energy must arrive (0.61 %)."""
-    if not hp.isRaytracingEnabled():
-        pytest.skip("ray tracing is not supported")
-
-    position = (12.0, 15.0, 0.2) * u.m
-    light_pos = (2.0, 5.0, 0.0) * u.m  # offset light
-    radius = 100.0 * u.m
-    radius_inner = 65.0 * u.m
-    budget = 1e9
-    t0 = 10.0 * u.ns
-    lam = 400.0 * u.nm
-    max_length = 50
-    scatter_coef = 0.03
-    maxTime = float("inf")
-    batch_size = 2 * 1024 * 1024
-    n_batches = 10
-
-    # set mu_a=0 so we can skip the calculation to remove it
-    media_inner = MediumModel(0.0, 0.01, 0.9, n=1.8).createMedium(name="inner")
-    media_outer = MediumModel(0.0, 0.04, 0.9, n=1.2).createMedium(name="outer")
-    mat_det = theia.material.Material("det", media_outer, None, flags="DB")
-    # need both reflection and transmission to recover all the energy
-    mat_inner = theia.material.Material("inner", media_inner, media_outer, flags="TR")
-    matStore = theia.material.MaterialStore([mat_det, mat_inner])
-
-    meshStore = theia.scene.MeshStore({"sphere": S.bundled_mesh("sphere")})
-    t_inner = Transform.TRS(scale=radius_inner, translate=position)
-    t_det = Transform.TRS(scale=radius, translate=position)
-    inner = meshStore.createInstance("sphere", "inner", t_inner)
-    det = meshStore.createInstance("sphere", "det", t_det)
-    scene = theia.scene.Scene([inner, det], matStore.material)
-
-    photons = theia.light.ConstWavelengthSource(lam)
-    light = theia.light.SphericalLightSource(position=light_pos, timeRange=(t0, t0), budget=budget)
-    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
-    response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), nBins=400, binSize=100.0 * u.ns)
-    tracer = theia.trace.SceneForwardTracer(batch_size, light, photons, response, rng, scene, maxPathLength=max_length,
-                                            scatterCoefficient=scatter_coef, sourceMedium=matStore.media["inner"],
-                                            maxTime=maxTime, polarized=polarized)
+def test_scene_multi_media(polarized):
+    """off-centre light inside a 65 m glass-like shell (n 1.8) inside the 100 m detector sphere
+    (n 1.2), no absorption: reflection and transmission together return all the energy (0.61 %)"""
+    budget, batch, tasks = 1e9, 2 * Mi, 10
+    inner = medium_model(0.0, 0.01, 0.9, n=1.8).createMedium(name="inner")
+    outer = medium_model(0.0, 0.04, 0.9, n=1.2).createMedium(name="outer")
+    store = TM.MaterialStore([TM.Material("det", outer, None, flags="DB"), TM.Material("inner", inner, outer, flags="TR")])
+    meshes = TS.MeshStore({"sphere": S.bundled_mesh("sphere")})
+    shells = [meshes.createInstance("sphere", name, TS.Transform.TRS(scale=r, translate=OFF_CENTRE))
+              for name, r in (("inner", 65.0 * u.m), ("det", 100.0 * u.m))]
+    scene = TS.Scene(shells, store.material)
+    rng = PhiloxRNG(key=0xC0FFEE)
+    response = TR.HistogramHitResponse(TR.UniformValueResponse(), nBins=400, binSize=100.0 * u.ns)
+    tracer = TT.SceneForwardTracer(batch, point_source((2.0, 5.0, 0.0) * u.m, budget), TL.ConstWavelengthSource(LAMBDA), response, rng,
+                                   scene, maxPathLength=50, scatterCoefficient=0.03, sourceMedium=store.media["inner"],
+                                   maxTime=float("inf"), polarized=polarized)
     rng.autoAdvance = tracer.nRNGSamples
-
-    hists = []
-
-    def process(config: int, batch: int, args) -> None:
-        hists.append(response.result(config).copy())
-
-    pipeline = pl.Pipeline(tracer.collectStages())
-    scheduler = pl.PipelineScheduler(pipeline, processFn=process)
-    scheduler.schedule([{} for _ in range(n_batches)])
-    scheduler.wait()
-    scheduler.destroy()
-    hist = np.mean(hists, 0)
-    estimate = hist.sum()
-
-    assert abs(estimate / budget - 1.0) < 0.0061
+    assert abs(mean_curve(tracer, response, tasks).sum() / budget - 1.0) < 0.0061
 
 
-@pytest.mark.parametrize(
-    "mu_a,mu_s,mu_sample,g,disableDirect,sampleTarget,polarized,err",
-    [
-        (0.0, 0.005, 0.05, 0.0, False, True, False, 4.5e-4),
-        (0.0, 0.005, 0.05, 0.0, False, False, False, 0.011),
-        (0.0, 0.005, 0.05, 0.0, True, True, False, 0.011),
-        (0.05, 0.01, 0.05, 0.0, False, True, False, 1.8e-3),
-        (0.05, 0.01, 0.05, 0.0, True, True, False, 2.6e-3),
-        (0.05, 0.01, 0.05, -0.9, False, True, False, 0.012),
-        (0.05, 0.01, 0.05, 0.9, True, True, False, 2.8e-4),
-        (0.05, 0.01, 0.05, 0.9, True, False, False, 2.9e-3),
-        (0.05, 0.01, np.nan, 0.9, False, True, True, 2.9e-3),
-        (0.0, 0.005, 0.05, 0.0, False, True, True, 5e-4),
-        (0.0, 0.005, 0.05, 0.0, True, True, True, 1.2e-3),
-        (0.05, 0.01, 0.05, -0.9, False, True, True, 0.012),
-    ],
-)
-def test_VolumeForwardTracer(mu_a, mu_s, mu_sample, g, disableDirect, sampleTarget, polarized, err) -> None:
-    """Spherical light source placed within a spherical target"""
-    position = (12.0, 15.0, 0.2) * u.m
-    radius = 100.0 * u.m
-    budget = 1e9
-    t0 = 10.0 * u.ns
-    lam = 400.0 * u.nm
-    max_length = 10
-    maxTime = float("inf")
-    batch_size = 512 * 1024
-    n_batches = 10
+VOLUME_ROWS = [  # mu_a, mu_s, sampling coefficient, g, no direct light, target sampling, polarized, tolerance
+    (0.0, 0.005, 0.05, 0.0, False, True, False, 4.5e-4), (0.0, 0.005, 0.05, 0.0, False, False, False, 0.011),
+    (0.0, 0.005, 0.05, 0.0, True, True, False, 0.011), (0.05, 0.01, 0.05, 0.0, False, True, False, 1.8e-3),
+    (0.05, 0.01, 0.05, 0.0, True, True, False, 2.6e-3), (0.05, 0.01, 0.05, -0.9, False, True, False, 0.012),
+    (0.05, 0.01, 0.05, 0.9, True, True, False, 2.8e-4), (0.05, 0.01, 0.05, 0.9, True, False, False, 2.9e-3),
+    (0.05, 0.01, np.nan, 0.9, False, True, True, 2.9e-3), (0.0, 0.005, 0.05, 0.0, False, True, True, 5e-4),
+    (0.0, 0.005, 0.05, 0.0, True, True, True, 1.2e-3), (0.05, 0.01, 0.05, -0.9, False, True, True, 0.012),
+]
 
-    model = MediumModel(mu_a, mu_s, g)
-    medium = model.createMedium()
-    store = theia.material.MaterialStore([], media=[medium])
 
-    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
-    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
-    light = theia.light.SphericalLightSource(position=position, timeRange=(t0, t0), budget=budget)
-    target = InnerSphereTarget(position=position, radius=radius)
-    recorder = theia.response.HitRecorder(polarized=polarized)
-    tracer = theia.trace.VolumeForwardTracer(
-        batch_size, light, target, photons, recorder, rng,
-        medium=store.media["homogenous"], maxTime=maxTime, nScattering=max_length, scatterCoefficient=mu_sample,
-        polarized=polarized, disableDirectLighting=disableDirect, disableTargetSampling=not sampleTarget,
-    )
+@pytest.mark.parametrize("mu_a,mu_s,mu_sample,g,no_direct,sample_target,polarized,tol", VOLUME_ROWS)
+def test_volume_energy(mu_a, mu_s, mu_sample, g, no_direct, sample_target, polarized, tol):
+    """light at the centre of a 100 m InnerSphereTarget: the budget (minus the unscattered share when
+    direct light is off) arrives once absorption is undone"""
+    budget, batch, tasks, radius = 1e9, 512 * 1024, 10, 100.0 * u.m
+    model = medium_model(mu_a, mu_s, g)
+    store = TM.MaterialStore([], media=[model.createMedium()])
+    rng, recorder = PhiloxRNG(key=0xC0FFEE), TR.HitRecorder(polarized=polarized)
+    tracer = TT.VolumeForwardTracer(batch, point_source(OFF_CENTRE, budget), InnerSphereTarget(position=OFF_CENTRE, radius=radius),
+                                    TL.UniformWavelengthSource(lambdaRange=(LAMBDA, LAMBDA)), recorder, rng,
+                                    medium=store.media["homogenous"], maxTime=float("inf"), nScattering=10,
+                                    scatterCoefficient=mu_sample, polarized=polarized, disableDirectLighting=no_direct,
+                                    disableTargetSampling=not sample_target)
     rng.autoAdvance = tracer.nRNGSamples
+    acc = {"sum": 0.0, "stokes": []}
 
-    total = 0
-    stokes = []
-
-    def process(config: int, batch: int, args) -> None:
-        nonlocal total
-        result = recorder.queue.view(config)
-        result = result[: result.count]
-        # undo attenuation
-        vg = 1.0 / model.ng * u.c
-        d = vg * (result["time"] - t0)
-        value0 = result["contrib"] * np.exp(mu_a * d)
-        total += value0.sum(dtype=np.float64)
+    def collect(cfg):
+        q = recorder.queue.view(cfg)
+        q = q[: q.count]
+        acc["sum"] += unattenuated(model, mu_a, q["time"], q["contrib"]).sum(dtype=np.float64)
         if polarized:
-            stokes.append(result["stokes"].copy())
+            acc["stokes"].append(q["stokes"].copy())
 
-    pipeline = pl.Pipeline(tracer.collectStages())
-    scheduler = pl.PipelineScheduler(pipeline, processFn=process)
-    scheduler.schedule([{}] * n_batches)
-    scheduler.wait()
-    scheduler.destroy()
-
-    # calculate direct contribution without attenuation
-    directContrib = budget * np.exp(-mu_s * radius)
-    contrib = budget - directContrib if disableDirect else budget
-
-    # check for energy conservation
-    estimate = total / (batch_size * n_batches)
-    assert np.abs(estimate / contrib - 1.0) < err
-
+    run_tasks(tracer, tasks, collect)
+    expected = budget - budget * np.exp(-mu_s * radius) if no_direct else budget
+    assert abs(acc["sum"] / (batch * tasks) / expected - 1.0) < tol
     if polarized:
-        stokes = np.concatenate(stokes)
-        assert np.abs(stokes[:, 0] - 1.0).max() < 1e-5
-        assert stokes[:, 1:].max() <= 1.0
-        assert stokes[:, 1:].min() >= -1.0
-        assert np.all(np.square(stokes[:, 1:]).sum(-1) <= 1.0 + 1e-6)
+        assert_stokes_valid(np.concatenate(acc["stokes"]))
 
 
-@pytest.mark.parametrize(
-    "mu_a,mu_s,g,polarized",
-    [
-        (0.0, 0.05, 0.0, False),
-        (0.05, 0.05, 0.0, False),
-        (0.05, 0.01, -0.9, False),
-        (0.05, 0.01, 0.9, False),
-        # FIXME (reference): Polarization seems broken for now
-        # (0.0, 0.05, 0.0, True),
-        (0.05, 0.01, -0.9, True),
-    ],
-)
-def test_ScenePhotonTracer(mu_a: float, mu_s: float, g: float, polarized: bool):
-    """/root/reference/tests/test_trace_energy.py:1342-1465: the number of photons a ScenePhotonTracer
-    detects (StoreTimeHitResponse) against the light curve integral of a SceneForwardTracer"""
-    if not hp.isRaytracingEnabled():
-        pytest.skip("ray tracing is not supported")
+# the reference leaves (0.0, 0.05, 0.0, polarized) out: "Polarization seems broken for now"
+PHOTON_ROWS = [(0.0, 0.05, 0.0, False), (0.05, 0.05, 0.0, False), (0.05, 0.01, -0.9, False), (0.05, 0.01, 0.9, False),
+               (0.05, 0.01, -0.9, True)]
 
-    position = (12.0, 15.0, 0.2) * u.m
-    radius = 60.0 * u.m
-    budget = 1e6
-    t0 = 10.0 * u.ns
-    lam = 400.0 * u.nm
-    max_length = 80
-    scatter_coef = 0.05
-    maxTime = float("inf")
-    n_runs = 20
-    n_scatterPerRun = 5
-    batch_size = 1 * 1024 * 1024
-    n_batches = 20
 
-    model = MediumModel(mu_a, mu_s, g)
-    medium = model.createMedium()
-    material = theia.material.Material("det", medium, None, flags="DB")
-    matStore = theia.material.MaterialStore([material])
-    meshStore = theia.scene.MeshStore({"sphere": S.bundled_mesh("sphere")})
-    trafo = Transform.TRS(scale=radius, translate=position)
-    target = meshStore.createInstance("sphere", "det", trafo, detectorId=0)
-    scene = theia.scene.Scene([target], matStore.material, medium=matStore.media["homogenous"])
+def assert_photon_count(count, expected, budget, mu_a):
+    if mu_a != 0.0:  # a count of random survivors: 5 sigma
+        assert abs(count - expected) < 5.0 * np.sqrt(expected)
+    else:  # nothing absorbs: every photon arrives
+        assert count == int(budget)
 
-    rng = theia.random.PhiloxRNG(key=0xC01DC0FFEE)
-    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
-    light = theia.light.SphericalLightSource(position=position, timeRange=(t0, t0), budget=budget)
-    # use scene tracer as known truth source for estimating the amount hits
-    hist_response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), binSize=50.0 * u.ns, nBins=400)
-    hist_tracer = theia.trace.SceneForwardTracer(batch_size, light, photons, hist_response, rng, scene, maxPathLength=max_length,
-                                                 scatterCoefficient=scatter_coef, maxTime=maxTime, polarized=polarized)
-    rng.autoAdvance = hist_tracer.nRNGSamples
-    hists = []
-    process = lambda c, b, _: hists.append(hist_response.result(c).copy())
-    hist_pipeline = pl.Pipeline(hist_tracer.collectStages())
-    scheduler = pl.PipelineScheduler(hist_pipeline, processFn=process)
-    scheduler.schedule([{} for i in range(n_batches)])
-    scheduler.wait()
-    scheduler.destroy()
 
-    hist = np.mean(hists, 0)
-    exp_hits = hist.sum()
-
-    # next we can do the photon tracer
-    response = theia.response.StoreTimeHitResponse(theia.response.UniformValueResponse())
-    stats = theia.trace.EventStatisticCallback()
-    tracer = theia.trace.ScenePhotonTracer(
-        int(budget),  # this way a single batch is enough
-        light, photons, response, rng, scene,
-        nScatteringPerRun=n_scatterPerRun, nRuns=n_runs, maxTime=maxTime, polarized=polarized, callback=stats,
-    )
+@pytest.mark.parametrize("mu_a,mu_s,g,polarized", PHOTON_ROWS)
+def test_scene_photon_tracer(mu_a, mu_s, g, polarized):
+    """photons a ScenePhotonTracer detects (one batch of 10^6, 20 runs x 5 steps) against the light
+    curve integral of the SceneForwardTracer (20 Mi paths of length 80) in a 60 m detector sphere"""
+    budget, batch, tasks = 1e6, 1 * Mi, 20
+    scene, _store = detector_sphere(medium_model(mu_a, mu_s, g), 60.0 * u.m, OFF_CENTRE, inside=True)
+    rng, light = PhiloxRNG(key=0xC01DC0FFEE), point_source(OFF_CENTRE, budget)
+    photons = TL.UniformWavelengthSource(lambdaRange=(LAMBDA, LAMBDA))
+    curve = TR.HistogramHitResponse(TR.UniformValueResponse(), binSize=50.0 * u.ns, nBins=400)
+    forward = TT.SceneForwardTracer(batch, light, photons, curve, rng, scene, maxPathLength=80, scatterCoefficient=0.05,
+                                    maxTime=float("inf"), polarized=polarized)
+    rng.autoAdvance = forward.nRNGSamples
+    expected = mean_curve(forward, curve, tasks).sum()
+    stored = TR.StoreTimeHitResponse(TR.UniformValueResponse())
+    tracer = TT.ScenePhotonTracer(int(budget), light, photons, stored, rng, scene, nScatteringPerRun=5, nRuns=20,
+                                  maxTime=float("inf"), polarized=polarized, callback=TT.EventStatisticCallback())
     pl.runPipeline(tracer.collectStages())
-    hits = response.result(0)
-    assert hits is not None
-    if mu_a != 0.0:
-        # since the photon tracer samples a random distribution we need to allow a
-        # rather large error. here we use 5 sigmas as a rather pessimistic test
-        assert np.abs(hits.count - exp_hits) < 5.0 * np.sqrt(exp_hits)
-    else:
-        # no absorption means we should recover all photons
-        assert hits.count == int(budget)
+    assert stored.result(0) is not None
+    assert_photon_count(stored.result(0).count, expected, budget, mu_a)
 
 
-@pytest.mark.parametrize(
-    "mu_a,mu_s,g,polarized",
-    [
-        (0.0, 0.05, 0.0, False),
-        (0.05, 0.05, 0.0, False),
-        (0.05, 0.01, -0.9, False),
-        (0.05, 0.01, 0.9, False),
-        # FIXME (reference): Polarization seems broken for now
-        # (0.0, 0.05, 0.0, True),
-        (0.05, 0.01, -0.9, True),
-    ],
-)
-def test_VolumePhotonTracer(mu_a: float, mu_s: float, g: float, polarized: bool):
-    """/root/reference/tests/test_trace_energy.py:1467-1590: photons a VolumePhotonTracer detects inside an
-    InnerSphereTarget against the light-curve integral of the VolumeForwardTracer (target sampling on)"""
-    position = (12.0, 15.0, 0.2) * u.m
-    radius = 60.0 * u.m
-    budget = 1e6
-    t0 = 10.0 * u.ns
-    lam = 400.0 * u.nm
-    max_length = 80
-    maxTime = float("inf")
-    scatter_coef = 0.05
-    n_runs = 40
-    n_scatterPerRun = 5
-    batch_size = 1 * 1024 * 1024
-    n_batches = 20
-
-    model = MediumModel(mu_a, mu_s, g)
-    medium = model.createMedium()
-    store = theia.material.MaterialStore([], media=[medium])
-
-    rng = theia.random.PhiloxRNG(key=0xC0FFEE)
-    photons = theia.light.UniformWavelengthSource(lambdaRange=(lam, lam))
-    light = theia.light.SphericalLightSource(position=position, timeRange=(t0, t0), budget=budget)
-    target = InnerSphereTarget(position=position, radius=radius)
-    # use volume tracer as known truth source for estimating the amount of hits
-    hist_response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), binSize=50.0 * u.ns, nBins=400)
-    hist_tracer = theia.trace.VolumeForwardTracer(batch_size, light, target, photons, hist_response, rng,
-                                                  medium=store.media["homogenous"], maxTime=maxTime, nScattering=max_length,
-                                                  scatterCoefficient=scatter_coef, polarized=polarized)
-    rng.autoAdvance = hist_tracer.nRNGSamples
-    hists = []
-    process = lambda c, b, _: hists.append(hist_response.result(c).copy())
-    hist_pipeline = pl.Pipeline(hist_tracer.collectStages())
-    scheduler = pl.PipelineScheduler(hist_pipeline, processFn=process)
-    scheduler.schedule([{} for i in range(n_batches)])
-    scheduler.wait()
-    scheduler.destroy()
-
-    hist = np.mean(hists, 0)
-    exp_hits = hist.sum()
-
-    response = theia.response.StoreTimeHitResponse(theia.response.UniformValueResponse())
-    stats = theia.trace.EventStatisticCallback()
-    tracer = theia.trace.VolumePhotonTracer(
-        int(budget),  # this way a single batch is enough
-        light, target, photons, response, rng,
-        medium=store.media["homogenous"], nScatteringPerRun=n_scatterPerRun, nRuns=n_runs, maxTime=maxTime,
-        polarized=polarized, callback=stats,
-    )
+@pytest.mark.parametrize("mu_a,mu_s,g,polarized", PHOTON_ROWS)
+def test_volume_photon_tracer(mu_a, mu_s, g, polarized):
+    """the same for the VolumePhotonTracer (40 runs x 5 steps) inside a 60 m InnerSphereTarget against
+    the VolumeForwardTracer with target sampling"""
+    budget, batch, tasks = 1e6, 1 * Mi, 20
+    store = TM.MaterialStore([], media=[medium_model(mu_a, mu_s, g).createMedium()])
+    rng, light = PhiloxRNG(key=0xC0FFEE), point_source(OFF_CENTRE, budget)
+    photons, target = TL.UniformWavelengthSource(lambdaRange=(LAMBDA, LAMBDA)), InnerSphereTarget(position=OFF_CENTRE, radius=60.0 * u.m)
+    curve = TR.HistogramHitResponse(TR.UniformValueResponse(), binSize=50.0 * u.ns, nBins=400)
+    forward = TT.VolumeForwardTracer(batch, light, target, photons, curve, rng, medium=store.media["homogenous"],
+                                     maxTime=float("inf"), nScattering=80, scatterCoefficient=0.05, polarized=polarized)
+    rng.autoAdvance = forward.nRNGSamples
+    expected = mean_curve(forward, curve, tasks).sum()
+    stored = TR.StoreTimeHitResponse(TR.UniformValueResponse())
+    tracer = TT.VolumePhotonTracer(int(budget), light, target, photons, stored, rng, medium=store.media["homogenous"],
+                                   nScatteringPerRun=5, nRuns=40, maxTime=float("inf"), polarized=polarized,
+                                   callback=TT.EventStatisticCallback())
     pl.runPipeline(tracer.collectStages())
-    hits = response.result(0)
-    assert hits is not None
-    if mu_a != 0.0:
-        assert np.abs(hits.count - exp_hits) < 5.0 * np.sqrt(exp_hits)
-    else:
-        # no absorption means we should recover all photons
-        assert hits.count == int(budget)
+    assert stored.result(0) is not None
+    assert_photon_count(stored.result(0).count, expected, budget, mu_a)
