@@ -37,6 +37,21 @@ THX_DEV f3 ld3(const float* p) { return f3{p[0], p[1], p[2]}; }
 // which also tick the LDS counter and are waited for together with every LDS access.
 #define THX_GLOBAL __attribute__((address_space(1)))
 THX_DEV f3 ld3(const THX_GLOBAL float* p) { return f3{p[0], p[1], p[2]}; }
+// Parameter blocks that only rare code paths read (plane guides, host / cone light sources, function
+// wavelengths) are read through a laundered constant-address-space pointer: the scalar loads then
+// stay inside the branch that needs them. Left to itself the compiler hoists every kernel-argument
+// load to the top of the staged kernel, where the values live in SGPRs for its whole run -- the
+// kernel is at the SGPR limit, so each extra block spilled (measured: +100 SGPR spills, 36 B of
+// scratch per lane, config 2 +3 %).
+#define THX_KERNARG __attribute__((address_space(4)))
+// start of the kernel-argument segment = the kernel's first parameter (every kernel here takes its
+// LaunchArgs first), laundered so that loads through it are not hoisted out of the calling branch
+THX_DEV const THX_KERNARG unsigned char* coldKernarg() {
+    const THX_KERNARG unsigned char* p = (const THX_KERNARG unsigned char*)__builtin_amdgcn_kernarg_segment_ptr();
+    asm volatile("" : "+s"(p));
+    return p;
+}
+THX_DEV f3 ld3(const THX_KERNARG float* p) { return f3{p[0], p[1], p[2]}; }
 THX_DEV f3 operator+(f3 a, f3 b) { return f3{a.x + b.x, a.y + b.y, a.z + b.z}; }
 THX_DEV f3 operator-(f3 a, f3 b) { return f3{a.x - b.x, a.y - b.y, a.z - b.z}; }
 THX_DEV f3 operator-(f3 a) { return f3{-a.x, -a.y, -a.z}; }

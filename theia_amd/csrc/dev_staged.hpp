@@ -483,6 +483,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
 #endif
 
+        // Only the walk keeps its parameters in SGPRs for the whole kernel; the shading stages read theirs
+        // again from the kernel-argument segment when they start (a few scalar loads per 64 photons).
+        // Otherwise every parameter any stage uses is live across the scheduler loop and the SGPR file
+        // overflows into v_writelane / v_readlane pairs inside the walk.
+        L.a = stage == S_T0 ? &args : coldArgsPtr();
         bool doA = false, doBM = false, doM = false; // lanes that run the A / BM / M part after the stage body
         Ray rayA;
         Meta mA{0u, 0u, 0u, 0.0f};

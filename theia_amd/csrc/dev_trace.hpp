@@ -57,6 +57,12 @@ struct LaunchArgs {
     SceneView scene;
 };
 
+// the kernel's LaunchArgs as seen through the laundered kernel-argument pointer (dev_core.hpp)
+THX_DEV const THX_KERNARG LaunchArgs& coldArgs() { return *reinterpret_cast<const THX_KERNARG LaunchArgs*>(coldKernarg()); }
+// the same as a plain pointer (the compiler still sees the constant address space behind the cast and
+// emits scalar loads): what Lane::a points to while a stage runs whose parameters need not stay in SGPRs
+THX_DEV const LaunchArgs* coldArgsPtr() { return (const LaunchArgs*)reinterpret_cast<const THX_KERNARG LaunchArgs*>(coldKernarg()); }
+
 // Dynamic LDS of a tracing workgroup: [n_bins floats, padded to 16 B][per-wave
 // traversal stacks: stack_depth x 64 words each]. Accessed through the
 // __shared__ symbol so that the compiler keeps the LDS address space (ds_*).
@@ -365,15 +371,17 @@ struct SourceRay {
 // queue: the reference's idx is the position in the batch)
 template <class V>
 THX_DEV WavelengthSample sampleWavelength(Lane<V>& L) {
-    const thx_run_params& P = L.a->p;
+    const THX_KERNARG thx_run_params& P = coldArgs().p; // birth happens once per photon: nothing of it needs to stay in SGPRs
     const uint32_t flags = L.a->flags;
     if (flags & THX_FLAG_WAVELENGTH_HOST) {
-        const float* q = L.a->wavelength_queue + L.local;
-        return WavelengthSample{q[0], q[L.a->wavelength_capacity]};
+        const THX_KERNARG LaunchArgs& cold = coldArgs();
+        const float* q = cold.wavelength_queue + L.local;
+        return WavelengthSample{q[0], q[cold.wavelength_capacity]};
     }
     if (flags & THX_FLAG_WAVELENGTH_FUNCTION) {
-        const uint64_t table = (uint64_t)P.wavelength.table[0] | ((uint64_t)P.wavelength.table[1] << 32);
-        return WavelengthSample{lookUp(table, draw(L), 0.0f, L.cnt), P.wavelength.p2};
+        const THX_KERNARG thx_wavelength_params& w = P.wavelength;
+        const uint64_t table = (uint64_t)w.table[0] | ((uint64_t)w.table[1] << 32);
+        return WavelengthSample{lookUp(table, draw(L), 0.0f, L.cnt), w.p2};
     }
     if (flags & THX_FLAG_WAVELENGTH_UNIFORM) {
         float u = draw(L);
@@ -398,11 +406,12 @@ THX_DEV SourceRay sourceRay(f3 position, f3 direction, float startTime, float co
 // lightsource.pencil.glsl:18-35, lightsource.spherical.glsl:16-34
 template <class V>
 THX_DEV SourceRay sampleLight(Lane<V>& L) {
-    const thx_run_params& P = L.a->p;
+    const THX_KERNARG thx_run_params& P = coldArgs().p; // birth happens once per photon: nothing of it needs to stay in SGPRs
     const uint32_t flags = L.a->flags;
     if (flags & THX_FLAG_LIGHT_HOST) {
-        const float* q = L.a->light_queue + L.local;
-        const size_t cap = L.a->light_capacity;
+        const THX_KERNARG LaunchArgs& cold = coldArgs();
+        const float* q = cold.light_queue + L.local;
+        const size_t cap = cold.light_capacity;
         const f3 pos{q[0], q[cap], q[2 * cap]};
         const f3 dir{q[3 * cap], q[4 * cap], q[5 * cap]};
         if (flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) {
@@ -419,22 +428,23 @@ THX_DEV SourceRay sampleLight(Lane<V>& L) {
         return sourceRay<V>(pos, dir, q[6 * cap], q[7 * cap]);
     }
     if (flags & THX_FLAG_LIGHT_CONE) {
+        const THX_KERNARG thx_light_params& light = P.light;
         float u0 = draw(L);
         float u1 = draw(L);
         float phi = TWO_PI * u0;
-        float cos_theta = (1.0f - u1) + P.light.cosOpeningAngle * u1;
+        float cos_theta = (1.0f - u1) + light.cosOpeningAngle * u1;
         float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
         f3 localDir{sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta};
-        m3 trafo = createLocalCOSY(normalize(ld3(P.light.direction)));
+        m3 trafo = createLocalCOSY(normalize(ld3(light.direction)));
         f3 rayDir = mul(trafo, localDir);
         float v = draw(L);
-        SourceRay r = sourceRay<V>(ld3(P.light.position), rayDir, mixf(P.light.t_min, P.light.t_max, v), P.light.contribFwd);
+        SourceRay r = sourceRay<V>(ld3(light.position), rayDir, mixf(light.t_min, light.t_max, v), light.contribFwd);
         if constexpr (V::POL) {
             if (flags & THX_FLAG_LIGHT_POLARIZED) {
-                f3 polRef = ld3(P.light.polRef);
+                f3 polRef = ld3(light.polRef);
                 polRef = polRef - rayDir * dot(polRef, rayDir);
                 r.polRef = normalize(polRef);
-                r.stokes = f4{P.light.stokes[0], P.light.stokes[1], P.light.stokes[2], P.light.stokes[3]};
+                r.stokes = f4{light.stokes[0], light.stokes[1], light.stokes[2], light.stokes[3]};
             }
         }
         return r;
@@ -576,6 +586,9 @@ THX_DEV f3 sampleUnitDisk(float u0, float u1) {
     return f3{r * thx_cos(phi), r * thx_sin(phi), 0.0f};
 }
 THX_DEV m3 ldm3(const float* m) { // column major
+    return m3{f3{m[0], m[1], m[2]}, f3{m[3], m[4], m[5]}, f3{m[6], m[7], m[8]}};
+}
+THX_DEV m3 ldm3(const THX_KERNARG float* m) {
     return m3{f3{m[0], m[1], m[2]}, f3{m[3], m[4], m[5]}, f3{m[6], m[7], m[8]}};
 }
 THX_DEV float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
@@ -1353,7 +1366,8 @@ THX_DEV GuideSample guideSampleFromDir(f3 dir, float dist, f3 targetNrm, float t
 }
 THX_DEV bool guideIsPlane(uint32_t flags) { return (flags & (THX_FLAG_GUIDE_DISK | THX_FLAG_GUIDE_FLAT)) != 0u; }
 // target_guide.disk.glsl:25-44 / target_guide.flat.glsl:31-48
-THX_DEV GuideSample evalGuidePlane(const thx_guide_params& g, f3 observer, f3 direction, bool disk) {
+THX_DEV GuideSample evalGuidePlane(f3 observer, f3 direction, bool disk) {
+    const THX_KERNARG thx_guide_params& g = coldArgs().p.guide;
     const m3 w2o = transpose(ldm3(g.objToWorld));
     f3 localObs = mul(w2o, observer - ld3(g.position));
     f3 localDir = mul(w2o, direction);
@@ -1368,8 +1382,8 @@ THX_DEV GuideSample evalGuidePlane(const thx_guide_params& g, f3 observer, f3 di
 // target_guide.sphere.glsl:15-51; target_guide.disk.glsl:15-23 / target_guide.flat.glsl:17-29
 template <class V>
 THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
-    const thx_guide_params& g = L.a->p.guide;
     if (guideIsPlane(L.a->flags)) {
+        const THX_KERNARG thx_guide_params& g = coldArgs().p.guide;
         float u0 = draw(L);
         float u1 = draw(L);
         f3 localPos = (L.a->flags & THX_FLAG_GUIDE_DISK) ? sampleUnitDisk(u0, u1) * g.radius
@@ -1377,6 +1391,7 @@ THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
         f3 pos = mul(ldm3(g.objToWorld), localPos) + ld3(g.position);
         return guideSampleFromPoint(observer, pos, ld3(g.normal), g.prob);
     }
+    const thx_guide_params& g = L.a->p.guide;
     float d, cosMin, prob;
     f3 viewDir;
     guideCone(g, observer, d, viewDir, cosMin, prob);
@@ -1392,7 +1407,7 @@ THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
 }
 // target_guide.sphere.glsl:53-81
 THX_DEV GuideSample evalTargetGuide(const thx_guide_params& g, f3 observer, f3 direction, uint32_t flags) {
-    if (guideIsPlane(flags)) return evalGuidePlane(g, observer, direction, (flags & THX_FLAG_GUIDE_DISK) != 0u);
+    if (guideIsPlane(flags)) return evalGuidePlane(observer, direction, (flags & THX_FLAG_GUIDE_DISK) != 0u);
     float d, cosMin, prob;
     f3 viewDir;
     guideCone(g, observer, d, viewDir, cosMin, prob);
