@@ -313,3 +313,24 @@ def test_host_fed_tracer_hip_matches_oracle(polarized):
     # change of a scattering angle that long paths amplify
     assert np.isclose(a["contrib"][close], b["contrib"][idx][close], rtol=2e-3, atol=1e-7).mean() > 0.995
     assert np.isclose(a["position"][close], b["position"][idx][close], atol=2e-3).all(-1).mean() > 0.995
+
+
+def test_sampler_count_cannot_exceed_its_capacity(backend):
+    sampler = TL.LightSampler(TL.PencilLightSource(), TL.ConstWavelengthSource(), 256, rng=PhiloxRNG(key=1))
+    sampler.setParams(count=257)
+    with pytest.raises(ValueError):
+        pl.runPipeline(sampler.collectStages())
+
+
+@pytest.mark.gpu
+def test_batch_larger_than_the_host_queue_fails_loudly():
+    """a tracer may be larger than the host source feeding it, a batch may not"""
+    from theia_amd import _backend, _capi
+
+    prev, _backend._backend = _backend._backend, _backend.HipBackend()
+    try:
+        tracer, _recorder, _store = _volume_tracer(512, TL.HostLightSource(256), TL.HostWavelengthSource(512), False)
+        with pytest.raises(_capi.ThxError):
+            pl.runPipeline(tracer.collectStages())
+    finally:
+        _backend._backend = prev
