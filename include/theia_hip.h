@@ -185,6 +185,9 @@ enum {
     THX_FLAG_TARGET_FLAT           = 1u << 21, /* volume tracer: FlatTarget (target.flat.glsl) */
     THX_FLAG_GUIDE_DISK            = 1u << 22, /* scene tracer: DiskTargetGuide (target_guide.disk.glsl), else sphere */
     THX_FLAG_GUIDE_FLAT            = 1u << 23, /* scene tracer: FlatTargetGuide (target_guide.flat.glsl) */
+    THX_FLAG_RNG_SOBOL             = 1u << 24, /* SobolQRNG (random.py:285-352, random.sobol.glsl) instead of PhiloxRNG;
+                                                  its seed travels in thx_philox_params.key[0] (`offset` is unused
+                                                  by the reference's shader as well) */
     THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
                                                   absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;
@@ -356,6 +359,11 @@ int thx_probe_target(thx_ctx* ctx, const thx_philox_params* philox, uint32_t fla
                      const float box_min[3], const float box_max[3], uint32_t n, float* target_out);
 int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flags, const thx_guide_params* guide,
                     const float box_min[3], const float box_max[3], uint32_t n, float* guide_out);
+
+/* RNGBufferSink over a SobolQRNG (random.sink.glsl with random.sobol.glsl): out[stream][sample] =
+ * random_s(base_stream + stream, first_dim + sample); sample_dim 2: out[stream][sample][2] = random2D_s */
+int thx_rng_fill_sobol(thx_ctx* ctx, uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim,
+                       uint32_t n_samples, uint32_t sample_dim, float* out_f32);
 
 #ifdef __cplusplus
 }

@@ -37,6 +37,7 @@ FLAG_TARGET_DISK = 1 << 20
 FLAG_TARGET_FLAT = 1 << 21
 FLAG_GUIDE_DISK = 1 << 22
 FLAG_GUIDE_FLAT = 1 << 23
+FLAG_RNG_SOBOL = 1 << 24
 TRACK_WORDS = 20
 N_STATS = 20
 
@@ -255,6 +256,17 @@ def trace_volume(common: Common, trace: VolumeTraceParams, target: TargetParams,
     if rc != 0:
         raise RuntimeError(f"orc_trace_volume failed: {rc}")
     return hist, stats, tr
+
+
+def sobol_fill(seed: int, base_stream: int, n_streams: int, first_dim: int, n_samples: int, sample_dim: int = 1) -> np.ndarray:
+    """RNGBufferSink over a SobolQRNG"""
+    fn = lib().orc_sobol_fill
+    fn.argtypes = [C.c_uint32] * 6 + [C.c_void_p]
+    fn.restype = None
+    shape = (int(n_streams), int(n_samples)) if sample_dim == 1 else (int(n_streams), int(n_samples), 2)
+    out = np.zeros(shape, dtype=np.float32)
+    fn(int(seed) & 0xFFFFFFFF, int(base_stream), int(n_streams), int(first_dim), int(n_samples), int(sample_dim), out.ctypes.data)
+    return out
 
 
 def probe_target(philox: PhiloxParams, flags: int, target: TargetParams, box_min, box_max, n: int) -> np.ndarray:

@@ -319,10 +319,68 @@ static inline uint64_t rayMedium(const Ctx* x, const Ray* r) {
     return x->use_global_medium ? x->global_medium : r->medium;
 }
 
+/* ---- random.sobol.glsl: shuffled, Owen-scrambled Sobol sampler (Burley 2020), padded to higher
+ * dimensions: every draw re-scrambles the stream index with a seed derived from the dimension ---- */
+static inline uint32_t bitrev32(uint32_t v) {
+    v = ((v >> 1) & 0x55555555u) | ((v & 0x55555555u) << 1);
+    v = ((v >> 2) & 0x33333333u) | ((v & 0x33333333u) << 2);
+    v = ((v >> 4) & 0x0F0F0F0Fu) | ((v & 0x0F0F0F0Fu) << 4);
+    v = ((v >> 8) & 0x00FF00FFu) | ((v & 0x00FF00FFu) << 8);
+    return (v >> 16) | (v << 16);
+}
+/* :92-103 */
+static inline uint32_t hp_mix32(uint32_t n) {
+    n ^= n >> 16; n *= 0x21F0AAADu; n ^= n >> 15; n *= 0xD35A2D97u; n ^= n >> 15;
+    return n ^ 0xE6FE3BEBu;
+}
+/* :111-119 */
+static inline uint32_t lk_hash(uint32_t n, uint32_t seed) {
+    n ^= n * 0x3D20ADEAu; n += seed; n *= (seed >> 16) | 1u; n ^= n * 0x05526C56u; n ^= n * 0x53A22864u;
+    return n;
+}
+/* :122-124 */
+static inline uint32_t combineHash(uint32_t seed, uint32_t v) { return seed ^ (v + 0x9E3779B9u + (seed << 6) + (seed >> 2)); }
+/* :129-148; the direction numbers of dimension 1 (the table at :34-43) obey v[k+1] = v[k] ^ (v[k] >> 1) */
+static inline uint32_t sobolBits(uint32_t index, uint32_t dim) {
+    if (dim == 0) return bitrev32(index);
+    uint32_t result = 0, v = 0x80000000u;
+    for (; index != 0; index >>= 1, v ^= v >> 1)
+        if (index & 1u) result ^= v;
+    return result;
+}
+/* :150-155 */
+static inline uint32_t nestedScramble(uint32_t v, uint32_t seed) { return bitrev32(lk_hash(bitrev32(v), seed)); }
+/* :156-161 */
+static inline float scrambledSobol(uint32_t scrambled_index, uint32_t dim, uint32_t seed) {
+    return normalizeUint(nestedScramble(sobolBits(scrambled_index, dim), combineHash(seed, dim)));
+}
+
+/* random(idx, dim): random.philox.glsl:84-94, or with ORC_FLAG_RNG_SOBOL random.sobol.glsl:165-176 (the
+ * seed travels in philox.key[0]) */
 static inline float rnd(Ctx* x, uint32_t idx, uint32_t* dim) {
-    float r = normalizeUint(random_u32(&x->c->philox, idx, *dim));
+    float r;
+    if (x->c->flags & ORC_FLAG_RNG_SOBOL) {
+        uint32_t seed = combineHash(x->c->philox.key[0], hp_mix32(*dim));
+        r = scrambledSobol(nestedScramble(idx, seed), 0, seed);
+    } else {
+        r = normalizeUint(random_u32(&x->c->philox, idx, *dim));
+    }
     *dim += 1;
     return r;
+}
+/* random2D(idx, dim): two consecutive Philox draws (random.philox.glsl:79-82, 96-100), or the first two
+ * Sobol dimensions at one scrambled index (random.sobol.glsl:178-193) */
+static inline void rnd2(Ctx* x, uint32_t idx, uint32_t* dim, float* u0, float* u1) {
+    if (x->c->flags & ORC_FLAG_RNG_SOBOL) {
+        uint32_t seed = combineHash(x->c->philox.key[0], hp_mix32(*dim));
+        uint32_t index = nestedScramble(idx, seed);
+        *u0 = scrambledSobol(index, 0, seed);
+        *u1 = scrambledSobol(index, 1, seed);
+        *dim += 2;
+        return;
+    }
+    *u0 = rnd(x, idx, dim);
+    *u1 = rnd(x, idx, dim);
 }
 
 /* ray.glsl:136-143 */
@@ -848,8 +906,8 @@ static SourceRay sampleLight(Ctx* x, uint32_t idx, uint32_t item, uint32_t* dim)
         return unpolarizedSourceRay(x, pos, dir, q[6 * cap], q[7 * cap]);
     }
     if (c->flags & ORC_FLAG_LIGHT_CONE) {
-        float u0 = rnd(x, idx, dim);
-        float u1 = rnd(x, idx, dim);
+        float u0, u1;
+        rnd2(x, idx, dim, &u0, &u1); /* random2D */
         float phi = TWO_PI_F * u0;
         float cos_theta = (1.0f - u1) + c->light.cosOpeningAngle * u1;
         float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
@@ -876,8 +934,8 @@ static SourceRay sampleLight(Ctx* x, uint32_t idx, uint32_t item, uint32_t* dim)
                                   stokes, V3(c->light.polRef[0], c->light.polRef[1], c->light.polRef[2]),
                                   f_mix(c->light.t_min, c->light.t_max, v), c->light.contribFwd);
     }
-    float u0 = rnd(x, idx, dim);
-    float u1 = rnd(x, idx, dim);
+    float u0, u1;
+    rnd2(x, idx, dim, &u0, &u1); /* random2D */
     vec3 rayDir = sphericalToCartessian(TWO_PI_F * u0, 2.0f * u1 - 1.0f);
     float v = rnd(x, idx, dim);
     return unpolarizedSourceRay(x, lightPos, rayDir, f_mix(c->light.t_min, c->light.t_max, v), c->light.contribFwd);
@@ -1030,8 +1088,8 @@ static float f_sign(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f
 
 /* target.disk.glsl:15-41 / target.flat.glsl:17-45 */
 static TargetSample sampleTargetPlane(Ctx* x, const orc_target_params* tp, vec3 observer, uint32_t idx, uint32_t* dim) {
-    float u0 = rnd(x, idx, dim);
-    float u1 = rnd(x, idx, dim);
+    float u0, u1;
+    rnd2(x, idx, dim, &u0, &u1); /* random2D */
     vec3 localPos = g_target_flat == 1 ? v_scale(sampleUnitDisk(u0, u1), tp->radius)
                                        : V3(tp->width * (u0 - 0.5f), tp->height * (u1 - 0.5f), 0.0f);
     mat3 o2w = targetObjToWorld(tp->objToWorld);
@@ -1134,8 +1192,8 @@ static TargetSample sampleTarget(Ctx* x, const orc_target_params* tp, vec3 obser
     if (g_target_flat) return sampleTargetPlane(x, tp, observer, idx, dim);
     vec3 center = V3(tp->position[0], tp->position[1], tp->position[2]);
     if (g_target_inner) { /* target.sphere.inner.glsl:18-34: uniform over the sphere */
-        float v0 = rnd(x, idx, dim);
-        float v1 = rnd(x, idx, dim);
+        float v0, v1;
+        rnd2(x, idx, dim, &v0, &v1); /* random2D */
         vec3 normal = sphericalToCartessian(TWO_PI_F * v0, 2.0f * v1 - 1.0f); /* util.sample.glsl:84-88 */
         vec3 pos = v_add(v_scale(normal, tp->radius), center);
         TargetSample s;
@@ -1150,8 +1208,8 @@ static TargetSample sampleTarget(Ctx* x, const orc_target_params* tp, vec3 obser
     vec3 dir = v_normalize(v_sub(observer, center));
     float d = v_distance(observer, center);
     float cosOpening = tp->radius / d;
-    float u0 = rnd(x, idx, dim);
-    float u1 = rnd(x, idx, dim);
+    float u0, u1;
+    rnd2(x, idx, dim, &u0, &u1); /* random2D */
     /* util.sample.glsl:23-27 sampleDirectionCone */
     float phi = TWO_PI_F * u0;
     float cos_theta = (1.0f - u1) + cosOpening * u1;
@@ -1199,8 +1257,8 @@ static void vol_sampleTargetMIS(Ctx* x, const orc_volume_trace_params* tp,
     uint64_t med = x->global_medium;
     vec3 obs = ray->position, dir = ray->direction;
     float pPP;
-    float u0 = rnd(x, idx, dim);
-    float u1 = rnd(x, idx, dim);
+    float u0, u1;
+    rnd2(x, idx, dim, &u0, &u1); /* random2D */
     vec3 dirPhase = scatter(med, dir, u0, u1, &pPP, &x->cnt);
     TargetSample phaseHit = intersectTarget(tg, obs, dirPhase);
     TargetSample targetHit = sampleTarget(x, tg, obs, idx, dim);
@@ -1275,8 +1333,8 @@ static void vol_photonMain(Ctx* x, const orc_volume_trace_params* tp, const orc_
                 result = RESULT_CODE_RAY_SCATTERED;
             }
         }
-        float u0 = rnd(x, idx, &dim);
-        float u1 = rnd(x, idx, &dim);
+        float u0, u1;
+        rnd2(x, idx, &dim, &u0, &u1); /* random2D */
         scatterRay(x, &ray, u0, u1);
         if (result >= 0) {
             if (x->polarized) {
@@ -1325,8 +1383,8 @@ static void vol_traceMain(Ctx* x, const orc_volume_trace_params* tp, const orc_t
     onEvent(x, &ray, result, local_idx, 1, dim);
     if (result < 0) return;
     for (uint32_t i = 0; i < c->path_length; ++i) {
-        float u0 = rnd(x, idx, &dim);
-        float u1 = rnd(x, idx, &dim);
+        float u0, u1;
+        rnd2(x, idx, &dim, &u0, &u1); /* random2D */
         scatterRay(x, &ray, u0, u1);
         result = vol_trace(x, tp, tg, &ray, idx, &dim, ALLOW_RESPONSE);
         onEvent(x, &ray, result, local_idx, i + 2, dim);
@@ -1850,8 +1908,8 @@ static GuideSample guideSampleFromDir(vec3 dir, float dist, vec3 targetNrm, floa
 }
 /* target_guide.disk.glsl:15-23 / target_guide.flat.glsl:17-29 */
 static GuideSample sampleGuidePlane(Ctx* x, const orc_guide_params* g, vec3 observer, uint32_t idx, uint32_t* dim) {
-    float u0 = rnd(x, idx, dim);
-    float u1 = rnd(x, idx, dim);
+    float u0, u1;
+    rnd2(x, idx, dim, &u0, &u1); /* random2D */
     vec3 localPos = g_guide_flat == 1 ? v_scale(sampleUnitDisk(u0, u1), g->radius)
                                       : V3(g->width * (u0 - 0.5f), g->height * (u1 - 0.5f), 0.0f);
     vec3 pos = v_add(m3_mul(targetObjToWorld(g->objToWorld), localPos), V3(g->position[0], g->position[1], g->position[2]));
@@ -2015,8 +2073,8 @@ static void scn_sampleTargetMIS(Ctx* x, const SceneArgs* a, const Ray* ray, uint
     uint64_t med = ray->medium;
     vec3 obs = ray->position, dir = ray->direction;
     float pPP;
-    float u0 = rnd(x, idx, dim);
-    float u1 = rnd(x, idx, dim);
+    float u0, u1;
+    rnd2(x, idx, dim, &u0, &u1); /* random2D */
     vec3 dirPhase = scatter(med, dir, u0, u1, &pPP, &x->cnt);
     GuideSample targetSample = sampleTargetGuide(x, a->guide, obs, idx, dim);
     float pTT = targetSample.prob;
@@ -2069,8 +2127,8 @@ static int processInteraction(Ctx* x, const SceneArgs* a, Ray* ray, const Surfac
     if (hit->valid) return processHit(x, a, ray, hit, idx, dim, allowResponse);
     if (!last) {
         if (!(x->c->flags & ORC_FLAG_DISABLE_MIS)) scn_sampleTargetMIS(x, a, ray, idx, dim);
-        float u0 = rnd(x, idx, dim);
-        float u1 = rnd(x, idx, dim);
+        float u0, u1;
+        rnd2(x, idx, dim, &u0, &u1); /* random2D */
         scatterRay(x, ray, u0, u1);
     }
     return RESULT_CODE_RAY_SCATTERED;
@@ -2232,6 +2290,24 @@ int orc_replay(const orc_common* c, const uint32_t* queue, uint32_t capacity, in
     return run_blocks(c, &x, replay_item, &a, n_threads, hist_out, stats, NULL, 0);
 }
 
+void orc_sobol_fill(uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim, uint32_t n_samples,
+                    uint32_t sample_dim, float* out) {
+    orc_common c;
+    memset(&c, 0, sizeof(c));
+    c.flags = ORC_FLAG_RNG_SOBOL;
+    c.philox.key[0] = seed;
+    Ctx x;
+    memset(&x, 0, sizeof(x));
+    x.c = &c;
+    for (uint32_t st = 0; st < n_streams; ++st)
+        for (uint32_t k = 0; k < n_samples; ++k) {
+            uint32_t dim = first_dim + k; /* random_s / random2D_s: the sink addresses every sample itself */
+            size_t at = (size_t)st * n_samples + k;
+            if (sample_dim == 2) rnd2(&x, base_stream + st, &dim, &out[2 * at], &out[2 * at + 1]);
+            else out[at] = rnd(&x, base_stream + st, &dim);
+        }
+}
+
 /* target.sample.glsl:19-83 */
 static void putSample(float* o, vec3 observer, const TargetSample* ts, int checkDir, vec3 direction) {
     mat3 m = ts->worldToObj;
@@ -2257,7 +2333,8 @@ static void putSample(float* o, vec3 observer, const TargetSample* ts, int check
 static void probeObserver(Ctx* x, uint32_t i, uint32_t* dim, const float lo[3], const float hi[3], vec3* observer, vec3* direction) {
     float a = rnd(x, i, dim), b = rnd(x, i, dim), c = rnd(x, i, dim);
     *observer = V3(f_mix(lo[0], hi[0], a), f_mix(lo[1], hi[1], b), f_mix(lo[2], hi[2], c));
-    float u0 = rnd(x, i, dim), u1 = rnd(x, i, dim);
+    float u0, u1;
+    rnd2(x, i, dim, &u0, &u1);
     *direction = sphericalToCartessian(TWO_PI_F * u0, 2.0f * u1 - 1.0f); /* util.sample.glsl:84-88 */
 }
 void orc_probe_target(const orc_philox_params* philox, uint32_t flags, const orc_target_params* target,
@@ -2265,6 +2342,7 @@ void orc_probe_target(const orc_philox_params* philox, uint32_t flags, const orc
     orc_common c;
     memset(&c, 0, sizeof(c));
     c.philox = *philox;
+    c.flags = flags & ORC_FLAG_RNG_SOBOL;
     Ctx x;
     memset(&x, 0, sizeof(x));
     x.c = &c;
@@ -2291,6 +2369,7 @@ void orc_probe_guide(const orc_philox_params* philox, uint32_t flags, const orc_
     orc_common c;
     memset(&c, 0, sizeof(c));
     c.philox = *philox;
+    c.flags = flags & ORC_FLAG_RNG_SOBOL;
     Ctx x;
     memset(&x, 0, sizeof(x));
     x.c = &c;

@@ -113,7 +113,8 @@ class OracleBackend:
         flags = (spec.flags & 0x7F) | (spec.flags & (capi.FLAG_LIGHT_PENCIL | capi.FLAG_TARGET_INNER | capi.FLAG_KERNEL_HISTOGRAM |
                                                      capi.FLAG_LIGHT_HOST | capi.FLAG_LIGHT_QUEUE_POLARIZED | capi.FLAG_WAVELENGTH_HOST |
                                                      capi.FLAG_LIGHT_CONE | capi.FLAG_LIGHT_POLARIZED | capi.FLAG_WAVELENGTH_FUNCTION |
-                                                     capi.FLAG_TARGET_DISK | capi.FLAG_TARGET_FLAT | capi.FLAG_GUIDE_DISK | capi.FLAG_GUIDE_FLAT))
+                                                     capi.FLAG_TARGET_DISK | capi.FLAG_TARGET_FLAT | capi.FLAG_GUIDE_DISK | capi.FLAG_GUIDE_FLAT |
+                                                     capi.FLAG_RNG_SOBOL))
         photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE
@@ -158,6 +159,9 @@ class OracleBackend:
         t.raw[cfg] = hist
         t.stats += stats
         t.track = track
+
+    def rng_fill_sobol(self, seed, base_stream, n_streams, first_dim, n_samples, sample_dim=1):
+        return orc.sobol_fill(seed, base_stream, n_streams, first_dim, n_samples, sample_dim)
 
     def probe_target(self, philox, flags, target, box_min, box_max, n):
         ph, tg = orc.PhiloxParams(), orc.TargetParams()

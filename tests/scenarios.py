@@ -89,7 +89,7 @@ class Scenario:
 
 
 def config1_volume(batch: int = 100_000, *, polarized: bool = False, stats: bool = False, track: bool = False,
-                   disableTargetSampling: bool = False, disableDirectLighting: bool = False, key: int = 42) -> Scenario:
+                   disableTargetSampling: bool = False, disableDirectLighting: bool = False, key: int = 42, rng=None) -> Scenario:
     """BASELINE config 1 = example 01: VolumeForwardTracer in a homogeneous HG medium."""
     model = HomogeneousModel(n=1.33, mu_a=0.05 / u.m, mu_s=0.02 / u.m, g=0.2)
     medium = model.createMedium()
@@ -98,20 +98,21 @@ def config1_volume(batch: int = 100_000, *, polarized: bool = False, stats: bool
     light = SphericalLightSource(position=(1.0, 0.0, 0.0) * u.m, timeRange=(0.0, 10.0) * u.ns, budget=1.0e5)
     target = SphereTarget(position=(-1.0, 0.0, 0.0) * u.m, radius=50.0 * u.cm)
     response = HistogramHitResponse(UniformValueResponse(), nBins=100, binSize=5.0 * u.ns)
-    rng = PhiloxRNG(key=key)
+    rng = PhiloxRNG(key=key) if rng is None else rng
     callback = EventStatisticCallback() if stats else EmptyEventCallback()
     tracer = VolumeForwardTracer(batch, light, target, wavelength, response, rng, scatterCoefficient=0.05 / u.m,
                                  nScattering=10, medium=store.media["homogenous"], polarized=polarized, callback=callback,
                                  disableTargetSampling=disableTargetSampling, disableDirectLighting=disableDirectLighting,
                                  trackEvents=track)
-    rng.autoAdvance = tracer.nRNGSamples
+    if isinstance(rng, PhiloxRNG):
+        rng.autoAdvance = tracer.nRNGSamples
     return Scenario(name="config1_volume", store=store, light=light, target=target, wavelength=wavelength,
                     response=response, rng=rng, tracer=tracer, callback=callback, medium=medium)
 
 
 def config2_sphere(batch: int = 1 << 20, *, polarized: bool = False, stats: bool = False, track: bool = False,
                    guide: bool = True, mu_a: float = 0.05, mu_s: float = 0.005, g: float = 0.5,
-                   maxPathLength: int = 10, key: int = 0xC0FFEE, subdivide: int = 0, custom_guide=None) -> Scenario:
+                   maxPathLength: int = 10, key: int = 0xC0FFEE, subdivide: int = 0, custom_guide=None, rng=None) -> Scenario:
     """BASELINE config 2 = sphere-in-medium (reference tests/test_trace_energy.py:187-337,
     Crosscheck geometry): detector sphere r=5 m at the origin, light 6 m away."""
     model = EnergyTestModel(mu_a, mu_s, g)
@@ -127,13 +128,14 @@ def config2_sphere(batch: int = 1 << 20, *, polarized: bool = False, stats: bool
     photons = UniformWavelengthSource(lambdaRange=(lam, lam))
     light = SphericalLightSource(position=(-6.0, 0.0, 0.0) * u.m, timeRange=(30.0, 30.0) * u.ns, budget=1e9)
     response = HistogramHitResponse(UniformValueResponse(), nBins=30, binSize=20.0, t0=0.0, normalization=1 / batch)
-    rng = PhiloxRNG(key=key)
+    rng = PhiloxRNG(key=key) if rng is None else rng
     tg = SphereTargetGuide(position=(0.0, 0.0, 0.0), radius=radius) if guide else custom_guide
     callback = EventStatisticCallback() if stats else EmptyEventCallback()
     tracer = SceneForwardTracer(batch, light, photons, response, rng, scene, maxPathLength=maxPathLength, targetGuide=tg,
                                 scatterCoefficient=0.01, maxTime=600.0, polarized=polarized, callback=callback,
                                 trackEvents=track)
-    rng.autoAdvance = tracer.nRNGSamples
+    if isinstance(rng, PhiloxRNG):
+        rng.autoAdvance = tracer.nRNGSamples
     return Scenario(name="config2_sphere", store=store, meshes=meshes, scene=scene, light=light, photons=photons,
                     response=response, rng=rng, guide=tg, tracer=tracer, callback=callback, medium=medium)
 

@@ -175,6 +175,14 @@ class HipBackend:
         """copies the HitRecorder queue into `out` (uint8) and resets its counter"""
         capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
 
+    def rng_fill_sobol(self, seed: int, base_stream: int, n_streams: int, first_dim: int, n_samples: int, sample_dim: int = 1) -> np.ndarray:
+        """RNGBufferSink over a SobolQRNG: float32 [streams][samples] (or [...][2] for 2-D samples)"""
+        shape = (int(n_streams), int(n_samples)) if sample_dim == 1 else (int(n_streams), int(n_samples), 2)
+        out = np.zeros(shape, dtype=np.float32)
+        capi.check(self._lib.thx_rng_fill_sobol(self._ctx, int(seed) & 0xFFFFFFFF, int(base_stream), int(n_streams), int(first_dim),
+                                                int(n_samples), int(sample_dim), out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def probe_target(self, philox: capi.PhiloxParams, flags: int, target: capi.TargetParams, box_min, box_max, n: int) -> np.ndarray:
         """theia.testing.TargetSampler: [n][25] words (include/theia_hip.h)"""
         out = np.zeros((int(n), 25), dtype=np.float32)

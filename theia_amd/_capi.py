@@ -22,7 +22,7 @@ __all__ = [
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
     "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "FLAG_KERNEL_HISTOGRAM", "EXPORTED_SYMBOLS",
     "FLAG_LIGHT_HOST", "FLAG_LIGHT_QUEUE_POLARIZED", "FLAG_WAVELENGTH_HOST", "FLAG_LIGHT_CONE", "FLAG_LIGHT_POLARIZED",
-    "FLAG_WAVELENGTH_FUNCTION", "TRACER_LIGHT_SAMPLER", "FLAG_TARGET_DISK", "FLAG_TARGET_FLAT", "FLAG_GUIDE_DISK", "FLAG_GUIDE_FLAT",
+    "FLAG_WAVELENGTH_FUNCTION", "TRACER_LIGHT_SAMPLER", "FLAG_TARGET_DISK", "FLAG_TARGET_FLAT", "FLAG_GUIDE_DISK", "FLAG_GUIDE_FLAT", "FLAG_RNG_SOBOL",
 ]
 
 TRACER_VOLUME_FORWARD = 0
@@ -55,6 +55,7 @@ FLAG_TARGET_DISK = 1 << 20
 FLAG_TARGET_FLAT = 1 << 21
 FLAG_GUIDE_DISK = 1 << 22
 FLAG_GUIDE_FLAT = 1 << 23
+FLAG_RNG_SOBOL = 1 << 24
 N_STATS = 20
 TRACK_WORDS = 20
 STAT_NAMES = (
@@ -201,6 +202,7 @@ _PROTOS = {
     "thx_tracer_kernel_times": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_uint32)]),
     "thx_probe_target": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, POINTER(TargetParams), POINTER(c_float), POINTER(c_float), c_uint32, c_void_p]),
     "thx_probe_guide": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, POINTER(GuideParams), POINTER(c_float), POINTER(c_float), c_uint32, c_void_p]),
+    "thx_rng_fill_sobol": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_float)]),
     "thx_rng_fill": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_float)]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())

@@ -842,4 +842,21 @@ int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream,
     return THX_OK;
 }
 
+int thx_rng_fill_sobol(thx_ctx* ctx, uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim,
+                       uint32_t n_samples, uint32_t sample_dim, float* out_f32) {
+    if (!ctx || !out_f32) return fail(THX_ERR_INVALID, "null argument");
+    if (sample_dim != 1 && sample_dim != 2) return fail(THX_ERR_INVALID, "sample_dim must be 1 or 2");
+    const size_t total = (size_t)n_streams * n_samples * sample_dim;
+    if (total == 0) return THX_OK;
+    THX_HIP(hipSetDevice(ctx->device));
+    float* d = nullptr;
+    THX_HIP(hipMalloc((void**)&d, 4 * total));
+    hipError_t e = launchSobolFill(seed, base_stream, n_streams, first_dim, n_samples, sample_dim, d, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = hipMemcpy(out_f32, d, 4 * total, hipMemcpyDeviceToHost);
+    (void)hipFree(d);
+    if (e != hipSuccess) return hipFail(e, "thx_rng_fill_sobol");
+    return THX_OK;
+}
+
 } // extern "C"

@@ -232,6 +232,43 @@ THX_DEV float rnd(const thx_philox_params& p, uint32_t stream, uint32_t& dim) {
     return r;
 }
 
+// random.sobol.glsl: shuffled, Owen-scrambled Sobol sampler (Burley 2020), padded to higher
+// dimensions: every draw re-scrambles the stream index with a seed derived from the dimension
+THX_DEV uint32_t hp_mix32(uint32_t n) { // :92-103
+    n ^= n >> 16; n *= 0x21F0AAADu; n ^= n >> 15; n *= 0xD35A2D97u; n ^= n >> 15;
+    return n ^ 0xE6FE3BEBu;
+}
+THX_DEV uint32_t lk_hash(uint32_t n, uint32_t seed) { // :111-119
+    n ^= n * 0x3D20ADEAu; n += seed; n *= (seed >> 16) | 1u; n ^= n * 0x05526C56u; n ^= n * 0x53A22864u;
+    return n;
+}
+THX_DEV uint32_t combineHash(uint32_t seed, uint32_t v) { return seed ^ (v + 0x9E3779B9u + (seed << 6) + (seed >> 2)); } // :122-124
+// :129-148; the direction numbers of dimension 1 (the table at :34-43) obey v[k+1] = v[k] ^ (v[k] >> 1)
+THX_DEV uint32_t sobolBits(uint32_t index, uint32_t dim) {
+    if (dim == 0) return __brev(index);
+    uint32_t result = 0, v = 0x80000000u;
+    for (; index != 0; index >>= 1, v ^= v >> 1)
+        if (index & 1u) result ^= v;
+    return result;
+}
+THX_DEV uint32_t nestedScramble(uint32_t v, uint32_t seed) { return __brev(lk_hash(__brev(v), seed)); } // :150-155
+THX_DEV float scrambledSobol(uint32_t scrambled_index, uint32_t dim, uint32_t seed) { // :156-161
+    return normalizeUint(nestedScramble(sobolBits(scrambled_index, dim), combineHash(seed, dim)));
+}
+// random.sobol.glsl:165-176 / :178-193
+THX_DEV float rndSobol(uint32_t baseSeed, uint32_t stream, uint32_t& dim) {
+    const uint32_t seed = combineHash(baseSeed, hp_mix32(dim));
+    dim += 1;
+    return scrambledSobol(nestedScramble(stream, seed), 0, seed);
+}
+THX_DEV void rndSobol2(uint32_t baseSeed, uint32_t stream, uint32_t& dim, float& u0, float& u1) {
+    const uint32_t seed = combineHash(baseSeed, hp_mix32(dim));
+    const uint32_t index = nestedScramble(stream, seed);
+    dim += 2;
+    u0 = scrambledSobol(index, 0, seed);
+    u1 = scrambledSobol(index, 1, seed);
+}
+
 // ------------------------------------------------- lookup.glsl / material.glsl
 
 struct MediumConstants {

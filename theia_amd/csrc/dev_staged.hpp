@@ -591,8 +591,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 rayA = loadRay(pool, slotA);
                 mA = loadMeta(pool, slotA);
                 bindLane(L, mA);
-                float u0 = draw(L);
-                float u1 = draw(L);
+                float u0, u1;
+                draw2(L, u0, u1); // random2D
                 scatterRay(L, rayA, rayA.medium, u0, u1);
                 doA = endStep(L, rayA, mA, RESULT_CODE_RAY_SCATTERED);
                 storeRay(pool, slotA, rayA);
@@ -669,8 +669,8 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 Meta m = loadMeta(pool, slot);
                 bindLane(L, m);
                 float pPP;
-                float u0 = draw(L);
-                float u1 = draw(L);
+                float u0, u1;
+                draw2(L, u0, u1); // random2D
                 f3 dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
                 GuideSample ts = sampleTargetGuide(L, ray.position);
                 float pTT = ts.prob;

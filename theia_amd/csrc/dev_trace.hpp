@@ -81,9 +81,23 @@ struct Lane {
     uint32_t dim;   // RNG dimension
 };
 
+// random(idx, dim) of the RNG the tracer was built with: Philox, or with THX_FLAG_RNG_SOBOL the
+// scrambled Sobol sampler (its seed travels in philox.key[0])
 template <class V>
 THX_DEV float draw(Lane<V>& L) {
+    if (L.a->flags & THX_FLAG_RNG_SOBOL) return rndSobol(L.a->p.philox.key[0], L.idx, L.dim);
     return rnd(L.a->p.philox, L.idx, L.dim);
+}
+// random2D(idx, dim): two consecutive Philox draws (random.philox.glsl:79-82), or the first two Sobol
+// dimensions at one scrambled index (random.sobol.glsl:178-193)
+template <class V>
+THX_DEV void draw2(Lane<V>& L, float& u0, float& u1) {
+    if (L.a->flags & THX_FLAG_RNG_SOBOL) {
+        rndSobol2(L.a->p.philox.key[0], L.idx, L.dim, u0, u1);
+        return;
+    }
+    u0 = rnd(L.a->p.philox, L.idx, L.dim);
+    u1 = rnd(L.a->p.philox, L.idx, L.dim);
 }
 
 // ray.glsl:136-143
@@ -429,8 +443,8 @@ THX_DEV SourceRay sampleLight(Lane<V>& L) {
     }
     if (flags & THX_FLAG_LIGHT_CONE) {
         const THX_KERNARG thx_light_params& light = P.light;
-        float u0 = draw(L);
-        float u1 = draw(L);
+        float u0, u1;
+        draw2(L, u0, u1); // random2D
         float phi = TWO_PI * u0;
         float cos_theta = (1.0f - u1) + light.cosOpeningAngle * u1;
         float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
@@ -464,8 +478,8 @@ THX_DEV SourceRay sampleLight(Lane<V>& L) {
         }
         return r;
     }
-    float u0 = draw(L);
-    float u1 = draw(L);
+    float u0, u1;
+    draw2(L, u0, u1); // random2D
     f3 rayDir = sphericalToCartessian(TWO_PI * u0, 2.0f * u1 - 1.0f);
     float v = draw(L);
     return sourceRay<V>(ld3(P.light.position), rayDir, mixf(P.light.t_min, P.light.t_max, v), P.light.contribFwd);
@@ -672,8 +686,8 @@ THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 ob
     f3 center = ld3(tp.position);
     TargetSample s;
     if (targetIsPlane(flags)) {
-        float u0 = draw(L);
-        float u1 = draw(L);
+        float u0, u1;
+        draw2(L, u0, u1); // random2D
         f3 localPos = (flags & THX_FLAG_TARGET_DISK) ? sampleUnitDisk(u0, u1) * tp.radius
                                                      : f3{tp.width * (u0 - 0.5f), tp.height * (u1 - 0.5f), 0.0f};
         const m3 o2w = ldm3(tp.objToWorld);
@@ -691,8 +705,8 @@ THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 ob
     s.offset = ld3(tp.invPos);
     s.worldToObj = diag3(tp.invRad);
     if (flags & THX_FLAG_TARGET_INNER) {
-        float v0 = draw(L);
-        float v1 = draw(L);
+        float v0, v1;
+        draw2(L, v0, v1); // random2D
         f3 normal = sphericalToCartessian(TWO_PI * v0, 2.0f * v1 - 1.0f); // util.sample.glsl:84-88
         f3 pos = normal * tp.radius + center;
         s.position = pos; s.normal = normal * -1.0f; s.dist = distance(observer, pos);
@@ -703,8 +717,8 @@ THX_DEV TargetSample sampleTarget(Lane<V>& L, const thx_target_params& tp, f3 ob
     f3 dir = normalize(observer - center);
     float d = distance(observer, center);
     float cosOpening = tp.radius / d;
-    float u0 = draw(L);
-    float u1 = draw(L);
+    float u0, u1;
+    draw2(L, u0, u1); // random2D
     float phi = TWO_PI * u0; // util.sample.glsl:23-27
     float cos_theta = (1.0f - u1) + cosOpening * u1;
     f3 normal = mul(createLocalCOSY(dir), sphericalToCartessian(phi, cos_theta));
@@ -754,8 +768,8 @@ THX_DEV void volSampleTargetMIS(Lane<V>& L, const Ray& ray, uint64_t med) {
     const thx_target_params& tg = L.a->p.target;
     f3 obs = ray.position, dir = ray.direction;
     float pPP;
-    float u0 = draw(L);
-    float u1 = draw(L);
+    float u0, u1;
+    draw2(L, u0, u1); // random2D
     f3 dirPhase = scatter(med, dir, u0, u1, pPP, L.cnt);
     TargetSample phaseHit = intersectTarget(tg, obs, dirPhase, L.a->flags);
     TargetSample targetHit = sampleTarget(L, tg, obs, L.a->flags);
@@ -818,8 +832,8 @@ THX_DEV bool volStep(Lane<V>& L, Ray& ray, uint32_t& step) {
         }
         allow = !V::MIS && !disable_direct; // DIRECT_LIGHTING, :211-215
     } else {
-        float u0 = draw(L);
-        float u1 = draw(L);
+        float u0, u1;
+        draw2(L, u0, u1); // random2D
         scatterRay(L, ray, med, u0, u1);
         allow = !V::MIS; // ALLOW_RESPONSE, :217-221
     }
@@ -876,8 +890,8 @@ THX_DEV bool volPhotonStep(Lane<V>& L, Ray& ray, uint32_t& step) {
         }
     }
     // scatter for the next iteration
-    float u0 = draw(L);
-    float u1 = draw(L);
+    float u0, u1;
+    draw2(L, u0, u1); // random2D
     scatterRay(L, ray, med, u0, u1);
     result = photonRoulette(L, ray, result);
     onEvent(L, ray, result, step);
@@ -1384,8 +1398,8 @@ template <class V>
 THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
     if (guideIsPlane(L.a->flags)) {
         const THX_KERNARG thx_guide_params& g = coldArgs().p.guide;
-        float u0 = draw(L);
-        float u1 = draw(L);
+        float u0, u1;
+        draw2(L, u0, u1); // random2D
         f3 localPos = (L.a->flags & THX_FLAG_GUIDE_DISK) ? sampleUnitDisk(u0, u1) * g.radius
                                                          : f3{g.width * (u0 - 0.5f), g.height * (u1 - 0.5f), 0.0f};
         f3 pos = mul(ldm3(g.objToWorld), localPos) + ld3(g.position);
@@ -1592,8 +1606,8 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
             if (!lastNoScatter) {
                 if constexpr (V::MIS) { // sampleTargetMIS, :234-269
                     float pPP;
-                    float u0 = draw(L);
-                    float u1 = draw(L);
+                    float u0, u1;
+                    draw2(L, u0, u1); // random2D
                     dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
                     GuideSample ts = sampleTargetGuide(L, ray.position);
                     float pTT = ts.prob;
@@ -1613,8 +1627,8 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
         }
     }
     if (scatterAfter) { // scene.traverse.glsl:391
-        float u0 = draw(L);
-        float u1 = draw(L);
+        float u0, u1;
+        draw2(L, u0, u1); // random2D
         scatterRay(L, ray, ray.medium, u0, u1);
     }
     if (photon) result = photonRoulette(L, ray, result);

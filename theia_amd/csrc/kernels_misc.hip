@@ -186,7 +186,8 @@ template <class V>
 THX_DEV void probeObserver(Lane<V>& L, const float* lo, const float* hi, f3& observer, f3& direction) {
     float a = draw(L), b = draw(L), c = draw(L);
     observer = f3{mixf(lo[0], hi[0], a), mixf(lo[1], hi[1], b), mixf(lo[2], hi[2], c)};
-    float u0 = draw(L), u1 = draw(L);
+    float u0, u1;
+    draw2(L, u0, u1);
     direction = sphericalToCartessian(TWO_PI * u0, 2.0f * u1 - 1.0f); // util.sample.glsl:84-88
 }
 // target.sample.glsl:19-47 checkSample / checkIntersect
@@ -262,6 +263,27 @@ __global__ void rngFillKernel(thx_philox_params p, uint32_t base_stream, uint32_
     uint32_t v = random_u32(p, base_stream + s, first_dim + k);
     if (out_u32) out_u32[i] = v;
     if (out_f32) out_f32[i] = normalizeUint(v);
+}
+
+__global__ void sobolFillKernel(uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim,
+                                uint32_t n_samples, uint32_t sample_dim, float* out) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    size_t total = (size_t)n_streams * n_samples;
+    if (i >= total) return;
+    uint32_t s = (uint32_t)(i / n_samples), k = (uint32_t)(i % n_samples);
+    uint32_t dim = first_dim + k; // random_s / random2D_s: the sink addresses every sample itself
+    if (sample_dim == 2) rndSobol2(seed, base_stream + s, dim, out[2 * i], out[2 * i + 1]);
+    else out[i] = rndSobol(seed, base_stream + s, dim);
+}
+
+hipError_t launchSobolFill(uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim, uint32_t n_samples,
+                           uint32_t sample_dim, float* out, hipStream_t stream) {
+    size_t total = (size_t)n_streams * n_samples;
+    uint32_t grid = (uint32_t)((total + 255) / 256);
+    if (grid == 0) return hipSuccess;
+    hipLaunchKernelGGL(sobolFillKernel, dim3(grid), dim3(256), 0, stream, seed, base_stream, n_streams, first_dim, n_samples,
+                       sample_dim, out);
+    return hipGetLastError();
 }
 
 hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,

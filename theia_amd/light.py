@@ -503,6 +503,10 @@ class LightSampler(PipelineStage):
         self._lamQueue = IOQueue(WavelengthSampleItem, capacity, mode="retrieve")
         flags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
         flags |= capi.FLAG_POLARIZED if polarized else 0
+        if rng is not None:
+            from .random import rngFlags
+
+            flags |= rngFlags(rng)
         self._program = _Program(_backend.TracerSpec(capi.TRACER_LIGHT_SAMPLER, flags, 0, batchSize, 1, capacity,
                                                      light_queue_capacity=lightCap, wavelength_queue_capacity=lamCap), None)
 
@@ -535,10 +539,9 @@ class LightSampler(PipelineStage):
         P.photon_offset = sp.baseCount
         P.volume.medium[0], P.volume.medium[1] = sp.medium.lo, sp.medium.hi
         if self._rng is not None:
-            r = self._rng._getParamsBlock("PhiloxParams", i)
-            P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
-            for k in range(4):
-                P.philox.offset[k] = r.offset.word[k]
+            from .random import fillRngParams
+
+            fillRngParams(P.philox, self._rng, i)
         fillSourceParams(P, i, self._source, self._wavelengthSource)
         return P
 

@@ -1,10 +1,11 @@
 """
-Random number generators for the tracers. Only the counter-based Philox4x32-10
-generator is on the supported path (reference: src/theia/random.py:228-282,
-shader/random.philox.glsl). The device evaluates ``random(stream, dim)`` as a
-pure function of (key + stream, offset + 4*dim)[dim & 3]; `autoAdvance` shifts
-`offset` inside every `update()` -- i.e. *before* each batch, the first one
-included (random.py:278-282).
+Random number generators for the tracers: the counter-based Philox4x32-10
+generator (reference: src/theia/random.py:228-282, shader/random.philox.glsl) and
+the scrambled Sobol sampler (random.py:285-352, shader/random.sobol.glsl). The
+device evaluates ``random(stream, dim)`` as a pure function: Philox of (key + stream,
+offset + 4*dim)[dim & 3] -- `autoAdvance` shifts `offset` inside every `update()`,
+i.e. *before* each batch, the first one included (random.py:278-282) -- or the Owen-scrambled
+Sobol point of index `stream` under a seed derived from `dim`.
 """
 from __future__ import annotations
 
@@ -17,7 +18,9 @@ import numpy as np
 from . import _backend
 from .hp.pipeline import PipelineStage, SourceCodeMixin
 
-__all__ = ["Counter", "Key", "PhiloxRNG", "RNG", "RNGBufferSink"]
+__all__ = ["Counter", "Key", "PhiloxRNG", "SobolQRNG", "RNG", "RNGBufferSink"]
+
+_SOBOL_FLAG = 1 << 24  # THX_FLAG_RNG_SOBOL
 
 
 class RNG(SourceCodeMixin):
@@ -90,6 +93,44 @@ class PhiloxRNG(RNG):
         super()._finishParams(i)
 
 
+class SobolQRNG(RNG):
+    """
+    Shuffled, Owen-scrambled Sobol sampler (Burley 2020: "Practical Hash-based Owen Scrambling"),
+    padded to higher dimensions: every draw scrambles the photon index with a seed derived from
+    the draw's dimension; a 2-D draw takes the first two Sobol dimensions at one scrambled index.
+    Parameters (also stage parameters): `seed` (32 bit), `offset` (kept for API parity: the
+    reference's shader never reads it), `advanceSeed` (seeds a host generator that draws a fresh
+    `seed` on every update; None: the seed stays). About half the arithmetic of a Philox draw.
+    """
+
+    name = "Sobol QRNG"
+
+    class SobolParams(Structure):
+        _fields_ = [("seed", c_uint32), ("offset", c_uint32)]
+
+    def __init__(self, *, seed: int | None = None, offset: int = 0, advanceSeed: int | None = None) -> None:
+        super().__init__({"SobolParams": self.SobolParams}, {"advanceSeed"})
+        if seed is None and advanceSeed is None:
+            seed = int.from_bytes(urandom(4), "big")
+            warnings.warn(f"Random RNG seed generated: 0x{seed:04X}")
+        self._hostRNG = None
+        self.setParams(seed=seed if seed is not None else 0, offset=offset, advanceSeed=advanceSeed)
+
+    @property
+    def advanceSeed(self) -> int | None:
+        return self._advanceSeed
+
+    @advanceSeed.setter
+    def advanceSeed(self, value: int | None) -> None:
+        self._advanceSeed = value
+        self._hostRNG = None if value is None else np.random.default_rng(value)
+
+    def _finishParams(self, i: int) -> None:
+        if self._hostRNG is not None:
+            self.setParam("seed", int.from_bytes(self._hostRNG.bytes(4), "big"))
+        super()._finishParams(i)
+
+
 class RNGBufferSink(PipelineStage):
     """
     Fills a host array with draws of a generator: `streams` parallel streams of
@@ -99,15 +140,21 @@ class RNGBufferSink(PipelineStage):
 
     name = "RNG Sink"
 
-    def __init__(self, generator: RNG, streams: int, samples: int, *, baseStream: int = 0, baseCount: int = 0) -> None:
+    def __init__(self, generator: RNG, streams: int, samples: int, *, baseStream: int = 0, baseCount: int = 0,
+                 sampleDim: int = 1) -> None:
         super().__init__({})
-        if not isinstance(generator, PhiloxRNG):
-            raise NotImplementedError("Only PhiloxRNG is supported by the HIP backend")
+        if not isinstance(generator, (PhiloxRNG, SobolQRNG)):
+            raise NotImplementedError("PhiloxRNG and SobolQRNG are supported by the HIP backend")
+        if sampleDim not in (1, 2):
+            raise ValueError("sampleDim must be 1 or 2")
         self._generator = generator
-        self._streams, self._samples = streams, samples
+        self._streams, self._samples, self._sampleDim = streams, samples, sampleDim
         self._baseStream, self._baseCount = baseStream, baseCount
-        self._raw = [np.zeros((streams, samples), dtype=np.uint32) for _ in range(2)]
-        self._values = [np.zeros((streams, samples), dtype=np.float32) for _ in range(2)]
+        shape = (streams, samples) if sampleDim == 1 else (streams, samples, 2)
+        self._raw = [np.zeros(shape, dtype=np.uint32) for _ in range(2)]
+        self._values = [np.zeros(shape, dtype=np.float32) for _ in range(2)]
+
+    capacity = property(lambda self: self._streams * self._samples * self._sampleDim, doc="total number of floats drawn")
 
     @property
     def generator(self) -> RNG:
@@ -123,9 +170,41 @@ class RNGBufferSink(PipelineStage):
 
     def run(self, i: int):
         def cmd() -> None:
+            if isinstance(self._generator, SobolQRNG):
+                seed = self._generator._getParamsBlock("SobolParams", i).seed
+                self._values[i][...] = _backend.get().rng_fill_sobol(seed, self._baseStream, self._streams, self._baseCount,
+                                                                     self._samples, self._sampleDim)
+                return
             block = self._generator._getParamsBlock("PhiloxParams", i)
-            u, f = _backend.get().rng_fill(block.key.value, block.offset.value, self._baseStream, self._streams, self._baseCount, self._samples)
+            n = self._samples * self._sampleDim  # random2D_s = two consecutive draws
+            first = self._baseCount if self._sampleDim == 1 else None
+            if first is None:  # pairs (k, k + 1) for every sample k, like random.sink.glsl with SAMPLE_DIM 2
+                u0, f0 = _backend.get().rng_fill(block.key.value, block.offset.value, self._baseStream, self._streams, self._baseCount, self._samples)
+                u1, f1 = _backend.get().rng_fill(block.key.value, block.offset.value, self._baseStream, self._streams, self._baseCount + 1, self._samples)
+                self._raw[i][...] = np.stack([u0, u1], axis=-1)
+                self._values[i][...] = np.stack([f0, f1], axis=-1)
+                return
+            u, f = _backend.get().rng_fill(block.key.value, block.offset.value, self._baseStream, self._streams, first, n)
             self._raw[i][...] = u
             self._values[i][...] = f
 
         return [cmd]
+
+
+def rngFlags(rng) -> int:
+    """THX_FLAG_* bit selecting the generator's kernel branch"""
+    return _SOBOL_FLAG if isinstance(rng, SobolQRNG) else 0
+
+
+def fillRngParams(dst, rng, i: int) -> None:
+    """copies the generator's parameter block of config `i` into `thx_philox_params` (a Sobol seed
+    travels in key[0])"""
+    if isinstance(rng, SobolQRNG):
+        dst.key[0], dst.key[1] = rng._getParamsBlock("SobolParams", i).seed, 0
+        for k in range(4):
+            dst.offset[k] = 0
+        return
+    r = rng._getParamsBlock("PhiloxParams", i)
+    dst.key[0], dst.key[1] = r.key.lo, r.key.hi
+    for k in range(4):
+        dst.offset[k] = r.offset.word[k]

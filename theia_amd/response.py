@@ -446,6 +446,10 @@ class HitReplay(PipelineStage):
         from . import _backend
 
         flags = capi.FLAG_POLARIZED if polarized else 0
+        if rng is not None:
+            from .random import rngFlags
+
+            flags |= rngFlags(rng)
         if isinstance(response, HitRecorder):
             spec = (1, capacity, capi.RESPONSE_RECORD, response.capacity, response.polarized)
         elif isinstance(response, StoreTimeHitResponse):
@@ -479,10 +483,9 @@ class HitReplay(PipelineStage):
         P.dispatch.groupCountX = -(self._capacity // -self._blockSize)
         P.dispatch.groupCountY = P.dispatch.groupCountZ = 1
         if self._rng is not None:
-            r = self._rng._getParamsBlock("PhiloxParams", i)
-            P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
-            for k in range(4):
-                P.philox.offset[k] = r.offset.word[k]
+            from .random import fillRngParams
+
+            fillRngParams(P.philox, self._rng, i)
         if isinstance(self._response, HistogramHitResponse):
             rp = self._response._getParamsBlock("ResponseParams", i)
             P.response.t0, P.response.binSize = rp.t0, rp.binSize

@@ -24,12 +24,17 @@ class WaterTestModel(WaterBaseModel, HenyeyGreensteinPhaseFunction, KokhanovskyO
         KokhanovskyOceanWaterPhaseMatrix.__init__(self, p90=0.66, theta0=0.25, alpha=4.0, xi=25.6)
 
 
+def _rngFlags(rng) -> int:
+    from .random import rngFlags
+
+    return rngFlags(rng)
+
+
 def _philoxParams(rng, i: int) -> capi.PhiloxParams:
-    r = rng._getParamsBlock("PhiloxParams", i)
+    from .random import fillRngParams
+
     P = capi.PhiloxParams()
-    P.key[0], P.key[1] = r.key.lo, r.key.hi
-    for k in range(4):
-        P.offset[k] = r.offset.word[k]
+    fillRngParams(P, rng, i)
     return P
 
 
@@ -72,7 +77,7 @@ class TargetSampler(PipelineStage):
         def launch() -> None:
             T = capi.TargetParams()
             fillTargetParams(T, self._target, i)
-            self._result[i] = _backend.get().probe_target(_philoxParams(self._rng, i), targetFlags(self._target), T,
+            self._result[i] = _backend.get().probe_target(_philoxParams(self._rng, i), targetFlags(self._target) | _rngFlags(self._rng), T,
                                                           self._box.lowerCorner, self._box.upperCorner, self._batch)
 
         return [launch]
@@ -112,7 +117,7 @@ class TargetGuideSampler(PipelineStage):
         def launch() -> None:
             G = capi.GuideParams()
             fillGuideParams(G, self._guide, i)
-            self._result[i] = _backend.get().probe_guide(_philoxParams(self._rng, i), guideFlags(self._guide), G,
+            self._result[i] = _backend.get().probe_guide(_philoxParams(self._rng, i), guideFlags(self._guide) | _rngFlags(self._rng), G,
                                                          self._box.lowerCorner, self._box.upperCorner, self._batch)
 
         return [launch]

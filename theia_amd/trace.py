@@ -27,7 +27,7 @@ from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .light import (_LIGHTS, _WAVELENGTHS, HostLightSource, HostWavelengthSource, fillSourceParams, sourceSpec, uploadSourceQueues,
                     ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
                     WavelengthSource)
-from .random import RNG, PhiloxRNG
+from .random import RNG, PhiloxRNG, SobolQRNG, fillRngParams, rngFlags
 from .response import (EmptyResponse, HistogramHitResponse, HitRecorder, HitResponse, KernelHistogramHitResponse,
                        StoreTimeHitResponse, TraceConfig)
 from .scene import RectBBox, Scene
@@ -305,10 +305,7 @@ class Tracer(PipelineStage):
         P.dispatch.batchSize = d._batchSize
         P.dispatch.groupCountX, P.dispatch.groupCountY, P.dispatch.groupCountZ = d._groupCountX, d._groupCountY, d._groupCountZ
         P.photon_offset = getattr(self, "_offsets", [0, 0])[i] & 0xFFFFFFFF
-        r = rng._getParamsBlock("PhiloxParams", i)
-        P.philox.key[0], P.philox.key[1] = r.key.lo, r.key.hi
-        for k in range(4):
-            P.philox.offset[k] = r.offset.word[k]
+        fillRngParams(P.philox, rng, i)
         fillSourceParams(P, i, source, wavelength)
         if isinstance(response, HistogramHitResponse):
             rp = response._getParamsBlock("ResponseParams", i)
@@ -346,8 +343,8 @@ class Tracer(PipelineStage):
         if not isinstance(response, (HistogramHitResponse, HitRecorder, EmptyResponse, StoreTimeHitResponse)):
             raise _unsupported("response", response, "HistogramHitResponse(UniformValueResponse()), HitRecorder, "
                                "StoreTimeHitResponse(UniformValueResponse()), EmptyResponse")
-        if not isinstance(rng, PhiloxRNG):
-            raise _unsupported("random number generator", rng, "PhiloxRNG")
+        if not isinstance(rng, (PhiloxRNG, SobolQRNG)):
+            raise _unsupported("random number generator", rng, "PhiloxRNG, SobolQRNG")
         if not isinstance(callback, (EmptyEventCallback, EventStatisticCallback, TrackRecordCallback)):
             raise _unsupported("event callback", callback, "EmptyEventCallback, EventStatisticCallback, TrackRecordCallback")
 
@@ -416,7 +413,7 @@ class VolumeForwardTracer(Tracer):
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
         flags |= targetFlags(target)
         srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
-        flags |= srcFlags
+        flags |= srcFlags | rngFlags(rng)
         flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response),
@@ -543,7 +540,7 @@ class SceneForwardTracer(Tracer):
         flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
         flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
         srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
-        flags |= srcFlags
+        flags |= srcFlags | rngFlags(rng)
         flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
         self._code = b"" if code is None else code
         self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response),
