@@ -48,6 +48,7 @@ struct thx_scene {
     thx_ctx* ctx = nullptr;
     SceneView view{};
     thx_scene_info info{};
+    uint32_t nPairs = 0; // pair records the walk reads (inner nodes of all trees)
     float lastQueryMs = 0.0f;
     std::vector<void*> allocs;
 };
@@ -227,7 +228,8 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     rc = uploadVec(s, (vec).data(), (vec).size() * sizeof((vec)[0]), &p);          \
     if (rc != THX_OK) { thx_scene_destroy(s); return rc; }                         \
     s->view.field = reinterpret_cast<const T*>(p);
-    UP(built.nodes, nodes, BvhNode)
+    UP(built.pairs, nodes, NodePair)
+    UP(built.frames, frames, TreeFrame)
     UP(built.tris, tris, TriRecord)
     UP(built.instances, instances, InstanceRecord)
     UP(built.tlasInstance, tlasInstance, uint32_t)
@@ -252,14 +254,15 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     rc = uploadVec(s, geo.data(), geo.size() * sizeof(GeometryGLSL), &p);
     if (rc != THX_OK) { thx_scene_destroy(s); return rc; }
     s->view.geometries = reinterpret_cast<const GeometryGLSL*>(p);
-    s->view.tlasRoot = built.tlasRoot;
+    s->view.tlas = built.frames[0];
     s->view.nInstances = n_instances;
 
     s->info.n_nodes = (uint32_t)built.nodes.size();
     s->info.n_triangles = (uint32_t)built.tris.size();
     s->info.n_instances = n_instances;
     s->info.max_depth = built.maxDepth;
-    s->info.bytes_nodes = built.nodes.size() * sizeof(BvhNode);
+    s->info.bytes_nodes = built.pairs.size() * sizeof(NodePair) + built.frames.size() * sizeof(TreeFrame);
+    s->nPairs = (uint32_t)built.pairs.size();
     s->info.bytes_triangles = built.tris.size() * sizeof(TriRecord);
     s->info.bytes_instances = built.instances.size() * sizeof(InstanceRecord);
     uint64_t total = s->info.bytes_nodes + s->info.bytes_triangles + s->info.bytes_instances +
@@ -359,7 +362,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     t->block = replay ? kReplayBlock : kTraceBlock;
     if (scene) {
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
-        t->stack16 = scene->info.n_nodes < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
+        t->stack16 = scene->nPairs < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
     }
     // kernel form: the staged scene kernel unless THX_KERNEL=lane asks for the lane kernel
@@ -388,11 +391,11 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
                 t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0);
             }
         t->ldsNodes = 0;
-        const uint32_t withNodes = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, scene->info.n_nodes);
+        const uint32_t withNodes = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, scene->nPairs);
         bool stage = withNodes == t->pool;
-        if (const char* env = std::getenv("THX_LDS_NODES")) stage = scene->info.n_nodes <= (uint32_t)std::max(0, std::atoi(env));
+        if (const char* env = std::getenv("THX_LDS_NODES")) stage = scene->nPairs <= (uint32_t)std::max(0, std::atoi(env));
         if (stage) {
-            t->ldsNodes = scene->info.n_nodes;
+            t->ldsNodes = scene->nPairs;
             t->pool = withNodes;
             t->mode |= 4u;
         }

@@ -183,6 +183,68 @@ void invertAffine(const float m[12], float out[12]) {
     }
 }
 
+// ---- quantised pair records (thx_layout.h: NodePair, TreeFrame) ------------------------------
+
+namespace {
+// coordinate a 16-bit value stands for; the same expression the conservative rounding below checks
+inline float dequant(uint32_t q, float step, float origin) { return std::fmaf((float)q, step, origin); }
+
+void emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame) {
+    const BvhNode& rn = out.nodes[root];
+    for (int k = 0; k < 3; ++k) {
+        const float lo = rn.lo[k], hi = rn.hi[k];
+        frame.origin[k] = lo;
+        // 65533 steps span the extent (one step of padding on either side stays inside 16 bit)
+        float step = (hi - lo) / 65533.0f;
+        step = std::max(step, 1e-7f * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30f);
+        while (dequant(65534u, step, lo) < hi) step = std::nextafter(step, INFINITY);
+        frame.step[k] = step;
+    }
+    frame.pad = 0;
+    auto qlo = [&](float v, int k) { // largest q with dequant(q) <= v, one more step outwards
+        float f = std::floor((v - frame.origin[k]) / frame.step[k]);
+        int64_t q = (int64_t)std::min(std::max(f, 0.0f), 65534.0f);
+        while (q > 0 && dequant((uint32_t)q, frame.step[k], frame.origin[k]) > v) --q;
+        return (uint32_t)std::max<int64_t>(q - 1, 0);
+    };
+    auto qhi = [&](float v, int k) { // smallest q with dequant(q) >= v, one more step outwards
+        float f = std::ceil((v - frame.origin[k]) / frame.step[k]);
+        int64_t q = (int64_t)std::min(std::max(f, 0.0f), 65534.0f);
+        while (q < 65534 && dequant((uint32_t)q, frame.step[k], frame.origin[k]) < v) ++q;
+        return (uint32_t)std::min<int64_t>(q + 1, 65535);
+    };
+    // inner nodes of this tree get consecutive pair indices in depth-first order
+    auto refOf = [&](uint32_t node, auto&& self) -> uint32_t {
+        const BvhNode& n = out.nodes[node];
+        if (n.count != 0) return (n.leftFirst << 3) | n.count; // leaf: as the walk's `cur`
+        const uint32_t index = (uint32_t)out.pairs.size();
+        out.pairs.emplace_back();
+        uint32_t w[8];
+        for (int c = 0; c < 2; ++c) {
+            const BvhNode& ch = out.nodes[n.leftFirst + c];
+            uint32_t l[3], h[3];
+            for (int k = 0; k < 3; ++k) { l[k] = qlo(ch.lo[k], k); h[k] = qhi(ch.hi[k], k); }
+            w[4 * c + 0] = l[0] | (l[1] << 16);
+            w[4 * c + 1] = h[0] | (h[1] << 16);
+            w[4 * c + 2] = l[2] | (h[2] << 16);
+        }
+        w[3] = self(n.leftFirst, self);
+        w[7] = self(n.leftFirst + 1, self);
+        std::memcpy(out.pairs[index].w, w, sizeof(w));
+        return index << 3;
+    };
+    frame.rootRef = refOf(root, refOf);
+}
+
+void emitPairs(BuiltScene& out) {
+    out.pairs.clear();
+    out.frames.assign(1 + out.blasRoot.size(), TreeFrame{});
+    emitTree(out, out.tlasRoot, out.frames[0]);
+    for (size_t m = 0; m < out.blasRoot.size(); ++m) emitTree(out, out.blasRoot[m], out.frames[1 + m]);
+    if (out.pairs.empty()) out.pairs.emplace_back(); // single-leaf trees only: keep the array non-empty
+}
+} // namespace
+
 BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
                       const thx_instance_desc* instances, uint32_t n_instances,
                       uint32_t max_stack_depth) {
@@ -283,6 +345,8 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
     out.maxDepth = tdepth + 1 + deepestBlas;
     if (out.maxDepth + 1 > max_stack_depth)
         throw std::runtime_error("scene hierarchy deeper than the traversal stack");
+    for (uint32_t k = 0; k < n_instances; ++k) out.instances[k].frame = 1 + instances[k].mesh;
+    emitPairs(out);
     return out;
 }
 

@@ -12,7 +12,9 @@
 namespace thx {
 
 struct BuiltScene {
-    std::vector<BvhNode> nodes;         // [TLAS | BLAS 0 | BLAS 1 | ...]
+    std::vector<BvhNode> nodes;         // [TLAS | BLAS 0 | BLAS 1 | ...] (host only: the source of `pairs`)
+    std::vector<NodePair> pairs;        // what the device walks: one record per inner node
+    std::vector<TreeFrame> frames;      // quantisation frame + root ref per tree: [TLAS, BLAS 0, BLAS 1, ...]
     std::vector<TriRecord> tris;        // leaf order, all meshes
     std::vector<InstanceRecord> instances;
     std::vector<uint32_t> tlasInstance; // TLAS leaf slot -> instance id

@@ -174,9 +174,7 @@ THX_DEV void bindLane(Lane<V>& L, const Meta& m) {
 template <class V>
 THX_DEV bool rootHit(Lane<V>& L, f3 org, f3 dir, float tmax) {
     const SceneView& sc = L.a->scene;
-    const float4* nodes = walkNodes(L);
-    float4 n0 = nodes[2 * sc.tlasRoot], n1 = nodes[2 * sc.tlasRoot + 1];
-    bool hit = slabNode(n0, n1, slabRay(org, dir), tmax) >= 0.0f;
+    bool hit = slabRoot(qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir), tmax);
     if (!hit) { // account like rayQuery would have: one query, one node fetched
         L.cnt.add(ST_QUERIES);
         L.cnt.add(ST_NODES);
@@ -336,6 +334,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
 #ifdef THX_STAGE_PROFILE
     unsigned long long profIdle0 = __builtin_amdgcn_s_memtime();
     unsigned long long* const profLds = reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF);
+    L.prof = profLds;
 #endif
     uint32_t idleSpins = 0;
     while (true) {

@@ -79,6 +79,9 @@ struct Lane {
     uint32_t idx;   // photon index == RNG stream
     uint32_t local; // index inside the batch
     uint32_t dim;   // RNG dimension
+#ifdef THX_STAGE_PROFILE
+    unsigned long long* prof = nullptr; // LDS accumulators of the staged kernel's profile
+#endif
 };
 
 // random(idx, dim) of the RNG the tracer was built with: Philox, or with THX_FLAG_RNG_SOBOL the
@@ -1001,6 +1004,47 @@ THX_DEV float slabNode(const float4 a, const float4 b, const SlabRay& r, float t
     return tn <= tf * 1.0000004f ? tn : -1.0f;
 }
 
+// The walk reads 16-bit quantised child boxes (thx_layout.h: NodePair): plane = origin + q * step in
+// the frame of the tree. Folded into the ray that is one fma per plane again:
+//   t = (origin + q * step - o) / d = q * (step / d) + (origin - o) / d = q * a + b.
+// Rounding: a and b carry a few 1e-7 relative of |origin / d| resp. |q step / d| -- the same size as
+// the errors of the unquantised form above; the builder pads every box by 2e-6 relative and by one
+// quantisation step, the interval test carries the 4e-7 slack.
+struct QRay {
+    v2f a_xy, b_xy;
+    float a_z, b_z;
+};
+THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origin, rootRef}, f1 = {step, -}
+    const float ix = slabInv(d.x), iy = slabInv(d.y), iz = slabInv(d.z);
+    QRay r;
+    r.a_xy = v2f{f1.x * ix, f1.y * iy};
+    r.b_xy = v2f{__builtin_fmaf(f0.x, ix, -(o.x * ix)), __builtin_fmaf(f0.y, iy, -(o.y * iy))};
+    r.a_z = f1.z * iz;
+    r.b_z = __builtin_fmaf(f0.z, iz, -(o.z * iz));
+    return r;
+}
+// one child of a pair record: c.x = lo.x | lo.y << 16, c.y = hi.x | hi.y << 16, c.z = lo.z | hi.z << 16
+THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
+    const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
+    const v2f t0 = __builtin_elementwise_fma(v2f{(float)(wl & 0xFFFFu), (float)(wl >> 16)}, r.a_xy, r.b_xy);
+    const v2f t1 = __builtin_elementwise_fma(v2f{(float)(wh & 0xFFFFu), (float)(wh >> 16)}, r.a_xy, r.b_xy);
+    const float tz0 = __builtin_fmaf((float)(wz & 0xFFFFu), r.a_z, r.b_z), tz1 = __builtin_fmaf((float)(wz >> 16), r.a_z, r.b_z);
+    float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
+    return tn <= tf * 1.0000004f ? tn : -1.0f;
+}
+// the root box of a tree = its whole frame, q = 0 .. 65535
+THX_DEV bool slabRoot(const QRay& r, float tmax) {
+    const v2f t0 = r.b_xy;
+    const v2f t1 = __builtin_elementwise_fma(v2f{65535.0f, 65535.0f}, r.a_xy, r.b_xy);
+    const float tz0 = r.b_z, tz1 = __builtin_fmaf(65535.0f, r.a_z, r.b_z);
+    float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
+    float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
+    return tn <= tf * 1.0000004f;
+}
+THX_DEV float4 tlasFrame0(const SceneView& sc) { return make_float4(sc.tlas.origin[0], sc.tlas.origin[1], sc.tlas.origin[2], __uint_as_float(sc.tlas.rootRef)); }
+THX_DEV float4 tlasFrame1(const SceneView& sc) { return make_float4(sc.tlas.step[0], sc.tlas.step[1], sc.tlas.step[2], 0.0f); }
+
 constexpr uint32_t WALK_DONE = 0xFFFFFFFFu;     // low bits 7
 constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current instance
 
@@ -1015,9 +1059,10 @@ THX_DEV const float4* walkNodes(const Lane<V>& L) {
 
 // Closest-hit query: opaque, no culling, 0 < t < tmax, committed closest triangle
 // (what scene.traverse.glsl:312-323 / :198-205 ask of the driver). Two-level
-// BVH2 with 32-B nodes; the per-lane stack lives in LDS (lane-strided so a
-// push/pop of the whole wave touches 64 consecutive banks). A node is fetched
-// exactly once, together with its sibling, when its parent is opened.
+// BVH2 read as 32-B pair records (both children of an inner node, boxes quantised to 16 bit);
+// the per-lane stack lives in LDS (lane-strided so a push/pop of the whole wave touches 64
+// consecutive banks). A child's box is fetched exactly once, together with its sibling's, when
+// their parent is opened.
 //
 // Walker = the resumable state of one lane's query: begin() tests the TLAS root,
 // advance() opens inner nodes until the lane holds a leaf and then handles that
@@ -1036,9 +1081,12 @@ struct Walker {
     uint32_t sp, cur, curInst;
     bool inBlas;
     f3 org, dir, ao;
-    SlabRay sr, wsr;
+    QRay sr, wsr;
     WoopRay w;
     QueryHit h;
+#ifdef THX_STAGE_PROFILE
+    unsigned long long pInner = 0, pLeaf = 0, pOther = 0, pRounds = 0, pTrips = 0;
+#endif
 
     THX_DEV explicit Walker(Lane<V>& lane) : L(lane) {
         nodes = walkNodes(L);
@@ -1079,34 +1127,44 @@ struct Walker {
         sp = 0; inBlas = false; curInst = 0;
         // active ray: world space in the TLAS, object space inside an instance
         ao = org;
-        sr = slabRay(org, dir);
+        sr = qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir);
         wsr = sr;
-        float4 n0 = nodes[2 * sc.tlasRoot], n1 = nodes[2 * sc.tlasRoot + 1];
         L.cnt.add(ST_NODES);
-        cur = slabNode(n0, n1, sr, h.t) >= 0.0f
-                  ? ((__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w))
-                  : WALK_DONE;
+        cur = slabRoot(sr, h.t) ? sc.tlas.rootRef : WALK_DONE;
     }
 
     // one round: inner nodes down to a leaf, then that leaf. No-op for a finished lane.
     THX_DEV void advance() {
         const SceneView& sc = L.a->scene;
+#ifdef THX_STAGE_PROFILE
+        const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
+        pRounds += 1;
+#endif
         // open inner nodes until this lane holds a leaf
         while ((cur & 7u) == 0u) {
-            uint32_t left = cur >> 3;
-            float4 l0 = nodes[2 * left], l1 = nodes[2 * left + 1];
-            float4 r0 = nodes[2 * left + 2], r1 = nodes[2 * left + 3];
+#ifdef THX_STAGE_PROFILE
+            pTrips += 1; // lane 0's count is what gets reported: trips of the wave while lane 0 is in the loop
+#endif
+            const uint32_t pair = cur >> 3;
+            const float4 lc = nodes[2 * pair], rc = nodes[2 * pair + 1];
             L.cnt.add(ST_NODES, 2);
 #ifdef THX_EXTRA_LOADS // experiment: what do two more 16-B gathers per visit cost?
             {
-                float4 x0 = nodes[2 * left + 0 + THX_EXTRA_LOADS], x1 = nodes[2 * left + 1 + THX_EXTRA_LOADS];
+                float4 x0 = nodes[2 * pair + 0 + THX_EXTRA_LOADS], x1 = nodes[2 * pair + 1 + THX_EXTRA_LOADS];
                 if (x0.x == 12345.678f || x1.x == 12345.678f) h.t = 0.0f;
             }
 #endif
-            float tl = slabNode(l0, l1, sr, h.t);
-            float tr = slabNode(r0, r1, sr, h.t);
-            uint32_t ml = (__float_as_uint(l0.w) << 3) | __float_as_uint(l1.w);
-            uint32_t mr = (__float_as_uint(r0.w) << 3) | __float_as_uint(r1.w);
+            float tl = slabChild(lc, sr, h.t);
+            float tr = slabChild(rc, sr, h.t);
+#ifdef THX_EXTRA_VALU // experiment: is the walk bound by VALU issue? N dependent FMAs per visit that cannot be removed
+            {
+                float acc = tl;
+#pragma unroll
+                for (int e = 0; e < THX_EXTRA_VALU; ++e) acc = __builtin_fmaf(acc, 1.0000001f, tr);
+                if (acc == 12345.678f) h.t = 0.0f;
+            }
+#endif
+            const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
             if (tl >= 0.0f && tr >= 0.0f) {
                 bool leftFirst = tl <= tr;
                 push(leftFirst ? mr : ml);
@@ -1119,6 +1177,14 @@ struct Walker {
                 cur = pop();
             }
         }
+#ifdef THX_STAGE_PROFILE
+        const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
+        pInner += pt1 - pt0;
+        struct Tail { // charges the rest of the round to the triangle or the instance phase
+            unsigned long long t1; unsigned long long& leaf; unsigned long long& other; bool tri;
+            __device__ ~Tail() { const unsigned long long d = __builtin_amdgcn_s_memtime() - t1; if (tri) leaf += d; else other += d; }
+        } tail{pt1, pLeaf, pOther, inBlas && cur != WALK_DONE && cur != WALK_SENTINEL};
+#endif
         if (cur == WALK_DONE) return;
         if (cur == WALK_SENTINEL) { // back to world space
             inBlas = false;
@@ -1132,7 +1198,8 @@ struct Walker {
             curInst = sc.tlasInstance[first];
             const float4* rec = reinterpret_cast<const float4*>(sc.instances + curInst);
             float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
-            uint32_t blasRoot = __float_as_uint(rec[6].x);
+            const float4* frame = reinterpret_cast<const float4*>(sc.frames + __float_as_uint(rec[6].w));
+            const float4 f0 = frame[0], f1 = frame[1];
             L.cnt.add(ST_INSTANCES);
             ao = f3{m0.w + ((m0.x * org.x + m0.y * org.y) + m0.z * org.z),
                     m1.w + ((m1.x * org.x + m1.y * org.y) + m1.z * org.z),
@@ -1140,14 +1207,13 @@ struct Walker {
             f3 od = f3{(m0.x * dir.x + m0.y * dir.y) + m0.z * dir.z,
                        (m1.x * dir.x + m1.y * dir.y) + m1.z * dir.z,
                        (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
-            sr = slabRay(ao, od);
+            sr = qRay(f0, f1, ao, od);
             w = woopSetup(od);
             inBlas = true;
             push(WALK_SENTINEL);
-            float4 n0 = nodes[2 * blasRoot], n1 = nodes[2 * blasRoot + 1];
             L.cnt.add(ST_NODES);
-            if (slabNode(n0, n1, sr, h.t) >= 0.0f)
-                cur = (__float_as_uint(n0.w) << 3) | __float_as_uint(n1.w);
+            if (slabRoot(sr, h.t))
+                cur = __float_as_uint(f0.w);
             else
                 cur = pop(); // pops the sentinel
         } else {
@@ -1180,6 +1246,12 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
     wk.begin(org, dir, tmax);
     while (!wk.done()) wk.advance();
     if (wk.h.valid) L.cnt.add(ST_HITS);
+#ifdef THX_STAGE_PROFILE
+    if ((threadIdx.x & 63u) == 0u && L.prof != nullptr) { // wave-level sums (s_memtime is uniform)
+        atomicAdd(&L.prof[24], wk.pInner); atomicAdd(&L.prof[25], wk.pLeaf); atomicAdd(&L.prof[26], wk.pOther);
+        atomicAdd(&L.prof[27], wk.pRounds); atomicAdd(&L.prof[28], wk.pTrips);
+    }
+#endif
     return wk.h;
 }
 

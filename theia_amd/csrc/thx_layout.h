@@ -20,6 +20,27 @@ struct alignas(16) BvhNode {
 };
 static_assert(sizeof(BvhNode) == 32, "node must be 32 B");
 
+// What the walk reads instead of BvhNode: the two children of an inner node in ONE 32-B record (two
+// 16-B loads instead of four -- the walk is bound by the L1's gather rate, one cycle per lane and
+// load instruction). The child boxes are quantised to 16 bit per coordinate in the frame of their
+// tree (TLAS, or the mesh's BLAS): coordinate = origin + q * step, rounded outwards.
+//   w[0] = L.lo.x | L.lo.y << 16   w[1] = L.hi.x | L.hi.y << 16   w[2] = L.lo.z | L.hi.z << 16   w[3] = ref L
+//   w[4] = R.lo.x | R.lo.y << 16   w[5] = R.hi.x | R.hi.y << 16   w[6] = R.lo.z | R.hi.z << 16   w[7] = ref R
+//   ref = (index << 3) | count: count == 0 -> index of the child's own pair record, count > 0 -> first
+//   triangle record (BLAS) / first instance slot (TLAS) of the leaf
+struct alignas(16) NodePair {
+    uint32_t w[8];
+};
+static_assert(sizeof(NodePair) == 32, "node pair must be 32 B");
+// frame of one tree, 32 B: tree 0 = TLAS, tree 1 + m = BLAS of mesh m
+struct alignas(16) TreeFrame {
+    float origin[3];
+    uint32_t rootRef; // ref of the tree's root (a leaf if the tree is a single leaf)
+    float step[3];
+    uint32_t pad;
+};
+static_assert(sizeof(TreeFrame) == 32, "tree frame must be 32 B");
+
 // Triangle record in BVH leaf order, 48 B = three 16-B loads.
 struct alignas(16) TriRecord {
     float v0[3];
@@ -38,7 +59,7 @@ struct alignas(16) InstanceRecord {
     uint32_t blasRoot; // node index of the mesh's BLAS root
     int32_t customIndex;
     uint32_t geometry; // index into Geometry[]
-    uint32_t pad;
+    uint32_t frame;    // index of the mesh's TreeFrame
 };
 static_assert(sizeof(InstanceRecord) == 112, "instance record must be 112 B");
 
@@ -65,12 +86,13 @@ static_assert(sizeof(GeometryGLSL) == 24, "Geometry is 24 B");
 
 // everything a traversal needs
 struct SceneView {
-    const BvhNode* nodes;
+    const NodePair* nodes; // pair records of all trees
     const TriRecord* tris;
     const InstanceRecord* instances;
     const uint32_t* tlasInstance; // TLAS leaf slot -> instance id
     const GeometryGLSL* geometries;
-    uint32_t tlasRoot;
+    const TreeFrame* frames;
+    TreeFrame tlas; // frame 0 by value: every query starts with it
     uint32_t nInstances;
 };
 

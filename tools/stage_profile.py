@@ -32,3 +32,8 @@ print(f"per claim: failed looks {int(out[12]) / claims:.0f}  scan+claim {int(out
 if out[10]:
     r = int(out[16 + 2])
     print(f"T0 detail: waves/round={int(out[10]) / r:.1f} walk cycles/wave={int(out[8]) / int(out[10]):.0f} post cycles/wave={int(out[9]) / int(out[10]):.0f} round={int(out[2]) / r:.0f}")
+
+if out[27]:
+    w = int(out[10])
+    print(f"walk detail per wave-batch: advance rounds={int(out[27]) / w:.1f} inner trips (lane 0)={int(out[28]) / w:.1f} "
+          f"inner cycles={int(out[24]) / w:.0f} triangle-leaf cycles={int(out[25]) / w:.0f} instance/exit cycles={int(out[26]) / w:.0f}")
