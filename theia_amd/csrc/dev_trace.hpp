@@ -1131,11 +1131,39 @@ struct Walker {
         wsr = sr;
         L.cnt.add(ST_NODES);
         cur = slabRoot(sr, h.t) ? sc.tlas.rootRef : WALK_DONE;
+        // a scene of one instance: its TLAS is a single leaf, every ray that hits the root box enters
+        // the instance -- do it here, with all lanes together, instead of spending a walk round on it
+        if (cur != WALK_DONE && (cur & 7u) != 0u) enterInstance(cur >> 3);
+    }
+
+    // TLAS leaves hold exactly one instance: transform the ray into its object space and dive
+    THX_DEV void enterInstance(uint32_t first) {
+        const SceneView& sc = L.a->scene;
+        curInst = sc.tlasInstance[first];
+        const float4* rec = reinterpret_cast<const float4*>(sc.instances + curInst);
+        float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
+        const float4* frame = reinterpret_cast<const float4*>(sc.frames + __float_as_uint(rec[6].w));
+        const float4 f0 = frame[0], f1 = frame[1];
+        L.cnt.add(ST_INSTANCES);
+        ao = f3{m0.w + ((m0.x * org.x + m0.y * org.y) + m0.z * org.z),
+                m1.w + ((m1.x * org.x + m1.y * org.y) + m1.z * org.z),
+                m2.w + ((m2.x * org.x + m2.y * org.y) + m2.z * org.z)};
+        f3 od = f3{(m0.x * dir.x + m0.y * dir.y) + m0.z * dir.z,
+                   (m1.x * dir.x + m1.y * dir.y) + m1.z * dir.z,
+                   (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
+        sr = qRay(f0, f1, ao, od);
+        w = woopSetup(od);
+        inBlas = true;
+        push(WALK_SENTINEL);
+        L.cnt.add(ST_NODES);
+        if (slabRoot(sr, h.t))
+            cur = __float_as_uint(f0.w);
+        else
+            cur = pop(); // pops the sentinel
     }
 
     // one round: inner nodes down to a leaf, then that leaf. No-op for a finished lane.
     THX_DEV void advance() {
-        const SceneView& sc = L.a->scene;
 #ifdef THX_STAGE_PROFILE
         const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
         pRounds += 1;
@@ -1194,28 +1222,7 @@ struct Walker {
         }
         uint32_t first = cur >> 3, count = cur & 7u;
         if (!inBlas) {
-            // TLAS leaves hold exactly one instance: transform the ray and dive
-            curInst = sc.tlasInstance[first];
-            const float4* rec = reinterpret_cast<const float4*>(sc.instances + curInst);
-            float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
-            const float4* frame = reinterpret_cast<const float4*>(sc.frames + __float_as_uint(rec[6].w));
-            const float4 f0 = frame[0], f1 = frame[1];
-            L.cnt.add(ST_INSTANCES);
-            ao = f3{m0.w + ((m0.x * org.x + m0.y * org.y) + m0.z * org.z),
-                    m1.w + ((m1.x * org.x + m1.y * org.y) + m1.z * org.z),
-                    m2.w + ((m2.x * org.x + m2.y * org.y) + m2.z * org.z)};
-            f3 od = f3{(m0.x * dir.x + m0.y * dir.y) + m0.z * dir.z,
-                       (m1.x * dir.x + m1.y * dir.y) + m1.z * dir.z,
-                       (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
-            sr = qRay(f0, f1, ao, od);
-            w = woopSetup(od);
-            inBlas = true;
-            push(WALK_SENTINEL);
-            L.cnt.add(ST_NODES);
-            if (slabRoot(sr, h.t))
-                cur = __float_as_uint(f0.w);
-            else
-                cur = pop(); // pops the sentinel
+            enterInstance(first);
         } else {
             // leaves hold <= 4 triangles; fetch them in pairs before testing so that a
             // leaf costs two memory round trips instead of four (tests stay in order)
