@@ -334,3 +334,46 @@ def test_batch_larger_than_the_host_queue_fails_loudly():
             pl.runPipeline(tracer.collectStages())
     finally:
         _backend._backend = prev
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cone+function", "pencil+uniform", "spherical+sobol"])
+def test_tracer_with_every_source_hip_matches_oracle(kind):
+    """light curves of a volume tracer driven by each light / wavelength source (and by the Sobol
+    generator): oracle and HIP agree bin by bin"""
+    from oracle_backend import OracleBackend
+    from theia_amd import _backend
+    import theia.random as TRN
+
+    n, out, prev = 32 * 1024, {}, _backend._backend
+    for name in ("oracle", "hip"):
+        be = OracleBackend(threads=8) if name == "oracle" else _backend.HipBackend()
+        _backend._backend = be
+        try:
+            water = WaterTestModel().createMedium()
+            store = theia.material.MaterialStore([], media=[water])
+            where = (-1.0, -7.0, 0.0) * u.m
+            if kind == "cone+function":
+                light = TL.ConeLightSource(position=where, direction=(0.6, 0.8, 0.0), cosOpeningAngle=0.3, budget=100.0,
+                                           timeRange=(0.0, 5.0) * u.ns, polarized=True, stokes=(1.0, 0.4, 0.0, 0.1),
+                                           polarizationReference=(0.0, 0.0, 1.0))
+                photons = TL.FunctionWavelengthSource(lambda lam: 1.0 + (lam - 400.0) / 300.0, lambdaRange=(400.0, 700.0) * u.nm)
+            elif kind == "pencil+uniform":
+                light = TL.PencilLightSource(position=where, direction=(0.6, 0.8, 0.0), budget=100.0, timeRange=(0.0, 5.0) * u.ns,
+                                             stokes=(1.0, 0.0, 0.3, 0.0), polarizationRef=(0.0, 0.0, 1.0))
+                photons = TL.UniformWavelengthSource(lambdaRange=(400.0, 700.0) * u.nm)
+            else:
+                light = TL.SphericalLightSource(position=where, budget=100.0, timeRange=(0.0, 5.0) * u.ns)
+                photons = TL.ConstWavelengthSource(500.0 * u.nm)
+            rng = TRN.SobolQRNG(seed=0xBEEF) if kind.endswith("sobol") else PhiloxRNG(key=0xFEED)
+            response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), nBins=64, binSize=10.0 * u.ns)
+            tracer = theia.trace.VolumeForwardTracer(n, light, SphereTarget(position=(5.0, 2.0, -8.0) * u.m, radius=4.0 * u.m), photons,
+                                                     response, rng, medium=store.media["water"], nScattering=6, polarized=True)
+            pl.runPipeline(tracer.collectStages())
+            out[name] = np.array(response.result(0))
+        finally:
+            _backend._backend = prev
+            if name == "oracle":
+                be.close()
+    assert out["oracle"].sum() > 0
+    assert np.allclose(out["oracle"], out["hip"], rtol=2e-3, atol=1e-5 * out["oracle"].max())

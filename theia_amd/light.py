@@ -179,7 +179,11 @@ class FunctionWavelengthSource(WavelengthSource):
             def pdf(self, x):
                 return fn(x)
 
-        inv_cdf = NumericalInversePolynomial(Dist(), domain=tuple(lambdaRange))
+        import warnings
+
+        with warnings.catch_warnings():  # scipy notes that it moved the expansion centre into the domain
+            warnings.simplefilter("ignore", RuntimeWarning)
+            inv_cdf = NumericalInversePolynomial(Dist(), domain=tuple(lambdaRange))
         x = inv_cdf.ppf(np.linspace(0.0, 1.0, numSamples))
         self._tableMemory, [table_adr] = uploadTables([x])
         self.setParams(_table=table_adr, _contrib=contrib)
