@@ -10,7 +10,7 @@ Sobol point of index `stream` under a seed derived from `dim`.
 from __future__ import annotations
 
 import warnings
-from ctypes import Structure, c_uint32
+from ctypes import Structure, addressof, c_uint32, memmove, sizeof
 from os import urandom
 
 import numpy as np
@@ -32,39 +32,39 @@ class RNG(SourceCodeMixin):
         super().__init__(params, extras)
 
 
-class Key(Structure):
-    _fields_ = [("lo", c_uint32), ("hi", c_uint32)]
+class _WideUInt(Structure):
+    """unsigned integer wider than a machine word, stored as little-endian 32-bit words
+    (how the shader's uvec2 / uvec4 parameter fields are laid out)"""
 
     @property
     def value(self) -> int:
-        return self.lo + (self.hi << 32)
+        return int.from_bytes(bytes(self), "little")
 
     @value.setter
-    def value(self, value: int) -> None:
-        self.lo = value & 0xFFFFFFFF
-        self.hi = (value >> 32) & 0xFFFFFFFF
+    def value(self, number: int) -> None:
+        width = sizeof(self)
+        memmove(addressof(self), (int(number) % (1 << (8 * width))).to_bytes(width, "little"), width)
 
 
-class Counter(Structure):
-    _fields_ = [("word", c_uint32 * 4)]
+class Key(_WideUInt):
+    """64-bit Philox key"""
 
-    @property
-    def value(self) -> int:
-        return sum(self.word[i] << (32 * i) for i in range(4))
+    _fields_ = [("words", c_uint32 * 2)]
 
-    @value.setter
-    def value(self, value: int) -> None:
-        for i in range(4):
-            self.word[i] = (value >> (32 * i)) & 0xFFFFFFFF
+
+class Counter(_WideUInt):
+    """128-bit Philox counter"""
+
+    _fields_ = [("words", c_uint32 * 4)]
 
 
 class PhiloxRNG(RNG):
     """
-    Philox 4x32-10.
+    Philox4x32-10 addressed as the shader does (API of reference random.py:228-282).
 
-    Parameters (also stage parameters): `key` (64 bit; consecutive streams add one),
-    `offset` (128 bit position inside every stream), `autoAdvance` (added to
-    `offset` on every update).
+    Stage parameters: `key` (64 bit, stream s uses key + s), `offset` (128 bit, where every
+    stream starts), `autoAdvance` (how far `offset` moves on each `update()` -- before the batch
+    that update prepares, so the first batch already runs at `offset + autoAdvance`).
     """
 
     name = "Philox RNG"
@@ -74,22 +74,23 @@ class PhiloxRNG(RNG):
 
     def __init__(self, *, key: int | None = None, offset: int = 0, autoAdvance: int = 0) -> None:
         super().__init__({"PhiloxParams": self.PhiloxParams}, {"autoAdvance"})
+        self._step = 0
         if key is None:
             key = int.from_bytes(urandom(8), "little")
-            warnings.warn(f"Random RNG key generated: 0x{key:08X}")
+            warnings.warn(f"PhiloxRNG without a key: drew 0x{key:016X} from the OS")
         self.setParams(key=key, offset=offset, autoAdvance=autoAdvance)
 
     @property
     def autoAdvance(self) -> int:
-        return self._autoAdvance
+        return self._step
 
     @autoAdvance.setter
-    def autoAdvance(self, value: int) -> None:
-        self._autoAdvance = value
+    def autoAdvance(self, amount: int) -> None:
+        self._step = int(amount)
 
     def _finishParams(self, i: int) -> None:
-        if self.autoAdvance != 0:
-            self.setParam("offset", (self.getParam("offset") + self.autoAdvance) & ((1 << 128) - 1))
+        if self._step:
+            self.setParam("offset", self.getParam("offset") + self._step)  # wraps at 2^128 in Counter.value
         super()._finishParams(i)
 
 
@@ -116,18 +117,17 @@ class SobolQRNG(RNG):
         self._hostRNG = None
         self.setParams(seed=seed if seed is not None else 0, offset=offset, advanceSeed=advanceSeed)
 
-    @property
-    def advanceSeed(self) -> int | None:
-        return self._advanceSeed
+    def _reseed(self, value) -> None:
+        self._advance = value
+        self._hostRNG = np.random.default_rng(value) if value is not None else None
 
-    @advanceSeed.setter
-    def advanceSeed(self, value: int | None) -> None:
-        self._advanceSeed = value
-        self._hostRNG = None if value is None else np.random.default_rng(value)
+    advanceSeed = property(lambda self: self._advance, _reseed,
+                           doc="seed of the host generator that draws a new `seed` per update (None: keep the seed)")
 
     def _finishParams(self, i: int) -> None:
         if self._hostRNG is not None:
-            self.setParam("seed", int.from_bytes(self._hostRNG.bytes(4), "big"))
+            fresh = self._hostRNG.bytes(4)
+            self.setParam("seed", int.from_bytes(fresh, "big"))
         super()._finishParams(i)
 
 
@@ -205,6 +205,6 @@ def fillRngParams(dst, rng, i: int) -> None:
             dst.offset[k] = 0
         return
     r = rng._getParamsBlock("PhiloxParams", i)
-    dst.key[0], dst.key[1] = r.key.lo, r.key.hi
+    dst.key[0], dst.key[1] = r.key.words[0], r.key.words[1]
     for k in range(4):
-        dst.offset[k] = r.offset.word[k]
+        dst.offset[k] = r.offset.words[k]

@@ -1,10 +1,14 @@
 """
-Run-until-converged driver for light curves (reference: src/theia/task.py:22-196): a dynamic
-task keeps issuing batches of a histogram pipeline and averages them until the standard error of
-the mean of the curve's integral falls below `atol + rtol * integral`.
+Run-until-converged driver for light curves (API of reference src/theia/task.py:22-196): a
+dynamic task keeps issuing batches of a histogram pipeline and averages them until the
+standard error of the curve's integral falls below `atol + rtol * integral`.
+
+Host logic only. The statistics live in `_RunningCurve` (Welford update of the integrals, running
+mean of the bins); the task adds the batch policy on top.
 """
 from __future__ import annotations
 
+import math
 import warnings
 from typing import Callable
 
@@ -16,70 +20,108 @@ from .response import HistogramHitResponse
 __all__ = ["ConvergeHistogramTask"]
 
 
+class _RunningCurve:
+    """mean light curve over the batches seen so far + spread of the per-batch integrals"""
+
+    def __init__(self, n_bins: int) -> None:
+        self.mean = np.zeros(n_bins)
+        self.count = 0
+        self.integral = 0.0   # mean of the integrals
+        self.sq_dev = 0.0     # sum of squared deviations of the integrals from their mean
+
+    def add(self, curve: np.ndarray) -> None:
+        self.count += 1
+        k = self.count
+        self.mean += (curve - self.mean) / k
+        total = float(np.sum(curve))
+        before = total - self.integral
+        self.integral += before / k
+        self.sq_dev += before * (total - self.integral)
+
+    def standard_error(self) -> float:
+        """s / sqrt(n) with s^2 = sq_dev / (n - 1.5): the small-sample correction of the reference
+        (task.py:113-120), pessimistic for a handful of batches"""
+        k = self.count
+        if k < 2:
+            return math.inf
+        return math.sqrt(self.sq_dev / (k - 1.5) / k)
+
+
 class ConvergeHistogramTask(DynamicTask):
     """
-    Issues `initialBatchCount` batches with `params` applied to the pipeline, then
-    `extraBatchCount` more at a time until the error estimate drops below the threshold or
-    `maxBatchCount` batches were used (`converged` tells which). `result` is the running mean
-    of the batches' histograms, `error` the standard error of the mean of their integrals with
-    a small-sample correction (sqrt(M2 / (n - 1.5)) / sqrt(n)).
+    `initialBatchCount` batches with `params` applied to the pipeline first; whenever all issued
+    batches are in and the error is still above `atol + rtol * integral`, `extraBatchCount` more,
+    up to `maxBatchCount` in total. `converged` says how it ended, `result` is the mean curve,
+    `error` the standard error of its integral. `finishedCallback(task)` runs at the end.
     """
 
     def __init__(self, response: HistogramHitResponse, params: dict, pipeline: str | None = None, *,
                  initialBatchCount: int = 4, extraBatchCount: int = 2, maxBatchCount: int = 50, atol: float = 0.1,
                  rtol: float = 5e-5, finishedCallback: Callable[["ConvergeHistogramTask"], None] | None = None) -> None:
-        super().__init__(params, pipeline, initialBatchCount=initialBatchCount)
+        for name, least, given in (("initialBatchCount", 2, initialBatchCount), ("extraBatchCount", 1, extraBatchCount)):
+            if given < least:
+                raise ValueError(f"{name} = {given} is too small (minimum {least})")
         if not response.retrieve:
-            raise ValueError("Task requires response to retrieve results!")
-        if initialBatchCount < 2:
-            raise ValueError("initialBatchCount must be at least 2!")
-        if extraBatchCount < 1:
-            raise ValueError("extraBatchCount must be at least1!")
+            raise ValueError("the response does not copy its histogram to the host (retrieve=False)")
+        super().__init__(params, pipeline, initialBatchCount=initialBatchCount)
         self._response = response
-        self._extraCount = extraBatchCount
-        self._maxBatchCount = maxBatchCount
-        self._rtol, self._atol = rtol, atol
-        self._totalBatches = 0
-        self._converged = False
-        self._callback = finishedCallback
-        self._result = np.zeros(response.nBins)
-        self._integralMean = 0.0  # running mean of the curve integrals
-        self._m2 = 0.0            # Welford: sum of squared deviations
+        self._policy = {"extra": int(extraBatchCount), "limit": int(maxBatchCount), "atol": float(atol), "rtol": float(rtol)}
+        self._notify = finishedCallback
+        self._stat = _RunningCurve(response.nBins)
+        self._done = False
 
-    converged = property(lambda self: self._converged, doc="True if the result has converged")
-    atol = property(lambda self: self._atol, doc="absolute error threshold")
-    rtol = property(lambda self: self._rtol, doc="relative error threshold")
-    batchCountLimit = property(lambda self: self._maxBatchCount, doc="maximum allowed amount of batches")
-    response = property(lambda self: self._response, doc="response producing the histograms")
-    result = property(lambda self: self._result, doc="mean histogram; check `converged`")
-    totalBatches = property(lambda self: self._totalBatches, doc="batches used so far")
+    @property
+    def response(self) -> HistogramHitResponse:
+        return self._response
+
+    @property
+    def atol(self) -> float:
+        return self._policy["atol"]
+
+    @property
+    def rtol(self) -> float:
+        return self._policy["rtol"]
+
+    @property
+    def batchCountLimit(self) -> int:
+        return self._policy["limit"]
+
+    @property
+    def totalBatches(self) -> int:
+        return self._stat.count
+
+    @property
+    def converged(self) -> bool:
+        return self._done
+
+    @property
+    def result(self) -> np.ndarray:
+        return self._stat.mean
 
     @property
     def error(self) -> float:
-        """standard error of the mean of the curve integral (pessimistic for few batches)"""
-        n = self._totalBatches
-        return float(np.sqrt(self._m2 / (n - 1.5)) / np.sqrt(n))
+        return self._stat.standard_error()
 
-    def onTaskFinished(self) -> None:
-        if self._callback is not None:
-            self._callback(self)
+    def _threshold(self) -> float:
+        return self.atol + self.rtol * self._stat.integral
 
     def processBatch(self, config: int) -> int:
-        self._totalBatches += 1
-        hist = self._response.result(config)
-        assert hist is not None
-        self._result += (hist - self._result) / self._totalBatches
-        integral = float(hist.sum())
-        delta = integral - self._integralMean
-        self._integralMean += delta / self._totalBatches
-        self._m2 += delta * (integral - self._integralMean)
-        if self.batchesRemaining > 0:  # decide once everything issued so far is in
+        curve = self._response.result(config)
+        if curve is None:
+            raise RuntimeError("the response returned no histogram for a finished batch")
+        self._stat.add(curve)
+        if self.batchesRemaining > 0:
+            return 0  # judge only once every issued batch has arrived
+        if self.error <= self._threshold():
+            self._done = True
             return 0
-        if self.error <= self._atol + self._rtol * self._integralMean:
-            self._converged = True
-            return 0
-        n = min(max(self._maxBatchCount - self._totalBatches, 0), self._extraCount)
-        if n == 0:
-            warnings.warn(f"Failed to converge histogram (error: {self.error:.3e})!\nPipeline: {self.pipeline}\n"
-                          f"Params: {self.parameters}")
-        return n
+        room = self.batchCountLimit - self.totalBatches
+        more = max(0, min(room, self._policy["extra"]))
+        if more == 0:
+            warnings.warn(f"light curve did not converge within {self.batchCountLimit} batches: error {self.error:.3e} > "
+                          f"{self._threshold():.3e} (pipeline {self.pipeline!r}, parameters {self.parameters})")
+        return more
+
+    def onTaskFinished(self) -> None:
+        if self._notify is not None:
+            self._notify(self)
