@@ -86,7 +86,7 @@ def main() -> None:
     import numpy as np
     import torch
 
-    import scenarios as S
+    from theia_amd import workloads as S
     from theia_amd import _backend, distributed
     from theia_amd.hp.pipeline import Pipeline
 

@@ -37,7 +37,7 @@ detector = theia.material.Material("det", None, water, flags="DB")  # detect + b
 store = theia.material.MaterialStore([detector])
 
 # geometry: the icosphere this repository bundles for its tests (any STL / PLY works: theia_amd.meshio)
-mesh = np.load(os.path.join(ROOT, "tests", "golden", "meshes.npz"))
+mesh = np.load(os.path.join(ROOT, "theia_amd", "data", "meshes.npz"))
 sphere = theia.scene.Mesh()
 sphere.vertices, sphere.indices = mesh["sphere/vertices"], mesh["sphere/faces"]
 meshes = theia.scene.MeshStore({"sphere": sphere})

@@ -60,3 +60,25 @@ def hip_backend(hip):
     _backend._backend = hip
     yield hip
     _backend._backend = prev
+
+
+BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    """runs a test once on the CPU oracle stand-in and once (-m gpu) on the HIP library"""
+    from theia_amd import _backend
+
+    prev = _backend._backend
+    if request.param == "oracle":
+        from oracle_backend import OracleBackend
+
+        be = OracleBackend(threads=min(8, os.cpu_count() or 1))
+    else:
+        be = _backend.HipBackend()
+    _backend._backend = be
+    yield request.param
+    _backend._backend = prev
+    if request.param == "oracle":
+        be.close()

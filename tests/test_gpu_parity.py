@@ -221,6 +221,55 @@ def test_scene_tracer_parity_suzanne_grid(hip_backend):
     _compare(res, n, code_agree=0.99)
 
 
+def test_scene_tracer_parity_suzanne_grid_full_size(hip_backend):
+    """BASELINE config 5 with the scene SURVEY.md 8(d) specifies: 10^3 instanced suzannes (pitch 4 m,
+    rotated about z by default_rng(0xC0FFEE)) + the detector sphere = a 1001-leaf TLAS over 968-triangle
+    BLASes, polarized, path length 20; photon count sized for the oracle"""
+    n = 6000
+    res = _both(S.config5_suzanne_grid, batch=n, n_side=10, polarized=True, stats=True, track=True)
+    assert res[1][0].scene.info["n_instances"] == 1001
+    assert res[0][2][11] > 0  # media mismatches are counted on both sides
+    _compare(res, n, code_agree=0.99)
+
+
+def test_config3_batches_through_the_scheduler(hip_backend):
+    """BASELINE config 3 as specified: consecutive batches of the polarized cube + torus scene issued by
+    `PipelineScheduler`, the Philox offset advanced by `autoAdvance` BEFORE every batch
+    (/root/reference/src/theia/random.py:278-282: batch k runs at offset (k+1) * nRNGSamples), double-buffered
+    configs 0/1 -- compared batch by batch with the oracle driven the same way"""
+    from theia_amd.hp import pipeline as pl
+
+    n, batches = 20000, 4
+    curves, offsets = {}, {}
+    for name, be in (("oracle", OracleBackend(threads=8)), ("hip", hip_backend)):
+        prev = _backend._backend
+        _backend._backend = be
+        try:
+            sc = S.config3_cube_torus(batch=n, polarized=True)
+            got = []
+            sched = pl.PipelineScheduler(pl.Pipeline(sc.stages()), processFn=lambda c, b, a: got.append((c, b, sc.response.result(c).copy())))
+            sched.schedule([{}] * batches)
+            sched.wait()
+            sched.destroy()
+            assert [(c, b) for c, b, _ in got] == [(k % 2, k) for k in range(batches)]
+            curves[name] = [h for _, _, h in got]
+            offsets[name] = sc.rng.offset
+            assert sc.rng.offset == batches * sc.tracer.nRNGSamples
+        finally:
+            _backend._backend = prev
+    for k in range(batches):
+        ho, hg = curves["oracle"][k], curves["hip"][k]
+        assert ho.sum() > 0 and np.abs(hg - ho).max() <= 2e-3 * ho.sum(), k
+    # the batches differ from each other by far more than the backends do (they use different random numbers)
+    assert np.abs(curves["hip"][0] - curves["hip"][1]).max() > 20 * np.abs(curves["hip"][0] - curves["oracle"][0]).max()
+    # batch k on its own, at offset (k+1) * nRNGSamples, reproduces the scheduler's batch k
+    sc = S.config3_cube_torus(batch=n, polarized=True)
+    sc.rng.autoAdvance = 0
+    sc.rng.offset = 3 * sc.tracer.nRNGSamples
+    alone = S.run_batches(sc, 1)[0]
+    assert np.abs(alone - curves["hip"][2]).max() <= 1e-5 * alone.sum()
+
+
 def test_production_kernel_equals_instrumented(hip_backend):
     """the un-instrumented kernel (what bench.py times) produces the same light curve"""
     n = 50000

@@ -1,6 +1,7 @@
 """Host-side mirror of the reference's module API: signatures, formulas, stage
-parameters, pipeline protocol, error behaviour.
-Runs on the oracle stand-in backend -- no GPU."""
+parameters, pipeline protocol, error behaviour. The host-only
+checks run on the oracle stand-in; the flows of the three example notebooks (and the event
+counters) run on the oracle and, with -m gpu, on the HIP library."""
 import numpy as np
 import pytest
 
@@ -107,7 +108,7 @@ def test_unsupported_components_raise_clearly(oracle_backend):
         HistogramHitResponse(UniformValueResponse(), nBins=10000)
 
 
-def test_pipeline_and_scheduler_example01_flow(oracle_backend):
+def test_pipeline_and_scheduler_example01_flow(backend):
     """examples/01_volume_tracing.ipynb cells 24-38 on BASELINE config 1 (plumbing, CPU)"""
     sc = S.config1_volume(20_000)
     pipeline = pl.Pipeline(sc.tracer.collectStages())
@@ -146,7 +147,7 @@ def test_scheduler_surfaces_errors(oracle_backend):
     scheduler.destroy()
 
 
-def test_statistics_callback_counts(oracle_backend):
+def test_statistics_callback_counts(backend):
     """event counters add up (reference tests/test_trace.py:947-1045)"""
     n = 5000
     sc = S.config2_sphere(n, stats=True)
@@ -218,7 +219,7 @@ def test_scene_validation(oracle_backend):
     assert sc.medium == 0 and sc.bbox.diagonal == pytest.approx(np.sqrt(3) * 2000.0)
 
 
-def test_example02_scene_tracing_flow(oracle_backend):
+def test_example02_scene_tracing_flow(backend):
     """examples/02_scene_tracing.ipynb (cells 3-10, reduced batch): media by name, vacuum source medium,
     nested glass spheres around the light, detector sphere with a target guide, scheduler"""
     import hephaistos.pipeline as hpl
@@ -280,7 +281,7 @@ def test_example02_scene_tracing_flow(oracle_backend):
     assert 10.0 <= first <= 25.0
 
 
-def test_example03_shared_stages_between_pipelines(oracle_backend):
+def test_example03_shared_stages_between_pipelines(backend):
     """examples/03_multiple_lightsources.ipynb: two tracers share target, wavelength source, response
     and RNG; a scheduler feeds two named pipelines. The shared response must return the result of the
     pipeline that just ran."""

@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import scenarios as S
+from theia_amd import workloads as S
 n = 100_000_000
 sc = S.config2_sphere(batch=n, stats=True)
 h = S.run_batches(sc, 1)[0]

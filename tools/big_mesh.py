@@ -6,7 +6,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import scenarios as S
+from theia_amd import workloads as S
 
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 levels = [int(a) for a in sys.argv[2:]] or [0, 2, 3, 4, 5]

@@ -201,7 +201,7 @@ def main():
         meshes[f"{name}/vertices"] = v.astype(np.float32)
         meshes[f"{name}/faces"] = f.astype(np.uint32)
         print(name, v.shape, f.shape)
-    np.savez_compressed(os.path.join(OUT, "meshes.npz"), **meshes)
+    np.savez_compressed(os.path.join(REPO, "theia_amd", "data", "meshes.npz"), **meshes)
 
 
 if __name__ == "__main__":

@@ -4,7 +4,7 @@ import ctypes as C, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import scenarios as S
+from theia_amd import workloads as S
 from theia_amd import _backend, _capi
 from theia_amd.scene import Transform
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1 << 20

@@ -9,7 +9,7 @@ sys.path.insert(0, ROOT)
 sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 
-import scenarios as S
+from theia_amd import workloads as S
 from theia_amd import _backend
 
 

@@ -4,7 +4,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import scenarios as S
+from theia_amd import workloads as S
 import theia.random as TRN
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 10_000_000
 for name, rng in (("philox", None), ("sobol", TRN.SobolQRNG(seed=0xC0FFEE, advanceSeed=7))):

@@ -6,7 +6,7 @@ import os, sys, time
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import scenarios as S
+from theia_amd import workloads as S
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 gen = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)

@@ -5,7 +5,7 @@ import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
-import scenarios as S
+from theia_amd import workloads as S
 for make, name in ((S.config2_sphere, "config2"), (S.config3_cube_torus, "config3"), (S.config5_suzanne_grid, "config5")):
     for n in (1, 63, 64, 65, 1000, 4097, 100_003, 1_000_001):
         if name == "config5" and n > 200_000:
