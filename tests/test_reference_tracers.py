@@ -542,7 +542,7 @@ def _record(kind, polarized):
         run_once(scene_photons(keep, rec, none, polarized=polarized, n=4 * N))
     else:  # "volume-photon"
         keep = Water()
-        run_once(volume_photons(keep, rec, none, polarized=polarized, n=4 * N))
+        run_once(volume_photons(keep, rec, none, polarized=polarized, n=16 * N))  # ~1 % of the photons are detected
     return _sorted_hits(rec), keep
 
 
