@@ -188,6 +188,9 @@ enum {
     THX_FLAG_RNG_SOBOL             = 1u << 24, /* SobolQRNG (random.py:285-352, random.sobol.glsl) instead of PhiloxRNG;
                                                   its seed travels in thx_philox_params.key[0] (`offset` is unused
                                                   by the reference's shader as well) */
+    THX_FLAG_TARGET_MISS_INFINITE  = 1u << 25, /* DiskTarget / FlatTarget: report a missed outline (or a plane behind the ray) as infinitely
+                                                far. Default (flag clear) = the reference: target.disk.glsl:60 / target.flat.glsl:66 return the
+                                                distance to the plane regardless, and tracer.volume.forward.glsl:167 stops the ray there */
     THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
                                                   absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;

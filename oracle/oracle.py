@@ -38,6 +38,7 @@ FLAG_TARGET_FLAT = 1 << 21
 FLAG_GUIDE_DISK = 1 << 22
 FLAG_GUIDE_FLAT = 1 << 23
 FLAG_RNG_SOBOL = 1 << 24
+FLAG_TARGET_MISS_INFINITE = 1 << 25
 TRACK_WORDS = 20
 N_STATS = 20
 

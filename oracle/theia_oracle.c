@@ -1063,6 +1063,7 @@ static float intersectSphereFar(vec3 center, float radius, vec3 origin, vec3 dir
 
 static int g_target_inner = 0; /* set per trace from ORC_FLAG_TARGET_INNER */
 static int g_target_flat = 0;  /* 1: DiskTarget, 2: FlatTarget (ORC_FLAG_TARGET_DISK / _FLAT) */
+static int g_target_miss_inf = 0; /* ORC_FLAG_TARGET_MISS_INFINITE: plane targets report a miss as infinitely far */
 
 /* util.sample.glsl:31-56: concentric mapping of the unit square onto the unit disk */
 static vec3 sampleUnitDisk(float u0, float u1) {
@@ -1124,13 +1125,13 @@ static TargetSample intersectTargetPlane(const orc_target_params* tp, vec3 obser
     TargetSample s;
     memset(&s, 0, sizeof(s));
     s.position = pos; s.normal = v_scale(V3(tp->normal[0], tp->normal[1], tp->normal[2]), side);
-    /* DEVIATION from target.disk.glsl:60 / target.flat.glsl:66, which report the distance to the plane
-     * even when the outline is missed or the plane lies behind the ray: the tracers take
-     * min(hit.dist, free path) (tracer.volume.forward.glsl:167), so the reference stops every ray at
-     * the infinite plane and walks rays that point away from it BACKWARDS onto it (negative distance,
-     * earlier time, exp(+mu_e d) contribution). No test or example of the reference traces with these
-     * targets. A miss is a miss here: infinite distance, like createTargetSampleMiss(). */
-    s.dist = valid ? t : INFINITY;
+    /* target.disk.glsl:60 / target.flat.glsl:66 report the distance to the PLANE also when the outline is
+     * missed or the plane lies behind the ray, and the tracers take min(hit.dist, free path)
+     * (tracer.volume.forward.glsl:167): every ray stops at the infinite plane, rays pointing away
+     * from it walk backwards onto it (negative distance). That is the default here as well (results
+     * identical to the reference's). ORC_FLAG_TARGET_MISS_INFINITE opts into the repaired behaviour:
+     * a miss is infinitely far, like createTargetSampleMiss(). */
+    s.dist = (valid || !g_target_miss_inf) ? t : INFINITY;
     s.objPosition = localPos; s.objNormal = V3(0.0f, 0.0f, side);
     s.prob = tp->hemisphereProb * (valid ? 1.0f : 0.0f); s.valid = valid;
     s.worldToObj = w2o;
@@ -2246,6 +2247,7 @@ int orc_trace_volume(const orc_common* c, const orc_volume_trace_params* t,
     x.use_global_medium = 1;
     g_target_inner = (c->flags & ORC_FLAG_TARGET_INNER) != 0;
     g_target_flat = (c->flags & ORC_FLAG_TARGET_DISK) ? 1 : ((c->flags & ORC_FLAG_TARGET_FLAT) ? 2 : 0);
+    g_target_miss_inf = (c->flags & ORC_FLAG_TARGET_MISS_INFINITE) != 0;
     x.global_medium = (uint64_t)t->medium[0] | ((uint64_t)t->medium[1] << 32);
     x.prop = t->propagation;
     VolArgs a = {t, target};
@@ -2348,6 +2350,7 @@ void orc_probe_target(const orc_philox_params* philox, uint32_t flags, const orc
     x.c = &c;
     g_target_inner = (flags & ORC_FLAG_TARGET_INNER) != 0;
     g_target_flat = (flags & ORC_FLAG_TARGET_DISK) ? 1 : ((flags & ORC_FLAG_TARGET_FLAT) ? 2 : 0);
+    g_target_miss_inf = (flags & ORC_FLAG_TARGET_MISS_INFINITE) != 0;
     for (uint32_t i = 0; i < n; ++i) {
         uint32_t dim = 0;
         vec3 observer, direction;
@@ -2362,7 +2365,7 @@ void orc_probe_target(const orc_philox_params* philox, uint32_t flags, const orc
         uint32_t occ = isOccludedByTarget(target, observer) ? 1u : 0u;
         memcpy(&o[24], &occ, 4);
     }
-    g_target_inner = 0; g_target_flat = 0;
+    g_target_inner = 0; g_target_flat = 0; g_target_miss_inf = 0;
 }
 void orc_probe_guide(const orc_philox_params* philox, uint32_t flags, const orc_guide_params* guide,
                      const float box_min[3], const float box_max[3], uint32_t n, float* out) {

@@ -114,7 +114,7 @@ class OracleBackend:
                                                      capi.FLAG_LIGHT_HOST | capi.FLAG_LIGHT_QUEUE_POLARIZED | capi.FLAG_WAVELENGTH_HOST |
                                                      capi.FLAG_LIGHT_CONE | capi.FLAG_LIGHT_POLARIZED | capi.FLAG_WAVELENGTH_FUNCTION |
                                                      capi.FLAG_TARGET_DISK | capi.FLAG_TARGET_FLAT | capi.FLAG_GUIDE_DISK | capi.FLAG_GUIDE_FLAT |
-                                                     capi.FLAG_RNG_SOBOL))
+                                                     capi.FLAG_RNG_SOBOL | capi.FLAG_TARGET_MISS_INFINITE))
         photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE

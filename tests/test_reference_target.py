@@ -215,8 +215,8 @@ def test_plane_guides(backend, kind):
 def traced_plane_target(kind):
     where, facing = (5.0, 2.0, -8.0) * u.m, (-0.6, -0.5, 0.62)
     if kind == "disk":
-        return TT.DiskTarget(position=where, radius=4.0 * u.m, normal=facing, up=(0.0, 0.0, 1.0))
-    return TT.FlatTarget(width=6.0 * u.m, length=8.0 * u.m, position=where, direction=facing, up=(0.0, 0.0, 1.0))
+        return TT.DiskTarget(position=where, radius=4.0 * u.m, normal=facing, up=(0.0, 0.0, 1.0), missIsInfinite=True)
+    return TT.FlatTarget(width=6.0 * u.m, length=8.0 * u.m, position=where, direction=facing, up=(0.0, 0.0, 1.0), missIsInfinite=True)
 
 
 def _volume_case(target, *, mis: bool, n=64 * 1024, polarized=False):
@@ -254,19 +254,21 @@ def test_volume_tracer_with_plane_targets_is_unbiased(backend, kind):
 def test_direct_light_on_plane_targets_matches_the_analytic_integral(backend, kind, mis):
     """isotropic source 3 m above the target's centre in a purely absorbing medium: the detected
     share of the budget is (1 / 4 pi) * integral over the area of cos / d^2 * exp(-mu_a d). This
-    pins the deviation documented in `intersectTargetPlane`: with the reference's miss distance
-    every ray that crosses the target's plane outside the outline would stop there."""
+    pins the `missIsInfinite=True` extension (THX_FLAG_TARGET_MISS_INFINITE): with the reference's miss
+    distance -- the default, pinned by `test_plane_target_default_is_the_reference_miss_distance` --
+    every ray that crosses the target's plane outside the outline stops there."""
     n, h, mu_a, budget = 256 * 1024, 3.0, 0.05, 1.0e4
     medium = S.HomogeneousModel(n=1.33, mu_a=mu_a / u.m, mu_s=1e-9 / u.m, g=0.0).createMedium()
     store = theia.material.MaterialStore([], media=[medium])
     centre, axis = np.array((5.0, 2.0, -8.0)), np.array((-0.6, -0.5, 0.62))
     axis /= np.linalg.norm(axis)
     if kind == "disk":
-        target = TT.DiskTarget(position=tuple(centre), radius=4.0 * u.m, normal=tuple(axis), up=(0.0, 0.0, 1.0))
+        target = TT.DiskTarget(position=tuple(centre), radius=4.0 * u.m, normal=tuple(axis), up=(0.0, 0.0, 1.0), missIsInfinite=True)
         x, y = np.meshgrid(np.linspace(-4, 4, 1601), np.linspace(-4, 4, 1601))
         inside = x**2 + y**2 <= 16.0
     else:
-        target = TT.FlatTarget(width=6.0 * u.m, length=8.0 * u.m, position=tuple(centre), direction=tuple(axis), up=(0.0, 0.0, 1.0))
+        target = TT.FlatTarget(width=6.0 * u.m, length=8.0 * u.m, position=tuple(centre), direction=tuple(axis), up=(0.0, 0.0, 1.0),
+                               missIsInfinite=True)
         x, y = np.meshgrid(np.linspace(-3, 3, 1201), np.linspace(-4, 4, 1601))
         inside = np.ones_like(x, dtype=bool)
     d = np.sqrt(x**2 + y**2 + h**2)
@@ -281,6 +283,45 @@ def test_direct_light_on_plane_targets_matches_the_analytic_integral(backend, ki
     pl.runPipeline(tracer.collectStages())
     got = response.result(0).sum()
     assert abs(got / want - 1.0) < 0.02, (got, want)
+
+
+@pytest.mark.parametrize("kind", ["disk", "flat"])
+@pytest.mark.parametrize("repaired", [False, True])
+def test_plane_target_default_is_the_reference_miss_distance(backend, kind, repaired):
+    """What the first step of a volume tracer does with a plane target, photon by photon (event dump).
+    Default = the reference's shaders: `intersectTarget` returns the distance to the target's PLANE whether
+    or not the outline is hit (target.disk.glsl:60, target.flat.glsl:66) and `trace()` travels
+    min(hit.dist, free path) (tracer.volume.forward.glsl:167) -- so with an unbounded free path EVERY photon
+    ends its first step on the plane, also those that started out away from it (negative distance).
+    `missIsInfinite=True` (this backend's extension): photons that miss the outline leave the scene."""
+    n = 8192
+    medium = S.HomogeneousModel(n=1.33, mu_a=0.01 / u.m, mu_s=1e-9 / u.m, g=0.0).createMedium()
+    store = theia.material.MaterialStore([], media=[medium])
+    centre, axis = np.array((5.0, 2.0, -8.0)), np.array((-0.6, -0.5, 0.62))
+    axis /= np.linalg.norm(axis)
+    if kind == "disk":
+        target = TT.DiskTarget(position=tuple(centre), radius=4.0 * u.m, normal=tuple(axis), up=(0.0, 0.0, 1.0), missIsInfinite=repaired)
+    else:
+        target = TT.FlatTarget(width=6.0 * u.m, length=8.0 * u.m, position=tuple(centre), direction=tuple(axis), up=(0.0, 0.0, 1.0),
+                               missIsInfinite=repaired)
+    tracer = theia.trace.VolumeForwardTracer(
+        n, theia.light.SphericalLightSource(position=tuple(centre + 3.0 * axis), budget=1.0, timeRange=(0.0, 1.0) * u.ns), target,
+        theia.light.ConstWavelengthSource(500.0 * u.nm), theia.response.EmptyResponse(), PhiloxRNG(key=0xFACADE),
+        medium=store.media["homogenous"], nScattering=2, scatterCoefficient=0.0, disableTargetSampling=True, maxTime=1.0 * u.ms,
+        trackEvents=True)
+    pl.runPipeline(tracer.collectStages())
+    dump = tracer.program.read_track(n)
+    code = dump[:, 1, 0].astype(int)
+    height = (dump[:, 1, 1:4].astype(np.float64) - centre) @ axis  # distance of the first step's end from the plane
+    detected, scattered, lost = code == 4, code == 2, code == -1
+    assert detected.sum() > 100 and np.abs(height[detected]).max() < 1e-3
+    if repaired:
+        assert lost.sum() > 100 and not scattered.any() and (detected | lost).all()
+    else:
+        went_back = dump[:, 1, 7] < dump[:, 0, 7]  # time ran backwards: the plane lay behind the photon
+        # (the few photons lost here flew nearly parallel to the plane: they meet it beyond the 1 km trace box)
+        assert scattered.sum() > 100 and went_back.sum() > 100 and lost.sum() < 0.01 * n
+        assert np.abs(height[scattered]).max() < 1e-3
 
 
 @pytest.mark.parametrize("kind", ["disk", "flat"])

@@ -22,7 +22,7 @@ __all__ = [
     "FLAG_DISABLE_VOLUME_BORDER", "FLAG_HIT_USE_TRANSMITTED", "FLAG_WAVELENGTH_UNIFORM",
     "FLAG_STATISTICS", "FLAG_TRACK", "FLAG_LIGHT_PENCIL", "FLAG_TARGET_INNER", "FLAG_PHOTON", "FLAG_KERNEL_HISTOGRAM", "EXPORTED_SYMBOLS",
     "FLAG_LIGHT_HOST", "FLAG_LIGHT_QUEUE_POLARIZED", "FLAG_WAVELENGTH_HOST", "FLAG_LIGHT_CONE", "FLAG_LIGHT_POLARIZED",
-    "FLAG_WAVELENGTH_FUNCTION", "TRACER_LIGHT_SAMPLER", "FLAG_TARGET_DISK", "FLAG_TARGET_FLAT", "FLAG_GUIDE_DISK", "FLAG_GUIDE_FLAT", "FLAG_RNG_SOBOL",
+    "FLAG_WAVELENGTH_FUNCTION", "TRACER_LIGHT_SAMPLER", "FLAG_TARGET_DISK", "FLAG_TARGET_FLAT", "FLAG_TARGET_MISS_INFINITE", "FLAG_GUIDE_DISK", "FLAG_GUIDE_FLAT", "FLAG_RNG_SOBOL",
 ]
 
 TRACER_VOLUME_FORWARD = 0
@@ -53,6 +53,7 @@ FLAG_LIGHT_POLARIZED = 1 << 18
 FLAG_WAVELENGTH_FUNCTION = 1 << 19
 FLAG_TARGET_DISK = 1 << 20
 FLAG_TARGET_FLAT = 1 << 21
+FLAG_TARGET_MISS_INFINITE = 1 << 25
 FLAG_GUIDE_DISK = 1 << 22
 FLAG_GUIDE_FLAT = 1 << 23
 FLAG_RNG_SOBOL = 1 << 24

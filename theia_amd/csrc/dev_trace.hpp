@@ -611,7 +611,7 @@ THX_DEV m3 ldm3(const THX_KERNARG float* m) {
 THX_DEV float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
 
 // target.disk.glsl:43-66 / target.flat.glsl:47-72
-THX_DEV TargetSample intersectTargetPlane(const thx_target_params& tp, f3 observer, f3 direction, bool disk) {
+THX_DEV TargetSample intersectTargetPlane(const thx_target_params& tp, f3 observer, f3 direction, bool disk, bool missInfinite) {
     const m3 o2w = ldm3(tp.objToWorld);
     const m3 w2o = transpose(o2w);
     const f3 center = ld3(tp.position);
@@ -626,12 +626,13 @@ THX_DEV TargetSample intersectTargetPlane(const thx_target_params& tp, f3 observ
     TargetSample s;
     s.position = mul(o2w, localPos) + center;
     s.normal = ld3(tp.normal) * side;
-    // DEVIATION from target.disk.glsl:60 / target.flat.glsl:66, which report the distance to the plane
-    // even when the outline is missed or the plane lies behind the ray: the tracers take
-    // min(hit.dist, free path) (tracer.volume.forward.glsl:167), so the reference stops every ray at
-    // the infinite plane and walks rays pointing away from it backwards onto it (negative distance).
-    // A miss is a miss here: infinite distance, like createTargetSampleMiss() (oracle: same).
-    s.dist = valid ? t : INFINITY;
+    // target.disk.glsl:60 / target.flat.glsl:66 report the distance to the PLANE also when the outline is
+    // missed or the plane lies behind the ray, and the tracers take min(hit.dist, free path)
+    // (tracer.volume.forward.glsl:167): every ray stops at the infinite plane, rays pointing away from
+    // it walk backwards onto it. Kept as the default (results identical to the reference's);
+    // THX_FLAG_TARGET_MISS_INFINITE opts into the repaired behaviour: a miss is infinitely far, like
+    // createTargetSampleMiss() (oracle: same switch).
+    s.dist = (valid || !missInfinite) ? t : INFINITY;
     s.prob = tp.hemisphereProb * (valid ? 1.0f : 0.0f);
     s.valid = valid;
     s.objPosition = localPos;
@@ -644,7 +645,7 @@ THX_DEV TargetSample intersectTargetPlane(const thx_target_params& tp, f3 observ
 // target.sphere.glsl:45-78 (objPosition = objNormal = normal, worldToObj = 1/r);
 // inner: target.sphere.inner.glsl:36-57 (seen from inside: far root, normal towards the centre)
 THX_DEV TargetSample intersectTarget(const thx_target_params& tp, f3 observer, f3 direction, uint32_t flags) {
-    if (targetIsPlane(flags)) return intersectTargetPlane(tp, observer, direction, (flags & THX_FLAG_TARGET_DISK) != 0u);
+    if (targetIsPlane(flags)) return intersectTargetPlane(tp, observer, direction, (flags & THX_FLAG_TARGET_DISK) != 0u, (flags & THX_FLAG_TARGET_MISS_INFINITE) != 0u);
     f3 center = ld3(tp.position);
     TargetSample s;
     s.offset = ld3(tp.invPos);

@@ -101,8 +101,9 @@ class FlatTarget(Target):
                     ("_objToWorld", mat3)]
 
     def __init__(self, *, width: float = 1.0 * u.cm, length: float = 1.0 * u.cm, position=(0.0, 0.0, 0.0),
-                 direction=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0)) -> None:
+                 direction=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), missIsInfinite: bool = False) -> None:
         super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"direction", "up"})
+        self.missIsInfinite = missIsInfinite  # extension, see `targetFlags`
         self.direction = direction
         self.up = up
         self.setParams(width=width, length=length, position=position)
@@ -127,8 +128,10 @@ class DiskTarget(Target):
     class TargetParams(Structure):
         _fields_ = [("position", vec3), ("radius", c_float), ("_normal", vec3), ("_prob", c_float), ("_objToWorld", mat3)]
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m, normal=(0.0, 0.0, 1.0), up=None) -> None:
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m, normal=(0.0, 0.0, 1.0), up=None,
+                 missIsInfinite: bool = False) -> None:
         super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"normal", "up"})
+        self.missIsInfinite = missIsInfinite  # extension, see `targetFlags`
         self.normal = normal
         self.up = up
         self.setParams(position=position, radius=radius)
@@ -231,9 +234,18 @@ _GUIDES = (SphereTargetGuide, DiskTargetGuide, FlatTargetGuide)
 
 
 def targetFlags(target) -> int:
+    """THX_FLAG_* bits selecting the target's kernel branch. Plane targets (`DiskTarget`, `FlatTarget`)
+    behave like the reference's shaders by default: `intersectTarget` reports the distance to the
+    target's PLANE even where the outline is missed or the plane lies behind the ray, and the volume
+    tracers stop the ray there (target.disk.glsl:60, target.flat.glsl:66, tracer.volume.forward.glsl:167).
+    `missIsInfinite=True` on the target (an extension of this backend) reports such a miss as
+    infinitely far instead."""
     from . import _capi as capi
 
-    return {InnerSphereTarget: capi.FLAG_TARGET_INNER, DiskTarget: capi.FLAG_TARGET_DISK, FlatTarget: capi.FLAG_TARGET_FLAT}.get(type(target), 0)
+    flags = {InnerSphereTarget: capi.FLAG_TARGET_INNER, DiskTarget: capi.FLAG_TARGET_DISK, FlatTarget: capi.FLAG_TARGET_FLAT}.get(type(target), 0)
+    if getattr(target, "missIsInfinite", False):
+        flags |= capi.FLAG_TARGET_MISS_INFINITE
+    return flags
 
 
 def guideFlags(guide) -> int:
