@@ -28,10 +28,13 @@ extern "C" {
 #define THX_ERR_HIP (-2)         /* HIP runtime error */
 #define THX_ERR_NO_DEVICE (-3)   /* no usable gfx950 device */
 #define THX_ERR_UNSUPPORTED (-4) /* component outside the supported closed set */
+#define THX_ERR_DEVICE (-5)      /* a kernel reported an error through the tracer's device error word (THX_DEVERR_*) */
+#define THX_DEVERR_WATCHDOG 1u   /* the staged kernel's scheduler watchdog tripped: the batch is incomplete */
 
 typedef struct thx_ctx thx_ctx;
 typedef struct thx_scene thx_scene;
 typedef struct thx_tracer thx_tracer;
+typedef struct thx_comm thx_comm;
 
 #pragma pack(push, 4)
 
@@ -301,6 +304,12 @@ int thx_tracer_run(thx_tracer* tracer, uint32_t cfg, const thx_run_params* param
 int thx_tracer_reduce(thx_tracer* tracer, uint32_t cfg, float norm, uint64_t d_out, void* stream);
 /* hp.retrieveTensor + response.result(i) (response.py:1184-1186, 1357-1365) */
 int thx_tracer_read_hist(thx_tracer* tracer, uint32_t cfg, float* out, uint32_t n_bins);
+/* Waits for the tracer's launches and returns THX_ERR_DEVICE if a kernel flagged an error in the tracer's
+ * device error word (THX_DEVERR_*; the word is cleared). Every thx_tracer_read_* does the same check; call
+ * this after thx_tracer_reduce into an EXTERNAL buffer (d_out != 0), which the library never reads back.
+ * (The reference counts device errors and never raises, callback.stat.glsl:66-69; a scheduler watchdog has
+ * no counterpart there -- it must not pass for a result.) */
+int thx_tracer_check(thx_tracer* tracer);
 int thx_tracer_hist_device_ptr(thx_tracer* tracer, uint32_t cfg, uint64_t* out);
 /* EventStatisticCallback (trace.py:77-187) */
 int thx_tracer_read_stats(thx_tracer* tracer, uint64_t* out, uint32_t n);
@@ -367,6 +376,18 @@ int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flag
  * random_s(base_stream + stream, first_dim + sample); sample_dim 2: out[stream][sample][2] = random2D_s */
 int thx_rng_fill_sobol(thx_ctx* ctx, uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim,
                        uint32_t n_samples, uint32_t sample_dim, float* out_f32);
+
+/* ---- multi-GPU exchange step (the reference is single-device, nothing to replace):
+ * photons shard by index range (thx_run_params.photon_offset), the per-GPU time histograms are summed with
+ * ONE RCCL all-reduce. RCCL is loaded on first use. Rank 0 makes the id (thx_comm_unique_id) and hands the
+ * 128 bytes to the other ranks by any host channel (file, socket, torch.distributed store); every rank then
+ * calls thx_comm_init with its own context. thx_hist_allreduce sums n_floats f32 at device address d_hist
+ * in place over all ranks, on `stream` (NULL = the context's stream); it is asynchronous like a launch. */
+#define THX_COMM_ID_BYTES 128
+int thx_comm_unique_id(uint8_t out[THX_COMM_ID_BYTES]);
+int thx_comm_init(thx_ctx* ctx, const uint8_t unique_id[THX_COMM_ID_BYTES], int rank, int world_size, thx_comm** out);
+int thx_comm_destroy(thx_comm* comm);
+int thx_hist_allreduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, void* stream);
 
 #ifdef __cplusplus
 }

@@ -293,17 +293,68 @@ def test_sharding_is_seed_identical(hip_backend):
 
 
 def test_scheduler_watchdog_is_loud(hip_backend, monkeypatch):
-    """a tripped scheduler watchdog (forced through the THX_TEST_ABORT hook) must not return a
-    plausible partial light curve: the kernel poisons its slabs, reading the histogram fails"""
+    """a tripped scheduler watchdog (forced through the THX_TEST_ABORT hook) must not return a plausible
+    partial result through ANY readback: the kernel raises the tracer's device error word (and poisons
+    its slabs); histogram, hit queue, statistics, track and `thx_tracer_check` (the check after a
+    reduction into an external buffer, bench.py's path) all fail"""
+    import theia.response
+    import theia.trace
     from theia_amd._capi import ThxError
 
     monkeypatch.setenv("THX_TEST_ABORT", "1")
     sc = S.config2_sphere(batch=10000)
     with pytest.raises(ThxError, match="watchdog"):
         S.run_batches(sc, 1)
+    # ... the error word is cleared by the failed readback: with the hook still set the next batch fails again
+    with pytest.raises(ThxError, match="watchdog"):
+        S.run_batches(sc, 1)
+
+    # a recording tracer has no histogram to poison
+    sc = S.config2_sphere(batch=10000, stats=True, track=True)
+    tr = sc.tracer
+    recorder = theia.response.HitRecorder()
+    rec = theia.trace.SceneForwardTracer(10000, sc.light, sc.photons, recorder, sc.rng, sc.scene, maxPathLength=10, targetGuide=sc.guide,
+                                         scatterCoefficient=0.01, maxTime=600.0)
+    from theia_amd.hp.pipeline import Pipeline
+    with pytest.raises(ThxError, match="watchdog"):
+        Pipeline(rec.collectStages()).run(0)
+    # statistics / track / explicit check after a bench-style run + reduce
+    Pipeline(sc.stages()).update(0)  # commits the parameter blocks of config 0
+    for read in (lambda: tr.program.read_stats(), lambda: tr.program.read_track(10000), lambda: hip_backend.tracer_check(tr.program.handle)):
+        hip_backend.tracer_run(tr.program.handle, 0, tr._assemble(0))
+        hip_backend.tracer_reduce(tr.program.handle, 0, 1.0)
+        with pytest.raises(ThxError, match="watchdog"):
+            read()
+
     monkeypatch.delenv("THX_TEST_ABORT")
     sc = S.config2_sphere(batch=10000)
     assert np.isfinite(S.run_batches(sc, 1)[0]).all()
+    hip_backend.tracer_check(sc.tracer.program.handle)
+
+
+def test_rccl_allreduce_through_the_c_abi(hip_backend):
+    """thx_comm_unique_id / thx_comm_init / thx_hist_allreduce: a communicator of one rank
+    on this box's single GPU -- the sum over ranks of a histogram is the histogram. (More ranks need more
+    GPUs: bench.py --gpus N is the multi-rank path, tests/test_distributed_cpu.py its gloo rehearsal.)"""
+    import ctypes as C
+
+    from theia_amd import _capi as capi
+
+    uid = hip_backend.comm_unique_id()
+    assert len(uid) == 128 and any(uid)
+    comm = hip_backend.comm_init(uid, 0, 1)
+    curve = np.linspace(0.0, 3.0, 100, dtype=np.float32)
+    addr = C.c_uint64()
+    capi.check(capi.lib().thx_mem_alloc(hip_backend._ctx, curve.nbytes, C.byref(addr)))
+    capi.check(capi.lib().thx_mem_upload(hip_backend._ctx, addr.value, curve.ctypes.data_as(C.c_void_p), curve.nbytes))
+    hip_backend.hist_allreduce(comm, addr.value, curve.size)
+    back = np.empty_like(curve)
+    capi.check(capi.lib().thx_mem_download(hip_backend._ctx, back.ctypes.data_as(C.c_void_p), addr.value, back.nbytes))  # syncs the stream
+    assert np.array_equal(back, curve)
+    capi.check(capi.lib().thx_mem_free(hip_backend._ctx, addr.value))
+    hip_backend.comm_destroy(comm)
+    with pytest.raises(capi.ThxError):
+        hip_backend.comm_init(uid, 3, 2)  # rank outside the world
 
 
 @pytest.mark.parametrize("kernel", ["staged", "lane"])

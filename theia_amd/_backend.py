@@ -148,6 +148,29 @@ class HipBackend:
     def tracer_reduce(self, tracer: int, cfg: int, norm: float, d_out: int = 0, stream: int = 0) -> None:
         capi.check(self._lib.thx_tracer_reduce(C.c_void_p(tracer), int(cfg), float(norm), int(d_out), C.c_void_p(stream) if stream else None))
 
+    def tracer_check(self, tracer: int) -> None:
+        """waits for the tracer's launches; raises ThxError if a kernel flagged a device error"""
+        capi.check(self._lib.thx_tracer_check(C.c_void_p(tracer)))
+
+    # -- multi-GPU exchange step (RCCL through the C ABI) -------------------
+    def comm_unique_id(self) -> bytes:
+        buf = C.create_string_buffer(128)
+        capi.check(self._lib.thx_comm_unique_id(buf))
+        return buf.raw
+
+    def comm_init(self, unique_id: bytes, rank: int, world: int) -> int:
+        if len(unique_id) != 128:
+            raise ValueError("an RCCL unique id has 128 bytes")
+        out = C.c_void_p()
+        capi.check(self._lib.thx_comm_init(self._ctx, C.create_string_buffer(unique_id, 128), int(rank), int(world), C.byref(out)))
+        return out.value
+
+    def comm_destroy(self, comm: int) -> None:
+        capi.check(self._lib.thx_comm_destroy(C.c_void_p(comm)))
+
+    def hist_allreduce(self, comm: int, d_hist: int, n_floats: int, stream: int = 0) -> None:
+        capi.check(self._lib.thx_hist_allreduce(C.c_void_p(comm), int(d_hist), int(n_floats), C.c_void_p(stream) if stream else None))
+
     def tracer_read_hist(self, tracer: int, cfg: int, n_bins: int) -> np.ndarray:
         out = np.empty(int(n_bins), dtype=np.float32)
         capi.check(self._lib.thx_tracer_read_hist(C.c_void_p(tracer), int(cfg), out.ctypes.data_as(C.POINTER(C.c_float)), int(n_bins)))

@@ -185,6 +185,7 @@ _PROTOS = {
     "thx_tracer_run": (c_int, [c_void_p, c_uint32, POINTER(RunParams), c_void_p]),
     "thx_tracer_reduce": (c_int, [c_void_p, c_uint32, c_float, c_uint64, c_void_p]),
     "thx_tracer_read_hist": (c_int, [c_void_p, c_uint32, POINTER(c_float), c_uint32]),
+    "thx_tracer_check": (c_int, [c_void_p]),
     "thx_tracer_hist_device_ptr": (c_int, [c_void_p, c_uint32, POINTER(c_uint64)]),
     "thx_tracer_read_stats": (c_int, [c_void_p, POINTER(c_uint64), c_uint32]),
     "thx_tracer_reset_stats": (c_int, [c_void_p]),
@@ -205,6 +206,10 @@ _PROTOS = {
     "thx_probe_guide": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, POINTER(GuideParams), POINTER(c_float), POINTER(c_float), c_uint32, c_void_p]),
     "thx_rng_fill_sobol": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_float)]),
     "thx_rng_fill": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_float)]),
+    "thx_comm_unique_id": (c_int, [c_void_p]),
+    "thx_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
+    "thx_comm_destroy": (c_int, [c_void_p]),
+    "thx_hist_allreduce": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 

@@ -3,6 +3,7 @@
 // every entry point fails with THX_ERR_NO_DEVICE / THX_ERR_HIP when there is no
 // usable GPU.
 #include <hip/hip_runtime.h>
+#include <dlfcn.h>
 
 #include <algorithm>
 #include <cmath>
@@ -73,6 +74,7 @@ struct thx_tracer {
     float* out[2] = {nullptr, nullptr};
     uint32_t lastGrid[2] = {0, 0};
     unsigned long long* stats = nullptr;
+    uint32_t* devError = nullptr; // device error word (THX_DEVERR_* bits), set by the kernels' exit paths
     unsigned long long* prof = nullptr;
     float* track = nullptr;
     uint32_t* hits = nullptr;     // HitRecorder queue (count + SoA columns) or null
@@ -95,6 +97,21 @@ static size_t hitColumns(const thx_tracer_desc& d) {
     if (d.kind == THX_TRACER_LIGHT_SAMPLER) return (d.flags & THX_FLAG_POLARIZED) ? 15 : 8; // lightsource.queue.glsl:10-30
     if (d.response_kind == THX_RESPONSE_STORE_TIME) return d.hit_polarized ? 2 : 1;
     return d.hit_polarized ? 20 : 13;
+}
+
+// Reads (and clears) the tracer's device error word. The caller has synchronised the device.
+// A tripped scheduler watchdog must never look like a result: every readback goes through here.
+static int deviceErrorCheck(thx_tracer* t) {
+    if (!t->devError) return THX_OK;
+    uint32_t bits = 0;
+    THX_HIP(hipMemcpy(&bits, t->devError, 4, hipMemcpyDeviceToHost));
+    if (bits == 0) return THX_OK;
+    THX_HIP(hipMemsetAsync(t->devError, 0, 4, t->ctx->stream));
+    THX_HIP(hipStreamSynchronize(t->ctx->stream));
+    std::string msg = "device error:";
+    if (bits & THX_DEVERR_WATCHDOG) msg += " the staged kernel's scheduler watchdog tripped (results of this batch are incomplete)";
+    if (bits & ~THX_DEVERR_WATCHDOG) msg += " unknown bits " + std::to_string(bits);
+    return fail(THX_ERR_DEVICE, msg);
 }
 
 extern "C" {
@@ -184,7 +201,10 @@ int thx_mem_upload(thx_ctx* ctx, uint64_t dev_addr, const void* src, size_t nbyt
     if (!ctx || (!src && nbytes) || (dev_addr == 0 && nbytes)) return fail(THX_ERR_INVALID, "null argument");
     if (nbytes == 0) return THX_OK;
     THX_HIP(hipSetDevice(ctx->device));
-    THX_HIP(hipMemcpy((void*)(uintptr_t)dev_addr, src, nbytes, hipMemcpyHostToDevice));
+    // on the context's stream (it is non-blocking: a null-stream copy would not be ordered with
+    // launches in flight that still read the old contents) and complete on return (`src` is the caller's)
+    THX_HIP(hipMemcpyAsync((void*)(uintptr_t)dev_addr, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
+    THX_HIP(hipStreamSynchronize(ctx->stream));
     return THX_OK;
 }
 
@@ -428,6 +448,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
     if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
+    if (e == hipSuccess) e = hipMalloc((void**)&t->devError, 4);
+    if (e == hipSuccess) e = hipMemset(t->devError, 0, 4);
     if (e == hipSuccess) e = hipMalloc((void**)&t->prof, sizeof(unsigned long long) * 48);
     if (e == hipSuccess) e = hipMemset(t->prof, 0, sizeof(unsigned long long) * 48);
     if (e == hipSuccess && (desc->flags & THX_FLAG_TRACK)) {
@@ -487,6 +509,7 @@ int thx_tracer_destroy(thx_tracer* t) {
     }
     if (t->stats) (void)hipFree(t->stats);
     if (t->prof) (void)hipFree(t->prof);
+    if (t->devError) (void)hipFree(t->devError);
     if (t->track) (void)hipFree(t->track);
     if (t->hits) (void)hipFree(t->hits);
     if (t->replayIn) (void)hipFree(t->replayIn);
@@ -560,6 +583,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.lds_nodes_word = (t->desc.n_bins + 3u) & ~3u;
     a.slabs = t->slabs[cfg];
     a.stats = t->stats;
+    a.error = t->devError;
     a.prof = t->prof;
     a.hits = t->hits;
     a.hit_capacity = t->desc.hit_capacity;
@@ -614,12 +638,21 @@ int thx_tracer_read_hist(thx_tracer* t, uint32_t cfg, float* out, uint32_t n_bin
     if (cfg > 1 || n_bins != t->desc.n_bins) return fail(THX_ERR_INVALID, "bad config index or bin count");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
+    if (int rc = deviceErrorCheck(t)) return rc;
     THX_HIP(hipMemcpy(out, t->out[cfg], sizeof(float) * n_bins, hipMemcpyDeviceToHost));
-    // a workgroup whose scheduler watchdog tripped poisons its slab with NaN (dev_staged.hpp)
+    // (second line of defence) a workgroup whose scheduler watchdog tripped also poisons its slab with NaN
     if (t->staged)
         for (uint32_t i = 0; i < n_bins; ++i)
             if (std::isnan(out[i])) return fail(THX_ERR_HIP, "the staged kernel's scheduler watchdog tripped: the light curve is invalid");
     return THX_OK;
+}
+
+int thx_tracer_check(thx_tracer* t) {
+    if (!t) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize());
+    return deviceErrorCheck(t);
 }
 
 int thx_tracer_hist_device_ptr(thx_tracer* t, uint32_t cfg, uint64_t* out) {
@@ -634,6 +667,7 @@ int thx_tracer_read_stats(thx_tracer* t, uint64_t* out, uint32_t n) {
     if (n > THX_N_STATS) n = THX_N_STATS;
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
+    if (int rc = deviceErrorCheck(t)) return rc;
     THX_HIP(hipMemcpy(out, t->stats, sizeof(uint64_t) * n, hipMemcpyDeviceToHost));
     return THX_OK;
 }
@@ -674,6 +708,7 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
     if (!t->hits) return fail(THX_ERR_INVALID, "tracer was not created with the record response");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
+    if (int rc = deviceErrorCheck(t)) return rc;
     // the counter first, then of every column only the entries that were appended (a queue is
     // sized for the worst case, maxHitsPerThread * batch: reading it whole would move ~10x more)
     const size_t cap = t->desc.hit_capacity, columns = hitColumns(t->desc);
@@ -760,6 +795,7 @@ int thx_tracer_read_track(thx_tracer* t, float* out, size_t n_floats) {
     if (n_floats > have) return fail(THX_ERR_INVALID, "track buffer is smaller than requested");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
+    if (int rc = deviceErrorCheck(t)) return rc;
     THX_HIP(hipMemcpy(out, t->track, sizeof(float) * n_floats, hipMemcpyDeviceToHost));
     return THX_OK;
 }
@@ -860,6 +896,104 @@ int thx_rng_fill_sobol(thx_ctx* ctx, uint32_t seed, uint32_t base_stream, uint32
     (void)hipFree(d);
     if (e != hipSuccess) return hipFail(e, "thx_rng_fill_sobol");
     return THX_OK;
+}
+
+} // extern "C"
+
+// ------------------------------------------------------------------ RCCL
+// The one exchange step of the sharded path: sum of the per-GPU time histograms. RCCL is loaded on
+// first use (dlopen), so single-GPU users never map it.
+namespace {
+struct Id128 { char b[128]; }; // ncclUniqueId: passed by value
+struct RcclApi {
+    void* lib = nullptr;
+    int (*getUniqueId)(void*) = nullptr;
+    int (*commInitRank)(void**, int, Id128, int) = nullptr;
+    int (*commDestroy)(void*) = nullptr;
+    int (*allReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    const char* (*getErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+std::mutex g_rcclLock;
+bool loadRccl(std::string& why) {
+    std::lock_guard<std::mutex> guard(g_rcclLock);
+    if (g_rccl.lib) return true;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1", "/opt/rocm/lib/librccl.so"}) {
+        g_rccl.lib = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.lib) break;
+    }
+    if (!g_rccl.lib) { why = std::string("cannot load librccl: ") + dlerror(); return false; }
+    g_rccl.getUniqueId = reinterpret_cast<decltype(g_rccl.getUniqueId)>(dlsym(g_rccl.lib, "ncclGetUniqueId"));
+    g_rccl.commInitRank = reinterpret_cast<decltype(g_rccl.commInitRank)>(dlsym(g_rccl.lib, "ncclCommInitRank"));
+    g_rccl.commDestroy = reinterpret_cast<decltype(g_rccl.commDestroy)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
+    g_rccl.allReduce = reinterpret_cast<decltype(g_rccl.allReduce)>(dlsym(g_rccl.lib, "ncclAllReduce"));
+    g_rccl.getErrorString = reinterpret_cast<decltype(g_rccl.getErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
+    if (!g_rccl.getUniqueId || !g_rccl.commInitRank || !g_rccl.commDestroy || !g_rccl.allReduce) {
+        why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+        dlclose(g_rccl.lib);
+        g_rccl = RcclApi{};
+        return false;
+    }
+    return true;
+}
+int rcclFail(int rc, const char* what) {
+    return fail(THX_ERR_HIP, std::string(what) + ": " + (g_rccl.getErrorString ? g_rccl.getErrorString(rc) : "RCCL error ") + " (" + std::to_string(rc) + ")");
+}
+} // namespace
+
+struct thx_comm {
+    thx_ctx* ctx = nullptr;
+    void* nccl = nullptr;
+    int rank = 0, world = 1;
+};
+
+extern "C" {
+
+int thx_comm_unique_id(uint8_t out[THX_COMM_ID_BYTES]) {
+    if (!out) return fail(THX_ERR_INVALID, "null argument");
+    std::string why;
+    if (!loadRccl(why)) return fail(THX_ERR_UNSUPPORTED, why);
+    static_assert(THX_COMM_ID_BYTES == 128, "ncclUniqueId is 128 bytes");
+    int rc = g_rccl.getUniqueId(out);
+    return rc == 0 ? THX_OK : rcclFail(rc, "ncclGetUniqueId");
+}
+
+int thx_comm_init(thx_ctx* ctx, const uint8_t unique_id[THX_COMM_ID_BYTES], int rank, int world_size, thx_comm** out) {
+    if (!ctx || !unique_id || !out) return fail(THX_ERR_INVALID, "null argument");
+    *out = nullptr;
+    if (world_size < 1 || rank < 0 || rank >= world_size) return fail(THX_ERR_INVALID, "rank / world size out of range");
+    std::string why;
+    if (!loadRccl(why)) return fail(THX_ERR_UNSUPPORTED, why);
+    THX_HIP(hipSetDevice(ctx->device));
+    Id128 id;
+    std::memcpy(id.b, unique_id, 128);
+    void* comm = nullptr;
+    int rc = g_rccl.commInitRank(&comm, world_size, id, rank);
+    if (rc != 0) return rcclFail(rc, "ncclCommInitRank");
+    thx_comm* c = new (std::nothrow) thx_comm();
+    if (!c) { g_rccl.commDestroy(comm); return fail(THX_ERR_INVALID, "out of host memory"); }
+    c->ctx = ctx; c->nccl = comm; c->rank = rank; c->world = world_size;
+    *out = c;
+    return THX_OK;
+}
+
+int thx_comm_destroy(thx_comm* comm) {
+    if (!comm) return THX_OK;
+    (void)hipSetDevice(comm->ctx->device);
+    if (comm->nccl) g_rccl.commDestroy(comm->nccl);
+    delete comm;
+    return THX_OK;
+}
+
+int thx_hist_allreduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, void* stream) {
+    if (!comm || (d_hist == 0 && n_floats)) return fail(THX_ERR_INVALID, "null argument");
+    if (n_floats == 0) return THX_OK;
+    THX_HIP(hipSetDevice(comm->ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : comm->ctx->stream;
+    void* p = (void*)(uintptr_t)d_hist;
+    // ncclFloat32 = 7, ncclSum = 0 (rccl.h); in place
+    int rc = g_rccl.allReduce(p, p, n_floats, 7, 0, comm->nccl, s);
+    return rc == 0 ? THX_OK : rcclFail(rc, "ncclAllReduce");
 }
 
 } // extern "C"

@@ -710,6 +710,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     // a tripped scheduler watchdog (a bug, never seen) poisons the light curve instead of
     // returning a plausible partial one
     const bool aborted = pool.ctr[C_ABORT] != 0u;
+    // ... and raises the tracer's device error word: hit queues, tracks, statistics and reductions into
+    // external buffers have no slab to poison (the host checks the word on every readback)
+    if (aborted && tid == 0 && args.error != nullptr) atomicOr(args.error, THX_DEVERR_WATCHDOG);
 #ifdef THX_STAGE_PROFILE
     if (tid < 48 && args.prof) atomicAdd(&args.prof[tid], reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF)[tid]);
 #endif

@@ -52,6 +52,7 @@ struct LaunchArgs {
     uint32_t light_capacity;
     uint32_t wavelength_capacity;
     unsigned long long* stats; // [THX_N_STATS]
+    uint32_t* error;           // device error word (THX_DEVERR_* bits), read and cleared by the host
     float* track;              // [batch][track_events][THX_TRACK_WORDS] or null
     unsigned long long* prof;  // staged kernel, THX_STAGE_PROFILE builds: [3][16] cycles/rounds/items per stage
     SceneView scene;
