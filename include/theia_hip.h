@@ -372,6 +372,26 @@ int thx_probe_target(thx_ctx* ctx, const thx_philox_params* philox, uint32_t fla
 int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flags, const thx_guide_params* guide,
                     const float box_min[3], const float box_max[3], uint32_t n, float* guide_out);
 
+/* ---- unit probe (replaces the reference's shader unit-test kernels, tests/shader/<name>.test.glsl driven by
+ * tests/test_lookup.py:41-65, test_scatter.py:15-331, test_polarization.py:14-255, test_math.py:8-38): applies ONE
+ * device function of the path to n inputs. in[n][n_in] f32 -> out[n][n_out] f32; `addr` = device address of the
+ * table (LOOKUP) or medium (LOOKUP_MEDIUM, SCATTER_*, PHASE_MATRIX), else 0. Columns per function:
+ *   LOOKUP         in u, nullValue                      out value
+ *   LOOKUP_MEDIUM  in lambda                            out n, vg, mu_s, mu_e
+ *   SCATTER_DIR    in dir3, cos_theta, phi              out dir3
+ *   FRESNEL        in cos_i (signed), n_i, n_t          out r_s, r_p
+ *   SCATTER_PROB   in inDir3, outDir3                   out p
+ *   SCATTER_SAMPLE in inDir3, u0, u1                    out dir3, p
+ *   ROTATE_POLREF  in dir3, ref3, newNormal3            out ref3, cos 2phi, sin 2phi
+ *   ALIGN_POLREF   in dir3, oldRef3, newRef3            out cos 2phi, sin 2phi
+ *   PHASE_MATRIX   in cos_theta, cos 2phi, sin 2phi, stokes4   out stokes4 = phase * rotate * stokes
+ *   POLARIZER      in p, s, stokes4                     out stokes4
+ *   SIGN_BIT       in x                                 out +-1 */
+enum { THX_UNIT_LOOKUP = 0, THX_UNIT_LOOKUP_MEDIUM, THX_UNIT_SCATTER_DIR, THX_UNIT_FRESNEL, THX_UNIT_SCATTER_PROB,
+       THX_UNIT_SCATTER_SAMPLE, THX_UNIT_ROTATE_POLREF, THX_UNIT_ALIGN_POLREF, THX_UNIT_PHASE_MATRIX, THX_UNIT_POLARIZER,
+       THX_UNIT_SIGN_BIT, THX_UNIT_COUNT };
+int thx_probe_unit(thx_ctx* ctx, uint32_t which, uint64_t addr, const float* in, uint32_t n_in, uint32_t n, float* out, uint32_t n_out);
+
 /* RNGBufferSink over a SobolQRNG (random.sink.glsl with random.sobol.glsl): out[stream][sample] =
  * random_s(base_stream + stream, first_dim + sample); sample_dim 2: out[stream][sample][2] = random2D_s */
 int thx_rng_fill_sobol(thx_ctx* ctx, uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim,

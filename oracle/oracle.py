@@ -146,6 +146,8 @@ def lib() -> C.CDLL:
         L.orc_sample_guide.restype = None
         L.orc_rotate_polref.argtypes = [fp, fp, fp, fp, fp]
         L.orc_rotate_polref.restype = None
+        L.orc_align_polref.argtypes = [fp, fp, fp, fp]
+        L.orc_align_polref.restype = None
         L.orc_polarizer.argtypes = [C.c_float, C.c_float, fp, fp]
         L.orc_polarizer.restype = None
         L.orc_phase_matrix_apply.argtypes = [C.c_uint64, C.c_float, C.c_float, C.c_float, fp, fp]

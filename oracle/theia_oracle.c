@@ -440,6 +440,11 @@ static void alignPolRef(vec3 rayDir, vec3 oldRef, vec3 newRef, float* c, float* 
     *s = 2.0f * cos_phi * sin_phi;
 }
 
+void orc_align_polref(const float dir[3], const float old_ref[3], const float new_ref[3], float out_cs[2]) {
+    alignPolRef(V3(dir[0], dir[1], dir[2]), V3(old_ref[0], old_ref[1], old_ref[2]), V3(new_ref[0], new_ref[1], new_ref[2]),
+                &out_cs[0], &out_cs[1]);
+}
+
 /* polarization.glsl:109-120 applied to a Stokes vector */
 static inline vec4 polarizerApply(float p, float s, vec4 v) {
     float att = p * p + s * s;

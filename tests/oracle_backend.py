@@ -163,6 +163,42 @@ class OracleBackend:
     def rng_fill_sobol(self, seed, base_stream, n_streams, first_dim, n_samples, sample_dim=1):
         return orc.sobol_fill(seed, base_stream, n_streams, first_dim, n_samples, sample_dim)
 
+    def probe_unit(self, name: str, inputs, addr: int = 0) -> np.ndarray:
+        """the oracle's restatement of one shader function applied to every row (counterpart of thx_probe_unit)"""
+        import ctypes as C
+
+        L = orc.lib()
+        n_in, n_out = {"lookup": (2, 1), "lookup_medium": (1, 4), "scatter_dir": (5, 3), "fresnel": (3, 2), "scatter_prob": (6, 1),
+                       "scatter_sample": (5, 4), "rotate_polref": (9, 5), "align_polref": (9, 2), "phase_matrix": (7, 4), "polarizer": (6, 4),
+                       "sign_bit": (1, 1)}[name]
+        x = np.ascontiguousarray(np.asarray(inputs, dtype=np.float32).reshape(-1, n_in))
+        out = np.zeros((x.shape[0], n_out), dtype=np.float32)
+        fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        for r, o in zip(x, out):
+            if name == "lookup":
+                o[0] = L.orc_lookup(addr, float(r[0]), float(r[1]))
+            elif name == "lookup_medium":
+                L.orc_lookup_medium(addr, float(r[0]), fp(o))
+            elif name == "scatter_dir":
+                L.orc_scatter_dir(fp(r[0:3]), float(r[3]), float(r[4]), fp(o))
+            elif name == "fresnel":
+                L.orc_fresnel(float(r[0]), float(r[1]), float(r[2]), fp(o))
+            elif name == "scatter_prob":
+                o[0] = L.orc_scatter_prob(addr, fp(r[0:3]), fp(r[3:6]))
+            elif name == "scatter_sample":
+                L.orc_scatter_sample(addr, fp(r[0:3]), float(r[3]), float(r[4]), fp(o[0:3]), fp(o[3:4]))
+            elif name == "rotate_polref":
+                L.orc_rotate_polref(fp(r[0:3]), fp(r[3:6]), fp(r[6:9]), fp(o[0:3]), fp(o[3:5]))
+            elif name == "align_polref":
+                L.orc_align_polref(fp(r[0:3]), fp(r[3:6]), fp(r[6:9]), fp(o))
+            elif name == "phase_matrix":
+                L.orc_phase_matrix_apply(addr, float(r[0]), float(r[1]), float(r[2]), fp(r[3:7]), fp(o))
+            elif name == "polarizer":
+                L.orc_polarizer(float(r[0]), float(r[1]), fp(r[2:6]), fp(o))
+            else:
+                o[0] = L.orc_sign_bit(float(r[0]))
+        return out
+
     def probe_target(self, philox, flags, target, box_min, box_max, n):
         ph, tg = orc.PhiloxParams(), orc.TargetParams()
         _copy(ph, philox)

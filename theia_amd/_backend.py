@@ -148,6 +148,15 @@ class HipBackend:
     def tracer_reduce(self, tracer: int, cfg: int, norm: float, d_out: int = 0, stream: int = 0) -> None:
         capi.check(self._lib.thx_tracer_reduce(C.c_void_p(tracer), int(cfg), float(norm), int(d_out), C.c_void_p(stream) if stream else None))
 
+    def probe_unit(self, name: str, inputs, addr: int = 0) -> np.ndarray:
+        """one device function of the path applied to every row of `inputs` (thx_probe_unit)"""
+        which, n_in, n_out = capi.UNIT_PROBES[name]
+        x = np.ascontiguousarray(np.asarray(inputs, dtype=np.float32).reshape(-1, n_in))
+        out = np.empty((x.shape[0], n_out), dtype=np.float32)
+        capi.check(self._lib.thx_probe_unit(self._ctx, which, int(addr), x.ctypes.data_as(C.POINTER(C.c_float)), n_in, x.shape[0],
+                                            out.ctypes.data_as(C.POINTER(C.c_float)), n_out))
+        return out
+
     def tracer_check(self, tracer: int) -> None:
         """waits for the tracer's launches; raises ThxError if a kernel flagged a device error"""
         capi.check(self._lib.thx_tracer_check(C.c_void_p(tracer)))

@@ -54,6 +54,10 @@ FLAG_WAVELENGTH_FUNCTION = 1 << 19
 FLAG_TARGET_DISK = 1 << 20
 FLAG_TARGET_FLAT = 1 << 21
 FLAG_TARGET_MISS_INFINITE = 1 << 25
+# thx_probe_unit: function -> (id, input columns, output columns)
+UNIT_PROBES = {"lookup": (0, 2, 1), "lookup_medium": (1, 1, 4), "scatter_dir": (2, 5, 3), "fresnel": (3, 3, 2), "scatter_prob": (4, 6, 1),
+               "scatter_sample": (5, 5, 4), "rotate_polref": (6, 9, 5), "align_polref": (7, 9, 2), "phase_matrix": (8, 7, 4),
+               "polarizer": (9, 6, 4), "sign_bit": (10, 1, 1)}
 FLAG_GUIDE_DISK = 1 << 22
 FLAG_GUIDE_FLAT = 1 << 23
 FLAG_RNG_SOBOL = 1 << 24
@@ -204,6 +208,7 @@ _PROTOS = {
     "thx_tracer_kernel_times": (c_int, [c_void_p, POINTER(c_float), c_uint32, POINTER(c_uint32)]),
     "thx_probe_target": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, POINTER(TargetParams), POINTER(c_float), POINTER(c_float), c_uint32, c_void_p]),
     "thx_probe_guide": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, POINTER(GuideParams), POINTER(c_float), POINTER(c_float), c_uint32, c_void_p]),
+    "thx_probe_unit": (c_int, [c_void_p, c_uint32, c_uint64, POINTER(c_float), c_uint32, c_uint32, POINTER(c_float), c_uint32]),
     "thx_rng_fill_sobol": (c_int, [c_void_p, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_float)]),
     "thx_rng_fill": (c_int, [c_void_p, POINTER(PhiloxParams), c_uint32, c_uint32, c_uint32, c_uint32, POINTER(c_uint32), POINTER(c_float)]),
     "thx_comm_unique_id": (c_int, [c_void_p]),

@@ -860,6 +860,27 @@ int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flag
     return probe(ctx, true, philox, flags, nullptr, guide, box_min, box_max, n, guide_out);
 }
 
+int thx_probe_unit(thx_ctx* ctx, uint32_t which, uint64_t addr, const float* in, uint32_t n_in, uint32_t n, float* out, uint32_t n_out) {
+    if (!ctx || !in || !out) return fail(THX_ERR_INVALID, "null argument");
+    static const uint32_t cols[THX_UNIT_COUNT][2] = {{2, 1}, {1, 4}, {5, 3}, {3, 2}, {6, 1}, {5, 4}, {9, 5}, {9, 2}, {7, 4}, {6, 4}, {1, 1}};
+    if (which >= THX_UNIT_COUNT) return fail(THX_ERR_INVALID, "unknown unit probe");
+    if (n_in != cols[which][0] || n_out != cols[which][1]) return fail(THX_ERR_INVALID, "column counts do not match the probed function");
+    if (n == 0) return THX_OK;
+    std::lock_guard<std::mutex> guard(ctx->lock);
+    THX_HIP(hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    THX_HIP(hipMalloc((void**)&d_in, 4 * (size_t)n_in * n));
+    hipError_t e = hipMalloc((void**)&d_out, 4 * (size_t)n_out * n);
+    if (e == hipSuccess) e = hipMemcpyAsync(d_in, in, 4 * (size_t)n_in * n, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launchUnitProbe(which, addr, d_in, n_in, n, d_out, n_out, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, 4 * (size_t)n_out * n, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hipFail(e, "thx_probe_unit");
+    return THX_OK;
+}
+
 int thx_rng_fill(thx_ctx* ctx, const thx_philox_params* p, uint32_t base_stream, uint32_t n_streams,
                  uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32, float* out_f32) {
     if (!ctx || !p) return fail(THX_ERR_INVALID, "null argument");

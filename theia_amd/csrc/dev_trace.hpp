@@ -1341,19 +1341,11 @@ struct Reflectance {
     float n_in, n_tr, r_s, r_p;
 };
 
-// scatter.surface.glsl:21-51
-template <class V>
-THX_DEV Reflectance fresnelReflect(Lane<V>& L, const Ray& ray, const SurfaceHit& hit) {
-    float cos_i = clampf(dot(ray.direction, hit.rayNrm), -1.0f, 1.0f);
+// scatter.surface.glsl:30-50: the arithmetic of fresnelReflect for given refractive indices
+// (cos_i = signed cosine between ray direction and surface normal)
+THX_DEV Reflectance fresnelCoefficients(float cos_i, float n_i, float n_t) {
+    cos_i = clampf(cos_i, -1.0f, 1.0f);
     float sin_i = sqrtf(fmaxf(1.0f - cos_i * cos_i, 0.0f));
-    uint64_t otherMed = hit.inward ? hit.mat_inside : hit.mat_outside;
-    float n_i = ray.constants.n;
-    float n_t = 1.0f;
-    if (otherMed != 0) {
-        const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(otherMed);
-        float u_t = normalize_lambda(m, ray.wavelength);
-        n_t = lookUp(m->n, u_t, 1.0f, L.cnt);
-    }
     float sin_t = sin_i * n_i / n_t;
     float cos_t = sqrtf(fmaxf(1.0f - sin_t * sin_t, 0.0f));
     cos_i = fabsf(cos_i);
@@ -1362,6 +1354,18 @@ THX_DEV Reflectance fresnelReflect(Lane<V>& L, const Ray& ray, const SurfaceHit&
     r.r_s = (n_i * cos_i - n_t * cos_t) / (n_i * cos_i + n_t * cos_t);
     r.r_p = (n_t * cos_i - n_i * cos_t) / (n_t * cos_i + n_i * cos_t);
     return r;
+}
+// scatter.surface.glsl:21-51
+template <class V>
+THX_DEV Reflectance fresnelReflect(Lane<V>& L, const Ray& ray, const SurfaceHit& hit) {
+    uint64_t otherMed = hit.inward ? hit.mat_inside : hit.mat_outside;
+    float n_t = 1.0f;
+    if (otherMed != 0) {
+        const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(otherMed);
+        float u_t = normalize_lambda(m, ray.wavelength);
+        n_t = lookUp(m->n, u_t, 1.0f, L.cnt);
+    }
+    return fresnelCoefficients(dot(ray.direction, hit.rayNrm), ray.constants.n, n_t);
 }
 
 // ray.surface.glsl:22-36 (integer-ULP nudge against self-intersection)

@@ -46,6 +46,9 @@ hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light
 // target.sample.glsl / target_guide.sample.glsl probes: out[n][25] resp. out[n][13]
 hipError_t launchProbe(bool guide, const LaunchArgs& args, const float* lo, const float* hi, uint32_t n, float* out,
                        hipStream_t stream);
+// one library function per element (unitProbeKernel): THX_UNIT_* of theia_hip.h
+hipError_t launchUnitProbe(uint32_t which, uint64_t addr, const float* in, uint32_t n_in, uint32_t n, float* out, uint32_t n_out,
+                           hipStream_t stream);
 hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint32_t n_streams,
                          uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
                          float* out_f32, hipStream_t stream);

@@ -252,6 +252,79 @@ hipError_t launchProbe(bool guide, const LaunchArgs& args, const float* lo, cons
     return hipGetLastError();
 }
 
+// Unit probe: one library function of the photon path per element, what the reference's shader unit
+// tests do with a tiny test kernel (tests/shader/*.test.glsl; tests/test_lookup.py, test_scatter.py,
+// test_polarization.py, test_math.py). in[n][n_in] -> out[n][n_out]; `addr` = table or medium address.
+__global__ void unitProbeKernel(uint32_t which, uint64_t addr, const float* __restrict__ in, uint32_t n_in, uint32_t n,
+                                float* __restrict__ out, uint32_t n_out) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const float* x = in + (size_t)i * n_in;
+    float* o = out + (size_t)i * n_out;
+    Counters<false> cnt;
+    switch (which) {
+    case THX_UNIT_LOOKUP: // lookup.glsl:14-28
+        o[0] = lookUp(addr, x[0], x[1], cnt);
+        break;
+    case THX_UNIT_LOOKUP_MEDIUM: { // material.glsl:50-74
+        const MediumConstants c = lookUpMedium(addr, x[0], cnt);
+        o[0] = c.n; o[1] = c.vg; o[2] = c.mu_s; o[3] = c.mu_e;
+        break;
+    }
+    case THX_UNIT_SCATTER_DIR: { // scatter.volume.glsl:7-26
+        const f3 d = scatterDir(f3{x[0], x[1], x[2]}, x[3], x[4]);
+        o[0] = d.x; o[1] = d.y; o[2] = d.z;
+        break;
+    }
+    case THX_UNIT_FRESNEL: { // scatter.surface.glsl:21-51
+        const Reflectance r = fresnelCoefficients(x[0], x[1], x[2]);
+        o[0] = r.r_s; o[1] = r.r_p;
+        break;
+    }
+    case THX_UNIT_SCATTER_PROB: // scatter.volume.glsl:54-65
+        o[0] = scatterProb(addr, f3{x[0], x[1], x[2]}, f3{x[3], x[4], x[5]}, cnt);
+        break;
+    case THX_UNIT_SCATTER_SAMPLE: { // scatter.volume.glsl:47-52
+        float p;
+        const f3 d = scatter(addr, f3{x[0], x[1], x[2]}, x[3], x[4], p, cnt);
+        o[0] = d.x; o[1] = d.y; o[2] = d.z; o[3] = p;
+        break;
+    }
+    case THX_UNIT_ROTATE_POLREF: { // polarization.glsl:38-68
+        f3 ref;
+        float c, s;
+        rotatePolRef(f3{x[0], x[1], x[2]}, f3{x[3], x[4], x[5]}, f3{x[6], x[7], x[8]}, ref, c, s);
+        o[0] = ref.x; o[1] = ref.y; o[2] = ref.z; o[3] = c; o[4] = s;
+        break;
+    }
+    case THX_UNIT_ALIGN_POLREF: { // polarization.glsl:21-34
+        float c, s;
+        alignPolRef(f3{x[0], x[1], x[2]}, f3{x[3], x[4], x[5]}, f3{x[6], x[7], x[8]}, c, s);
+        o[0] = c; o[1] = s;
+        break;
+    }
+    case THX_UNIT_PHASE_MATRIX: { // polarization.glsl:88-107 with ray.scatter.glsl:46-54
+        const f4 v = phaseRotateApply(addr, x[0], x[1], x[2], f4{x[3], x[4], x[5], x[6]}, cnt);
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        break;
+    }
+    case THX_UNIT_POLARIZER: { // polarization.glsl:109-120
+        const f4 v = polarizerApply(x[0], x[1], f4{x[2], x[3], x[4], x[5]});
+        o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
+        break;
+    }
+    default: // THX_UNIT_SIGN_BIT, math.glsl:18-20
+        o[0] = signBit(x[0]);
+        break;
+    }
+}
+hipError_t launchUnitProbe(uint32_t which, uint64_t addr, const float* in, uint32_t n_in, uint32_t n, float* out, uint32_t n_out,
+                           hipStream_t stream) {
+    if (n == 0) return hipSuccess;
+    hipLaunchKernelGGL(unitProbeKernel, dim3((n + 255u) / 256u), dim3(256), 0, stream, which, addr, in, n_in, n, out, n_out);
+    return hipGetLastError();
+}
+
 // random.sink.glsl equivalent: raw words + floats behind random(stream, dim)
 __global__ void rngFillKernel(thx_philox_params p, uint32_t base_stream, uint32_t n_streams,
                               uint32_t first_dim, uint32_t n_samples, uint32_t* out_u32,
