@@ -14,6 +14,13 @@ light 6 m away, sphere target guide (MIS), maxPathLength 10, unpolarized
 the timed region. Photon-steps are counted with the EventStatisticCallback
 semantics by an instrumented, untimed replay of exactly the timed batches.
 
+The JSON line carries, besides the contract fields:
+  roofline.units_per_step   the counted traversal units behind the algorithmic bytes (recompute at will)
+  roofline.achieved / frac  SURVEY.md 8(d) contract bytes (32 B per visited box, ...) / kernel time
+  roofline.achieved_layout  the same counts priced with the bytes this build's own records move
+  secondary                 BASELINE configs 3 and 5 at the same photon count (N = 1 only)
+  cpu_baseline              the C oracle on the host cores: all cores, and one thread
+
 Multi-GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
 one rank per GPU, every rank traces its own contiguous photon-index range of the
 global batch (weak scaling: `--batch` photons per GPU per step), no collective on
@@ -33,6 +40,17 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
         sys.path.insert(0, _p)
 
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
+# bytes per counted unit of the roofline contract
+CONTRACT_BYTES = {"nodes": 32.0, "triangles": 48.0, "instances": 112.0, "hits": 132.0, "lut_reads": 8.0}
+COUNTERS = ("queries", "nodes", "triangles", "instances", "hits", "lut_reads", "responses", "steps")  # statistics slots 12..19
+
+WORKLOADS = {
+    "config1": "BASELINE config 1: VolumeForwardTracer, homogeneous HG medium (example 01)",
+    "config2": "BASELINE config 2: SceneForwardTracer, single sphere.stl (1280 tris) in scattering medium, sphere guide/MIS, maxPathLength 10, unpolarized",
+    "config3": "BASELINE config 3: SceneForwardTracer, BK7 cube + torus detector in sea water, polarized",
+    "config5": "BASELINE config 5: SceneForwardTracer, suzanne x1000 instances + sphere detector, polarized",
+    "bigmesh": "config 2 with the detector sphere subdivided to 5 242 880 triangles (not a BASELINE config: out-of-cache BVH stress)",
+}
 
 
 def parse():
@@ -41,10 +59,11 @@ def parse():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=10_000_000, help="photons per GPU per step")
-    ap.add_argument("--workload", default="config2", choices=["config1", "config2", "config3", "config5", "bigmesh"])
+    ap.add_argument("--workload", default="config2", choices=list(WORKLOADS))
     ap.add_argument("--polarized", type=int, default=-1, help="override the workload's polarization (0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-seconds", type=float, default=12.0, help="target duration of the CPU-oracle sample")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 lines")
+    ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of each CPU-oracle sample")
     return ap.parse_args()
 
 
@@ -58,18 +77,157 @@ def make_scenario(S, name: str, batch: int, polarized: int, **kw):
         return S.config2_sphere(batch, **pol, **kw)
     if name == "config3":
         return S.config3_cube_torus(batch, **pol, **kw)
-    if name == "bigmesh":  # config 2 with the sphere subdivided to 5.2 M triangles: a BVH (410 MB) beyond every cache
+    if name == "bigmesh":  # config 2 with the sphere subdivided to 5.2 M triangles: a BVH beyond every cache
         return S.config2_sphere(batch, subdivide=6, **pol, **kw)
     return S.config5_suzanne_grid(batch, **pol, **kw)
 
 
-def algorithmic_bytes(delta, grid: int, n_bins: int, launches: int) -> float:
-    """32 B/node + 48 B/triangle + 112 B/instance + 132 B/hit +
-    8 B/LUT read + histogram flush (slab write + reducer read)."""
-    q = {n: float(delta[12 + i]) for i, n in enumerate(("queries", "nodes", "triangles", "instances", "hits", "lut_reads", "responses", "steps"))}
-    b = 32.0 * q["nodes"] + 48.0 * q["triangles"] + 112.0 * q["instances"] + 132.0 * q["hits"] + 8.0 * q["lut_reads"]
-    b += launches * grid * n_bins * 4.0 * 2.0
-    return b
+def unit_counts(delta) -> dict:
+    return {n: float(delta[12 + i]) for i, n in enumerate(COUNTERS)}
+
+
+def priced(units: dict, bytes_per: dict, grid: int, n_bins: int, launches: int) -> float:
+    """bytes of `launches` launches: counted units x bytes per unit + histogram flush (slab write + reducer read)"""
+    return sum(bytes_per[k] * units[k] for k in bytes_per) + launches * grid * n_bins * 4.0 * 2.0
+
+
+class Measurement:
+    """W warm-up + K timed batches of one workload on this rank's GPU, and the instrumented replay that
+    counts their photon-steps and traversal units"""
+
+    def __init__(self, S, hip, torch, workload: str, polarized: int, B: int, K: int, W: int, rank: int, world: int, dist, dev, stream):
+        import numpy as np
+        from theia_amd.hp.pipeline import Pipeline
+
+        self.workload, self.K, self.W, self.B = workload, K, W, B
+        norm = 1.0 / (B * world)
+
+        def prepared(stats: bool):
+            sc = make_scenario(S, workload, B, polarized, stats=stats)
+            sc.response.normalization = norm
+            sc.tracer.photonOffset = rank * B  # contiguous index range of this rank
+            return sc, Pipeline(sc.stages())
+
+        # ---- untimed, instrumented replay of the W + K batches: exact step and unit counts
+        sc_i, pipe_i = prepared(True)
+        for k in range(W):
+            pipe_i.run(k % 2)
+        before = sc_i.tracer.program.read_stats().astype(np.int64)
+        for k in range(W, W + K):
+            pipe_i.run(k % 2)
+        self.delta = sc_i.tracer.program.read_stats().astype(np.int64) - before
+        events = self.delta[:12]
+        self.steps_local = int(self.delta[19])
+        # cross-check with the reference's definition: one step = one loop event other than created / maxIter
+        assert self.steps_local == int(events[1:9].sum() + events[10]), (self.steps_local, events)
+        self.scene_info = sc_i.scene.info if hasattr(sc_i, "scene") else {}
+        del sc_i, pipe_i
+
+        # ---- timed region
+        sc, pipe = prepared(False)
+        tr, prog = sc.tracer, sc.tracer.program
+        self.n_bins = n_bins = sc.response.nBins
+        curves = torch.zeros((K, n_bins), dtype=torch.float32, device=dev)
+
+        def step(k: int, out_ptr: int) -> None:
+            cfg = k % 2
+            pipe.update(cfg)  # host side of one batch: RNG auto-advance, parameter commit
+            hip.tracer_run(prog.handle, cfg, tr._assemble(cfg), stream)
+            hip.tracer_reduce(prog.handle, cfg, norm, out_ptr, stream)
+
+        scratch = torch.zeros((n_bins,), dtype=torch.float32, device=dev)
+        for k in range(W):
+            step(k, scratch.data_ptr())
+        if dist is not None:
+            torch.cuda.synchronize()
+            dist.all_reduce(scratch)  # warm the communicator outside the timed region
+            dist.barrier()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        for k in range(K):
+            step(W + k, curves[k].data_ptr())
+        if dist is not None:
+            # the tracer works on the library's own (non-blocking) stream when torch's current stream
+            # is the default one: finish the reductions into `curves` before RCCL reads them
+            torch.cuda.synchronize()
+            dist.all_reduce(curves)  # the single collective: K x n_bins floats
+        torch.cuda.synchronize()
+        if dist is not None:
+            dist.barrier()
+        self.elapsed = time.perf_counter() - t0
+        # results went into an external buffer the library never reads back: ask it whether a kernel flagged
+        # an error (scheduler watchdog), and look at the curves themselves
+        hip.tracer_check(prog.handle)
+        if not bool(torch.isfinite(curves).all()) or float(curves.sum()) <= 0.0:
+            raise RuntimeError(f"{workload}: the timed batches produced an invalid light curve")
+
+        kt = prog.kernel_times(min(K, 64))  # live HIP-event durations of the timed launches
+        self.kernel_ms = float(np.mean(kt)) if len(kt) else float("nan")
+        self.info = prog.launch_info(B)
+        self.kernel = "thx::traceKernel (volume forward)" if workload == "config1" else (
+            "thx::sceneStagedKernel" if self.info.get("block") != 256 else "thx::traceKernel (scene forward)")
+
+    def roofline(self, steps_local: int) -> dict:
+        units = unit_counts(self.delta)
+        grid, K = self.info["grid"], self.K
+        contract = priced(units, CONTRACT_BYTES, grid, self.n_bins, K) / K
+        si = self.scene_info
+        layout_per = {"nodes": float(si.get("layout_box_bytes", 0)), "triangles": float(si.get("layout_triangle_bytes", 0)),
+                      "instances": float(si.get("layout_instance_bytes", 0)), "hits": float(si.get("layout_hit_bytes", 0)), "lut_reads": 8.0}
+        layout = priced(units, layout_per, grid, self.n_bins, K) / K
+        sec = self.kernel_ms * 1e-3
+        return {
+            "kernel": self.kernel,
+            "kernel_ms": self.kernel_ms,
+            "achieved": contract / sec / 1e9,
+            "frac": contract / sec / 1e9 / HBM_PEAK_GBS,
+            "algorithmic_bytes_per_launch": contract,
+            "algorithmic_bytes_per_step": contract * K / max(steps_local, 1),
+            "achieved_layout": layout / sec / 1e9,
+            "frac_layout": layout / sec / 1e9 / HBM_PEAK_GBS,
+            "layout_bytes_per_step": layout * K / max(steps_local, 1),
+            "units_per_step": {k: v / max(steps_local, 1) for k, v in units.items() if k != "steps"},
+            "unit_bytes": {"contract": CONTRACT_BYTES, "layout": layout_per, "hist_flush_per_launch": grid * self.n_bins * 8.0},
+        }
+
+
+def cpu_baseline(S, _backend, workload: str, polarized: int, seconds: float) -> dict:
+    """the C oracle (a port, not the reference's llvmpipe path) on a bounded sample: all cores, then one thread"""
+    from oracle_backend import OracleBackend
+
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    cores = min(cores, 16)  # CPU share of a one-GPU box
+
+    def sample(threads: int) -> dict:
+        ob = OracleBackend(threads=threads)
+        _backend.install(ob)
+
+        def cpu_run(n: int):
+            c = make_scenario(S, workload, n, polarized, stats=True)
+            t = time.perf_counter()
+            S.run_batches(c, 1)
+            dt = time.perf_counter() - t
+            return int(c.tracer.program.read_stats()[19]), dt
+
+        cpu_run(2_000)  # page in the library, spin up the OpenMP team
+        probe = 20_000 if threads == 1 else 50_000
+        _s0, d0 = cpu_run(probe)
+        n = int(min(max(seconds * probe / max(d0, 1e-6), probe), 50_000_000))
+        s1, d1 = cpu_run(n)
+        ob.close()
+        return {"value": s1 / d1 / 1e6, "photons": n, "photon_steps": s1, "seconds": d1}
+
+    many, one = sample(cores), sample(1)
+    return {
+        "value": many["value"],
+        "unit": "Mphoton-steps/s",
+        "cores": cores,
+        "kind": "port",
+        "sample": f"{many['photons']} photons of the same workload ({many['photon_steps']} photon-steps, {many['seconds']:.1f} s) on the C oracle with "
+                  f"OpenMP on {cores} threads; the reference's Vulkan/llvmpipe path cannot run here (no Vulkan, no hephaistos)",
+        "single_thread": {"value": one["value"], "unit": "Mphoton-steps/s", "cores": 1,
+                          "sample": f"{one['photons']} photons ({one['photon_steps']} photon-steps, {one['seconds']:.1f} s), one thread"},
+    }
 
 
 def main() -> None:
@@ -83,12 +241,10 @@ def main() -> None:
                      "--nproc-per-node N --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...")
         args.gpus = world
 
-    import numpy as np
     import torch
 
-    from theia_amd import workloads as S
     from theia_amd import _backend, distributed
-    from theia_amd.hp.pipeline import Pipeline
+    from theia_amd import workloads as S
 
     # rehearsal on a box with fewer GPUs than ranks (THX_BENCH_BACKEND=gloo): ranks share devices
     ndev = max(torch.cuda.device_count(), 1)
@@ -104,77 +260,17 @@ def main() -> None:
     stream = torch.cuda.current_stream().cuda_stream
 
     K, W, B = args.steps, args.warmup, args.batch
-    global_batch = B * world
-    norm = 1.0 / global_batch
+    m = Measurement(S, hip, torch, args.workload, args.polarized, B, K, W, rank, world, dist, dev, stream)
 
-    def prepared(stats: bool):
-        sc = make_scenario(S, args.workload, B, args.polarized, stats=stats)
-        sc.response.normalization = norm
-        sc.tracer.photonOffset = rank * B  # contiguous index range of this rank
-        return sc, Pipeline(sc.stages())
-
-    # ---- untimed, instrumented replay of the W + K batches: exact step counts
-    sc_i, pipe_i = prepared(True)
-    for k in range(W):
-        pipe_i.run(k % 2)
-    before = sc_i.tracer.program.read_stats().astype(np.int64)
-    for k in range(W, W + K):
-        pipe_i.run(k % 2)
-    delta = sc_i.tracer.program.read_stats().astype(np.int64) - before
-    events = delta[:12]
-    steps_local = int(delta[19])
-    # cross-check with the reference's definition: one step = one loop event other than created/maxIter
-    assert steps_local == int(events[1:9].sum() + events[10]), (steps_local, events)
-    del sc_i, pipe_i
-
-    # ---- timed region
-    sc, pipe = prepared(False)
-    tr = sc.tracer
-    prog = tr.program
-    n_bins = sc.response.nBins
-    curves = torch.zeros((K, n_bins), dtype=torch.float32, device=dev)
-
-    def step(k: int, out_ptr: int) -> None:
-        cfg = k % 2
-        pipe.update(cfg)  # host side of one batch: RNG auto-advance, parameter commit
-        hip.tracer_run(prog.handle, cfg, tr._assemble(cfg), stream)
-        hip.tracer_reduce(prog.handle, cfg, norm, out_ptr, stream)
-
-    scratch = torch.zeros((n_bins,), dtype=torch.float32, device=dev)
-    for k in range(W):
-        step(k, scratch.data_ptr())
-    if dist is not None:
-        torch.cuda.synchronize()
-        dist.all_reduce(scratch)  # warm the communicator outside the timed region
-        dist.barrier()
-    torch.cuda.synchronize()
-    t0 = time.perf_counter()
-    for k in range(K):
-        step(W + k, curves[k].data_ptr())
-    if dist is not None:
-        # the tracer works on the library's own (non-blocking) stream when torch's current stream
-        # is the default one: finish the reductions into `curves` before RCCL reads them
-        torch.cuda.synchronize()
-        dist.all_reduce(curves)  # the single collective: K x n_bins floats
-    torch.cuda.synchronize()
-    if dist is not None:
-        dist.barrier()
-    elapsed = time.perf_counter() - t0
-
-    t_max = torch.tensor([elapsed], dtype=torch.float64, device=dev)
-    total_steps = torch.tensor([steps_local], dtype=torch.float64, device=dev)
+    t_max = torch.tensor([m.elapsed], dtype=torch.float64, device=dev)
+    total_steps = torch.tensor([m.steps_local], dtype=torch.float64, device=dev)
     if dist is not None:
         dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
         dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
     elapsed = float(t_max.item())
     steps_all = float(total_steps.item())
+    global_batch = B * world
 
-    # ---- roofline of the dominant kernel (rank 0): live HIP-event durations of the timed launches
-    kt = prog.kernel_times(min(K, 64))
-    kernel_ms = float(np.mean(kt)) if len(kt) else float("nan")
-    info = prog.launch_info(B)
-    alg_bytes_launch = algorithmic_bytes(delta, info["grid"], n_bins, K) / K
-    achieved = alg_bytes_launch / (kernel_ms * 1e-3) / 1e9
     traffic = None
     tfile = os.path.join(ROOT, "profiles", "traffic.json")
     if os.path.exists(tfile):
@@ -182,6 +278,13 @@ def main() -> None:
             traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
         except Exception:
             traffic = None
+
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic}
+    roof.update(m.roofline(m.steps_local))
+    roof["note"] = ("bound = the north star's algorithmic-HBM contract: `achieved` = SURVEY.md 8(d) per-unit bytes x the counted units "
+                    "(units_per_step) / kernel time; `achieved_layout` prices the same counts with the bytes this build's records "
+                    "actually move. The BASELINE scenes are cache resident (`traffic` = HBM bytes from PMC counters), so what limits "
+                    "the kernel is instruction issue of divergent code and gather latency, not HBM (DESIGN.md section 3.1)")
 
     result = {
         "metric": "Mphoton-steps/sec at 10^7 photons; achieved HBM GB/s vs roofline",
@@ -197,68 +300,38 @@ def main() -> None:
         "dtype": "f32",
         "data": "synthetic",
         "config": {
-            "workload": {
-                "config1": "BASELINE config 1: VolumeForwardTracer, homogeneous HG medium (example 01)",
-                "config2": "BASELINE config 2: SceneForwardTracer, single sphere.stl (1280 tris) in scattering medium, sphere guide/MIS, maxPathLength 10, unpolarized",
-                "config3": "BASELINE config 3: SceneForwardTracer, BK7 cube + torus detector in sea water, polarized",
-                "config5": "BASELINE config 5: SceneForwardTracer, suzanne x1000 instances + sphere detector, polarized",
-                "bigmesh": "config 2 with the detector sphere subdivided to 5 242 880 triangles (not a BASELINE config: out-of-cache BVH stress)",
-            }[args.workload],
+            "workload": WORKLOADS[args.workload],
             "photons_per_step_per_gpu": B,
             "photons_total": global_batch * K,
             "photon_steps_total": steps_all,
             "steps_per_photon": steps_all / (global_batch * K),
-            "sharding": f"photon index ranges x{world}, one RCCL all-reduce of {K}x{n_bins} f32" if world > 1 else "single GPU",
-            "launch": info,
+            "sharding": f"photon index ranges x{world}, one RCCL all-reduce of {K}x{m.n_bins} f32" if world > 1 else "single GPU",
+            "launch": m.info,
+            "scene": m.scene_info,
         },
-        "roofline": {
-            "bound": "hbm",
-            "kernel": ("thx::sceneStagedKernel" if info.get("block") != 256 else "thx::traceKernel (scene forward)")
-            if args.workload != "config1" else "thx::traceKernel (volume forward)",
-            "achieved": achieved,
-            "peak": HBM_PEAK_GBS,
-            "unit": "GB/s",
-            "frac": achieved / HBM_PEAK_GBS,
-            "traffic": traffic,
-            "algorithmic_bytes_per_launch": alg_bytes_launch,
-            "algorithmic_bytes_per_step": alg_bytes_launch * K / max(steps_local, 1),
-            "kernel_ms": kernel_ms,
-            "note": "algorithmic bytes = SURVEY.md 8(d) per-unit figures x instrumented unit counts; the scene working set "
-                    "(88 KB for the sphere) is L1/L2 resident, so DRAM traffic is far below this figure and the kernel is "
-                    "bound by vector-cache gather rate and divergence, not HBM (DESIGN.md section 7)",
-        },
+        "roofline": roof,
     }
 
-    # ---- CPU baseline: the oracle (a port, not the reference's llvmpipe path) on a bounded sample
+    # ---- the other single-GPU BASELINE configs at the same photon count (reported, not the headline)
+    if rank == 0 and world == 1 and not args.no_secondary and args.workload == "config2":
+        secondary = []
+        for name in ("config3", "config5"):
+            k2 = max(2, min(K, 3))
+            s = Measurement(S, hip, torch, name, -1, B, k2, 1, 0, 1, None, dev, stream)
+            r = s.roofline(s.steps_local)
+            secondary.append({
+                "workload": WORKLOADS[name], "photons_per_step": B, "steps": k2, "value": s.steps_local / s.elapsed / 1e6,
+                "unit": "Mphoton-steps/s", "ms_per_step": s.elapsed / k2 * 1e3, "steps_per_photon": s.steps_local / (B * k2),
+                "kernel_ms": r["kernel_ms"], "bytes_per_step": r["algorithmic_bytes_per_step"], "achieved": r["achieved"], "frac": r["frac"],
+                "layout_bytes_per_step": r["layout_bytes_per_step"], "frac_layout": r["frac_layout"], "units_per_step": r["units_per_step"],
+                "launch": s.info,
+            })
+            del s
+        result["secondary"] = secondary
+
     if rank == 0 and world == 1 and not args.no_cpu_baseline:
-        from oracle_backend import OracleBackend
-
-        cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
-        cores = min(cores, 16)  # CPU share of a one-GPU box
-        ob = OracleBackend(threads=cores)
-        _backend.install(ob)
-
-        def cpu_run(n: int):
-            c = make_scenario(S, args.workload, n, args.polarized, stats=True)
-            t = time.perf_counter()
-            S.run_batches(c, 1)
-            dt = time.perf_counter() - t
-            return int(c.tracer.program.read_stats()[19]), dt
-
-        cpu_run(2_000)  # page in the library, spin up the OpenMP team
-        s0, d0 = cpu_run(50_000)
-        photons_per_s = 50_000 / max(d0, 1e-6)
-        n = int(min(max(args.cpu_seconds * photons_per_s, 50_000), 50_000_000))
-        s1, d1 = cpu_run(n)
+        result["cpu_baseline"] = cpu_baseline(S, _backend, args.workload, args.polarized, args.cpu_seconds)
         _backend.install(hip)
-        result["cpu_baseline"] = {
-            "value": s1 / d1 / 1e6,
-            "unit": "Mphoton-steps/s",
-            "cores": cores,
-            "kind": "port",
-            "sample": f"{n} photons of the same workload ({s1} photon-steps, {d1:.1f} s) on the C oracle with OpenMP; "
-                      "the reference's Vulkan/llvmpipe path cannot run here (no Vulkan, no hephaistos)",
-        }
 
     if rank == 0:
         print(json.dumps(result))

@@ -257,6 +257,10 @@ typedef struct {
 typedef struct {
     uint32_t n_nodes, n_triangles, n_instances, max_depth;
     uint64_t bytes_nodes, bytes_triangles, bytes_instances, bytes_total;
+    /* bytes the traversal's OWN records move per counted unit (the counters of the instrumented kernels):
+     * per child box tested, per triangle tested, per instance entered, per hit reconstructed. (SURVEY.md 8(d)
+     * fixes contract figures of 32 / 48 / 112 / 132 B for the roofline; these are what this build fetches.) */
+    uint32_t layout_box_bytes, layout_triangle_bytes, layout_instance_bytes, layout_hit_bytes;
 } thx_scene_info;
 
 /* Threading: every call may be made from any thread (each sets its device); calls on tracers and

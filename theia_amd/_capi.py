@@ -163,6 +163,7 @@ class SceneInfo(Structure):
     _fields_ = [
         ("n_nodes", c_uint32), ("n_triangles", c_uint32), ("n_instances", c_uint32), ("max_depth", c_uint32),
         ("bytes_nodes", c_uint64), ("bytes_triangles", c_uint64), ("bytes_instances", c_uint64), ("bytes_total", c_uint64),
+        ("layout_box_bytes", c_uint32), ("layout_triangle_bytes", c_uint32), ("layout_instance_bytes", c_uint32), ("layout_hit_bytes", c_uint32),
     ]
 
 

@@ -290,6 +290,14 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     for (uint32_t m = 0; m < n_meshes; ++m)
         total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
     s->info.bytes_total = total;
+    // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_trace.hpp: Walker,
+    // processRayQuery): half a NodePair per child box; a TriRecord; w2o (48) + the frame word's 16-B chunk +
+    // the TreeFrame (32) per instance entry; index triple (12) + three vertices (72) + Geometry (24) +
+    // Material (24) + the instance record (112) per reconstructed hit
+    s->info.layout_box_bytes = sizeof(NodePair) / 2;
+    s->info.layout_triangle_bytes = sizeof(TriRecord);
+    s->info.layout_instance_bytes = 48 + 16 + sizeof(TreeFrame);
+    s->info.layout_hit_bytes = 12 + 72 + sizeof(GeometryGLSL) + sizeof(MaterialGLSL) + sizeof(InstanceRecord);
     *out = s;
     return THX_OK;
 }
