@@ -1174,6 +1174,13 @@ struct Walker {
         while ((cur & 7u) == 0u) {
 #ifdef THX_STAGE_PROFILE
             pTrips += 1; // lane 0's count is what gets reported: trips of the wave while lane 0 is in the loop
+            {
+                const unsigned long long m = __ballot(1);
+                if (L.prof != nullptr && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
+                    atomicAdd(&L.prof[31], (unsigned long long)__popcll(m));
+                    atomicAdd(&L.prof[39], 1ull);
+                }
+            }
 #endif
             const uint32_t pair = cur >> 3;
             const float4 lc = nodes[2 * pair], rc = nodes[2 * pair + 1];
@@ -1253,7 +1260,20 @@ template <class V>
 THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
     Walker<V> wk(L);
     wk.begin(org, dir, tmax);
+#ifdef THX_STAGE_PROFILE
+    // lane occupancy of the walk: every round / inner trip is counted once per wave (by its first
+    // active lane) together with the number of lanes that take part in it
+    while (!wk.done()) {
+        const unsigned long long m = __ballot(1);
+        if (L.prof != nullptr && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
+            atomicAdd(&L.prof[29], (unsigned long long)__popcll(m));
+            atomicAdd(&L.prof[30], 1ull);
+        }
+        wk.advance();
+    }
+#else
     while (!wk.done()) wk.advance();
+#endif
     if (wk.h.valid) L.cnt.add(ST_HITS);
 #ifdef THX_STAGE_PROFILE
     if ((threadIdx.x & 63u) == 0u && L.prof != nullptr) { // wave-level sums (s_memtime is uniform)

@@ -8,7 +8,8 @@ from theia_amd import workloads as S
 from theia_amd import _backend, _capi
 n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
 which = sys.argv[2] if len(sys.argv) > 2 else "config2"
-make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid}[which]
+make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid,
+        "mid": lambda batch: S.config2_sphere(batch, subdivide=3), "bigmesh": lambda batch: S.config2_sphere(batch, subdivide=6)}[which]
 sc = make(batch=n)
 S.run_batches(sc, 2)
 be = _backend.get()
@@ -37,3 +38,7 @@ if out[27]:
     w = int(out[10])
     print(f"walk detail per wave-batch: advance rounds={int(out[27]) / w:.1f} inner trips (lane 0)={int(out[28]) / w:.1f} "
           f"inner cycles={int(out[24]) / w:.0f} triangle-leaf cycles={int(out[25]) / w:.0f} instance/exit cycles={int(out[26]) / w:.0f}")
+
+if out[30]:
+    print(f"walk occupancy: lanes per round={int(out[29]) / int(out[30]):.1f} of 64 (wave rounds per batch={int(out[30]) / max(int(out[10]), 1):.1f}), "
+          f"lanes per inner trip={int(out[31]) / max(int(out[39]), 1):.1f} (wave trips per batch={int(out[39]) / max(int(out[10]), 1):.1f})")
