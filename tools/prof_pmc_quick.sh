@@ -1,0 +1,34 @@
+#!/bin/bash
+# Two quick PMC passes (instruction mix, lane utilisation) over the tracing kernel of one workload:
+#   tools/prof_pmc_quick.sh <outdir-under-gpurun_out> [bench args...]
+set -u
+OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
+mkdir -p $OUT
+export TMPDIR=/tmp
+i=0
+for set in \
+  "SQ_WAVES SQ_WAVE_CYCLES SQ_BUSY_CYCLES SQ_ACTIVE_INST_ANY SQ_WAIT_INST_ANY SQ_WAIT_ANY SQ_ACTIVE_INST_VALU SQ_INSTS_VALU" \
+  "SQ_INSTS_SALU SQ_INSTS_SMEM SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INSTS_LDS SQ_ACTIVE_INST_LDS SQ_ACTIVE_INST_SCA SQ_INSTS_BRANCH" \
+  "SQ_THREAD_CYCLES_VALU SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS SQ_INSTS_VALU_TRANS SQ_VALU_MFMA_BUSY_CYCLES"; do
+  i=$((i+1))
+  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed"
+done
+python3 - "$OUT" <<'PY'
+import csv, glob, sys, collections, re
+out = sys.argv[1]
+agg = collections.defaultdict(lambda: collections.defaultdict(list))
+for f in glob.glob(out + "/pass*/**/*counter_collection.csv", recursive=True):
+    for r in csv.DictReader(open(f)):
+        k = r.get("Kernel_Name", "")
+        if "Staged" not in k and "traceKernel" not in k: continue
+        m = re.search(r"Variant<([^>]*)>", k)
+        a = [x.strip() for x in m.group(1).split(",")] if m else []
+        dbg = len(a) > 2 and a[2] == "true"
+        agg[("staged" if "Staged" in k else "trace") + ("_debug" if dbg else "")][r["Counter_Name"]].append(float(r["Counter_Value"]))
+with open(out + "/summary.txt", "w") as fh:
+    for k, d in agg.items():
+        fh.write(f"== {k}\n")
+        for c, v in sorted(d.items()):
+            fh.write(f"{c:32s} n={len(v):3d} mean={sum(v)/len(v):.6g}\n")
+print(open(out + "/summary.txt").read())
+PY

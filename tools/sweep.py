@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Kernel time of the scene workloads under environment overrides (development aid):
+   tools/sweep.py <photons> <workload,...> [VAR=v1,v2,... ...]   -- full cross product of the VAR lists."""
+import itertools, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
+import numpy as np
+from theia_amd import workloads as S
+from theia_amd.hp.pipeline import Pipeline
+
+MAKE = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid,
+        "mid": lambda batch: S.config2_sphere(batch, subdivide=3), "bigmesh": lambda batch: S.config2_sphere(batch, subdivide=6)}
+n = int(sys.argv[1])
+names = sys.argv[2].split(",")
+axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[3:]]
+for name in names:
+    for combo in itertools.product(*[v for _, v in axes]) if axes else [()]:
+        for (k, _), v in zip(axes, combo):
+            if v == "-":
+                os.environ.pop(k, None)
+            else:
+                os.environ[k] = v
+        sc = MAKE[name](batch=n)
+        pipe = Pipeline(sc.stages())
+        ms = []
+        for k in range(5):
+            pipe.run(k % 2)
+            ms.append(sc.tracer.program.last_kernel_ms(k % 2))
+        info = sc.tracer.program.launch_info(n)
+        tag = " ".join(f"{k}={v}" for (k, _), v in zip(axes, combo))
+        print(f"{name:8s} {tag:40s} kernel ms = {np.median(ms[2:]):8.3f}   block={info['block']} lds={info['lds_bytes']}", flush=True)
+        del sc, pipe
