@@ -358,6 +358,29 @@ def test_rccl_allreduce_through_the_c_abi(hip_backend):
 
 
 @pytest.mark.parametrize("kernel", ["staged", "lane"])
+def test_traversal_stack_overflow_is_counted(hip_backend, kernel, monkeypatch):
+    """a traversal stack shallower than the scene needs (forced through the THX_STACK_DEPTH hook; the host
+    sizes it as hierarchy depth + 2) is not silent: the photon whose walk lost an entry ends with
+    ERROR_CODE_TRACE_ABORT, counted in the statistics like every device error of the reference
+    (callback.stat.glsl:66-69), a shadow ray in that state contributes nothing; everything else goes on"""
+    if kernel == "lane":
+        monkeypatch.setenv("THX_KERNEL", "lane")
+    n = 20000
+    ok = S.config5_suzanne_grid(batch=n, n_side=4, stats=True)
+    h_ok = S.run_batches(ok, 1)[0]
+    st_ok = ok.tracer.program.read_stats().astype(np.int64)
+    monkeypatch.setenv("THX_STACK_DEPTH", "3")
+    sc = S.config5_suzanne_grid(batch=n, n_side=4, stats=True)
+    h = S.run_batches(sc, 1)[0]
+    st = sc.tracer.program.read_stats().astype(np.int64)
+    assert np.isfinite(h).all() and st[0] == n
+    assert st[10] > st_ok[10] + 100                       # errors counted (st_ok: media mismatches only)
+    ended = st[5] + st[6] + st[7] + st[9]                  # lost + decayed + absorbed + maxIter
+    assert ended <= n and ended + st[10] >= n              # every photon ends once: normally, or with an error
+    assert h.sum() < h_ok.sum() * 1.05                     # dropped work can only remove light (MC noise aside)
+
+
+@pytest.mark.parametrize("kernel", ["staged", "lane"])
 def test_scene_with_thousands_of_instances(hip_backend, kernel, monkeypatch):
     """4914 instances (32-bit traversal stacks, a TLAS deeper than any other test's): both kernel
     forms follow the oracle photon by photon"""

@@ -392,6 +392,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
         t->stack16 = scene->nPairs < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
+        // test hook: a stack shallower than the scene needs (the walk then flags ERROR_CODE_TRACE_ABORT)
+        if (const char* env = std::getenv("THX_STACK_DEPTH")) t->stackDepth = (uint32_t)std::min<int>(kStackDepth, std::max(1, std::atoi(env)));
     }
     // kernel form: the staged scene kernel unless THX_KERNEL=lane asks for the lane kernel
     // (kept as the simple cross-check of the staged one) or there is no step to stage

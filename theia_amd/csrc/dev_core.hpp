@@ -357,8 +357,20 @@ THX_DEV f4 polarizerApply(float p, float s, f4 v) {
 
 // ray.scatter.glsl:46-54: (phase * rotate) * stokes with the phase matrix of
 // polarization.glsl:88-107. This 4x4 contraction is the one spot the north star
-// earmarks for MFMA; with the block-sparse structure it is 14 multiplies per
-// photon, so it stays on the VALU ("Mueller contraction").
+// earmarks for MFMA. With the block-sparse structure it is 14 multiplies per photon on
+// the VALU (the default). -DTHX_MUELLER_MFMA builds the measured alternative: the same
+// contraction on the matrix pipe (profiles/r02_mueller_mfma.txt has both timings).
+#ifdef THX_MUELLER_MFMA
+typedef float v4f __attribute__((ext_vector_type(4)));
+// out[r] = sum_c M[r][c] * v[c] per LANE with v_mfma_f32_4x4x1f32 (16 blocks of 4 lanes): in a block,
+// D[i][j] += A(lane i) * B(lane j); with A = this lane's M[r][c] and B = this lane's v[c] the lane's own
+// product sits on the diagonal, i.e. in element (lane & 3) of the lane's accumulator. No data moves between
+// lanes; three quarters of the block's products are other lanes' cross terms and are thrown away.
+THX_DEV float mfmaDiag(v4f acc) {
+    const uint32_t k = threadIdx.x & 3u;
+    return k == 0u ? acc.x : (k == 1u ? acc.y : (k == 2u ? acc.z : acc.w));
+}
+#endif
 template <bool ST>
 THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, f4 v,
                             Counters<ST>& cnt) {
@@ -372,10 +384,29 @@ THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, 
         m34 = lookUp(m->phase_m34, t, 0.0f, cnt);
     }
     f4 o;
+#ifdef THX_MUELLER_MFMA
+    // M = phase * rotate, row by row (zero entries skipped: rows 0, 1 have no column 3, rows 2, 3 no column 0);
+    // the MFMA fuses multiply and add, so the last bits differ from the VALU form below (and from the oracle)
+    const v4f z = {0.0f, 0.0f, 0.0f, 0.0f};
+    v4f a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(1.0f, v.x, z, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(m12 * c, v.y, a0, 0, 0, 0);
+    a0 = __builtin_amdgcn_mfma_f32_4x4x1f32(m12 * (-s), v.z, a0, 0, 0, 0);
+    v4f a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(m12, v.x, z, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(m22 * c, v.y, a1, 0, 0, 0);
+    a1 = __builtin_amdgcn_mfma_f32_4x4x1f32(m22 * (-s), v.z, a1, 0, 0, 0);
+    v4f a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(m33 * s, v.y, z, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(m33 * c, v.z, a2, 0, 0, 0);
+    a2 = __builtin_amdgcn_mfma_f32_4x4x1f32(m34, v.w, a2, 0, 0, 0);
+    v4f a3 = __builtin_amdgcn_mfma_f32_4x4x1f32((-m34) * s, v.y, z, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_4x4x1f32((-m34) * c, v.z, a3, 0, 0, 0);
+    a3 = __builtin_amdgcn_mfma_f32_4x4x1f32(m33, v.w, a3, 0, 0, 0);
+    o.x = mfmaDiag(a0); o.y = mfmaDiag(a1); o.z = mfmaDiag(a2); o.w = mfmaDiag(a3);
+#else
     o.x = (v.x + (m12 * c) * v.y) + (m12 * (-s)) * v.z;
     o.y = (m12 * v.x + (m22 * c) * v.y) + (m22 * (-s)) * v.z;
     o.z = ((m33 * s) * v.y + (m33 * c) * v.z) + m34 * v.w;
     o.w = (((-m34) * s) * v.y + ((-m34) * c) * v.z) + m33 * v.w;
+#endif
     return o;
 }
 

@@ -551,9 +551,20 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 }
 #endif
                 if (which == 0) {
-                    dest = h.valid ? postPrimary(L, pool, slot, h) : 4;
+                    if (h.aborted) { // the traversal stack overflowed: ERROR_CODE_TRACE_ABORT ends the photon
+                        Ray ray = loadRay(pool, slot);
+                        Meta m = loadMeta(pool, slot);
+                        bindLane(L, m);
+                        endStep(L, ray, m, ERROR_CODE_TRACE_ABORT);
+                        storeMeta(pool, slot, m);
+                        dest = 3;
+                    } else {
+                        dest = h.valid ? postPrimary(L, pool, slot, h) : 4;
+                    }
                 } else {
-                    if (h.valid) {
+                    if (h.aborted) {
+                        L.cnt.add(ST_ERROR); // counted; the shadow ray contributes nothing
+                    } else if (h.valid) {
                         Ray s = loadRay(pool, slot); // the photon itself is not modified
                         Meta m = loadMeta(pool, slot);
                         bindLane(L, m);

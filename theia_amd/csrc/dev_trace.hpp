@@ -915,6 +915,7 @@ THX_DEV bool volPhotonStep(Lane<V>& L, Ray& ray, uint32_t& step) {
 
 struct QueryHit {
     bool valid;
+    bool aborted = false; // the traversal stack overflowed: the result is not the closest hit (ERROR_CODE_TRACE_ABORT)
     uint32_t instance, prim;
     float t, b1, b2; // b1, b2 = barycentric weights of v1, v2
 };
@@ -1047,6 +1048,9 @@ THX_DEV bool slabRoot(const QRay& r, float tmax) {
 THX_DEV float4 tlasFrame0(const SceneView& sc) { return make_float4(sc.tlas.origin[0], sc.tlas.origin[1], sc.tlas.origin[2], __uint_as_float(sc.tlas.rootRef)); }
 THX_DEV float4 tlasFrame1(const SceneView& sc) { return make_float4(sc.tlas.step[0], sc.tlas.step[1], sc.tlas.step[2], 0.0f); }
 
+#ifndef THX_INNER_KEEP
+#define THX_INNER_KEEP 2 // inner-node loop of a round ends early once fewer than KEEP / 8 of its starters are still in it (0: never)
+#endif
 constexpr uint32_t WALK_DONE = 0xFFFFFFFFu;     // low bits 7
 constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current instance
 
@@ -1082,6 +1086,7 @@ struct Walker {
     uint16_t* stack16;
     uint32_t sp, cur, curInst;
     bool inBlas;
+    bool overflow; // an entry did not fit the stack: the query's photon ends with ERROR_CODE_TRACE_ABORT
     f3 org, dir, ao;
     QRay sr, wsr;
     WoopRay w;
@@ -1100,12 +1105,15 @@ struct Walker {
         s16 = L.a->stack16 != 0u;
         stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
-        sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false;
+        sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false; overflow = false;
         w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
         h.valid = false; h.instance = 0; h.prim = 0; h.t = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
     }
+    // The host sizes the stack for the scene (hierarchy depth + 2), so a full stack means a broken
+    // invariant; it is not silent: the walk goes on without the entry and its photon is ended with
+    // ERROR_CODE_TRACE_ABORT, counted like every other device error (callback.stat.glsl:66-69).
     THX_DEV void push(uint32_t v) {
-        if (sp >= depth) return;
+        if (sp >= depth) { overflow = true; return; }
         if (s16) stack16[sp * 64] = (uint16_t)v;
         else stack32[sp * 64] = v;
         ++sp;
@@ -1126,7 +1134,7 @@ struct Walker {
         org = o; dir = d;
         h.valid = false; h.instance = 0; h.prim = 0; h.t = tmax; h.b1 = 0.0f; h.b2 = 0.0f;
         L.cnt.add(ST_QUERIES);
-        sp = 0; inBlas = false; curInst = 0;
+        sp = 0; inBlas = false; curInst = 0; overflow = false;
         // active ray: world space in the TLAS, object space inside an instance
         ao = org;
         sr = qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir);
@@ -1170,7 +1178,10 @@ struct Walker {
         const unsigned long long pt0 = __builtin_amdgcn_s_memtime();
         pRounds += 1;
 #endif
-        // open inner nodes until this lane holds a leaf
+        // open inner nodes until this lane holds a leaf -- or until so few lanes of the wave are still at inner
+        // nodes (fewer than THX_INNER_KEEP / 8 of those that started the loop) that the others should not wait any
+        // longer: everybody leaves then, lanes holding a leaf process it, the rest go on in the next round
+        const uint32_t innerKeep = ((uint32_t)__popcll(__ballot((cur & 7u) == 0u)) * (uint32_t)THX_INNER_KEEP) >> 3;
         while ((cur & 7u) == 0u) {
 #ifdef THX_STAGE_PROFILE
             pTrips += 1; // lane 0's count is what gets reported: trips of the wave while lane 0 is in the loop
@@ -1213,6 +1224,7 @@ struct Walker {
             } else {
                 cur = pop();
             }
+            if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
         }
 #ifdef THX_STAGE_PROFILE
         const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
@@ -1222,7 +1234,7 @@ struct Walker {
             __device__ ~Tail() { const unsigned long long d = __builtin_amdgcn_s_memtime() - t1; if (tri) leaf += d; else other += d; }
         } tail{pt1, pLeaf, pOther, inBlas && cur != WALK_DONE && cur != WALK_SENTINEL};
 #endif
-        if (cur == WALK_DONE) return;
+        if (cur == WALK_DONE || (cur & 7u) == 0u) return; // finished, or still at an inner node (early exit above)
         if (cur == WALK_SENTINEL) { // back to world space
             inBlas = false;
             ao = org; sr = wsr;
@@ -1275,6 +1287,7 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
     while (!wk.done()) wk.advance();
 #endif
     if (wk.h.valid) L.cnt.add(ST_HITS);
+    wk.h.aborted = wk.overflow;
 #ifdef THX_STAGE_PROFILE
     if ((threadIdx.x & 63u) == 0u && L.prof != nullptr) { // wave-level sums (s_memtime is uniform)
         atomicAdd(&L.prof[24], wk.pInner); atomicAdd(&L.prof[25], wk.pLeaf); atomicAdd(&L.prof[26], wk.pOther);
@@ -1676,6 +1689,11 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
         qh.valid = false;
         if (need) qh = rayQuery(L, ray.position, qd, qmax);
         if (!need) continue;
+        if (qh.aborted) { // traversal stack overflow: the photon ends with an error, a shadow ray contributes nothing
+            if (q == 0) result = ERROR_CODE_TRACE_ABORT;
+            else L.cnt.add(ST_ERROR);
+            continue;
+        }
 
         // the ray whose state the hit is evaluated with
         Ray s = ray;
