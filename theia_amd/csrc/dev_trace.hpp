@@ -200,8 +200,10 @@ THX_DEV void response(Lane<V>& L, const HitItem& item) {
     L.cnt.add(ST_RESPONSES);
     // `uint bin = int(floor(..))`: negative values wrap and fail bin < N_BINS
     if (f >= 0.0f && f < (float)L.a->n_bins) {
-        uint32_t bin = (uint32_t)f;
+        [[maybe_unused]] uint32_t bin = (uint32_t)f;
+#ifndef THX_NO_HIST_ATOMIC // (attribution of LDS bank conflicts only: profiles/r02_lds_conflicts.txt)
         if (bin < L.a->n_bins) atomicAdd(&ldsHist()[bin], item.contrib);
+#endif
     }
 }
 
@@ -1104,7 +1106,13 @@ struct Walker {
         // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
         s16 = L.a->stack16 != 0u;
         stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
+#ifdef THX_STACK16_LINEAR // the first layout: lanes 2k and 2k+1 share an LDS bank (profiles/r02_lds_conflicts.txt)
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
+#else
+        // 16-bit entries: lanes l and l + 32 share a 32-bit word, so the 32 lanes the LDS serves per cycle
+        // touch 32 different banks whatever their stack pointers are
+        stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (((threadIdx.x & 31u) << 1) | ((threadIdx.x >> 5) & 1u));
+#endif
         sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false; overflow = false;
         w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
         h.valid = false; h.instance = 0; h.prim = 0; h.t = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
