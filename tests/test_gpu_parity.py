@@ -7,10 +7,12 @@ paths: the kernels and the oracle perform the same IEEE operations in the same
 order (both built with -ffp-contract=off); they differ only in libm (glibc vs
 ROCm device libs: log/exp/sin/cos within ~1-2 ulp). A photon whose branch
 decision sits within that noise takes another path, so per-photon event codes
-must agree for >= 99.5 % of the photons and light curves -- accumulated with
-fp32 atomics in arbitrary order on the device -- must agree to 2e-3 of the curve's
-total per bin (fp32 Monte-Carlo tolerance of the north star; statistical noise
-at these sample sizes is >10x larger).
+must agree for >= 99.9 % of the photons (99.8 % on the two largest scenes) and light curves --
+accumulated with fp32 atomics in arbitrary order on the device -- to 1e-5 of the curve's total
+per bin. (The north star's fp32 Monte-Carlo tolerance is 2e-3; what is observed on MI355X,
+tools/parity_margins.py: identical event codes for 100 % of 20 000 photons on every scene and
+curves within 4e-8 -- the tolerances here leave room for a handful of libm-noise flips, not for
+a bug. Only the volume tracer without target sampling is looser, see there.)
 """
 import numpy as np
 import pytest
@@ -157,7 +159,7 @@ def _mask_after_first_detection(track):
     return ~seen_before
 
 
-def _compare(res, n, *, code_agree=0.995, hist_tol=2e-3, chaotic_after_detect=False):
+def _compare(res, n, *, code_agree=0.999, hist_tol=1e-5, chaotic_after_detect=False):
     (_, ho, so, to), (_, hg, sg, tg) = res
     if chaotic_after_detect and to is not None:
         # VolumeForwardTracer without target sampling keeps tracing after a detection
@@ -194,7 +196,10 @@ def test_volume_tracer_parity(hip_backend, polarized, mis):
     if mis:
         _compare(res, n)
     else:
-        _compare(res, n, chaotic_after_detect=True, hist_tol=2e-2, code_agree=0.97)
+        # without target sampling photons go on after a detection from a point ON the target sphere, where the
+        # reference's own intersectTarget is decided by the last bit (see _compare): those events are masked, and
+        # their responses move the curve by 1.5e-4 of its total (observed) -- the north star's 2e-3 is the bound
+        _compare(res, n, chaotic_after_detect=True, hist_tol=2e-3, code_agree=0.995)
 
 
 @pytest.mark.parametrize("polarized", [False, True])
@@ -218,7 +223,7 @@ def test_scene_tracer_parity_suzanne_grid(hip_backend):
     n = 8000
     res = _both(S.config5_suzanne_grid, batch=n, n_side=4, polarized=True, stats=True, track=True)
     assert res[0][2][11] > 0  # the oracle sees media mismatches (suzanne's eyes are separate shells)
-    _compare(res, n, code_agree=0.99)
+    _compare(res, n)
 
 
 def test_scene_tracer_parity_suzanne_grid_full_size(hip_backend):
@@ -229,7 +234,7 @@ def test_scene_tracer_parity_suzanne_grid_full_size(hip_backend):
     res = _both(S.config5_suzanne_grid, batch=n, n_side=10, polarized=True, stats=True, track=True)
     assert res[1][0].scene.info["n_instances"] == 1001
     assert res[0][2][11] > 0  # media mismatches are counted on both sides
-    _compare(res, n, code_agree=0.99)
+    _compare(res, n)
 
 
 def test_config3_batches_through_the_scheduler(hip_backend):
@@ -391,7 +396,7 @@ def test_scene_with_thousands_of_instances(hip_backend, kernel, monkeypatch):
     sc = res[1][0]
     info = sc.tracer.program.launch_info(n)
     assert (info["block"] == 256) == (kernel == "lane")
-    _compare(res, n, code_agree=0.99)
+    _compare(res, n, code_agree=0.998)
 
 
 def test_mesh_with_a_million_triangles(hip_backend):
@@ -399,4 +404,4 @@ def test_mesh_with_a_million_triangles(hip_backend):
     staged kernel follows the oracle"""
     n = 4000
     res = _both(S.config2_sphere, batch=n, stats=True, track=True, subdivide=5)
-    _compare(res, n, code_agree=0.99)
+    _compare(res, n, code_agree=0.998)
