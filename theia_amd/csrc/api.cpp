@@ -71,6 +71,7 @@ struct thx_tracer {
     uint32_t gridMax = 1;
     uint32_t refillBelow = 63;
     float* slabs[2] = {nullptr, nullptr};
+    float* cold = nullptr;        // staged kernel: cold chunks of the photon pools in global memory (one array per workgroup)
     float* out[2] = {nullptr, nullptr};
     uint32_t lastGrid[2] = {0, 0};
     unsigned long long* stats = nullptr;
@@ -429,7 +430,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
             t->pool = withNodes;
             t->mode |= 4u;
         }
-        if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(1024, std::max(64, std::atoi(env)));
+        if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(4080, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
     } else {
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
@@ -455,6 +456,10 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     for (uint32_t i = 0; i < thx_tracer::kRing && e == hipSuccess; ++i) {
         e = hipEventCreate(&t->evStart[i]);
         if (e == hipSuccess) e = hipEventCreate(&t->evStop[i]);
+    }
+    if (e == hipSuccess && t->staged) {
+        const size_t nb = stagedColdBytes(pol, t->pool) * t->gridMax;
+        if (nb) e = hipMalloc((void**)&t->cold, nb);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
     if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
@@ -518,6 +523,7 @@ int thx_tracer_destroy(thx_tracer* t) {
         if (t->evStop[i]) (void)hipEventDestroy(t->evStop[i]);
     }
     if (t->stats) (void)hipFree(t->stats);
+    if (t->cold) (void)hipFree(t->cold);
     if (t->prof) (void)hipFree(t->prof);
     if (t->devError) (void)hipFree(t->devError);
     if (t->track) (void)hipFree(t->track);
@@ -592,6 +598,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.lds_nodes_count = t->ldsNodes;
     a.lds_nodes_word = (t->desc.n_bins + 3u) & ~3u;
     a.slabs = t->slabs[cfg];
+    a.cold = t->cold;
     a.stats = t->stats;
     a.error = t->devError;
     a.prof = t->prof;

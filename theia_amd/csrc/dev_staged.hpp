@@ -31,6 +31,9 @@
 namespace thx {
 
 constexpr uint32_t kSchedThreads = 1024; // upper bound of the workgroup size
+#ifndef THX_POOL_MAX
+#define THX_POOL_MAX 2048 // upper bound of the photon pool of a workgroup (ring entries carry 12-bit slot ids: < 4096)
+#endif
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
 
 // stage ids == queue ids. The BIRTH queue is the free list of pool slots.
@@ -61,8 +64,17 @@ constexpr uint32_t F_PEND_SHIFT = 28, F_PEND_ONE = 1u << 28;     // outstanding 
 
 template <bool POL>
 struct StagedLayout {
-    static constexpr uint32_t NCH = POL ? 7u : 5u; // state chunks (float4) per photon
-    static constexpr uint32_t NSC = 2u;            // scratch chunks per photon
+    // A photon's state: three HOT chunks (float4) that the scheduler-side stages and the walk read -- position + time,
+    // direction + wavelength, meta (index, RNG dimension, flags incl. the pending-walk counter, shadow-ray length) --
+    // and COLD chunks only the shading stages touch: contributions + medium, medium constants[, Stokes vector,
+    // polarization reference]. Hot chunks and the scratch live in LDS, the cold ones in global memory (one array per
+    // workgroup, 32 / 64 B per photon: L2 resident): 112 / 144 -> 80 B of LDS per photon. Photons in flight per CU are
+    // what the throughput follows: pool 800 -> 1232 on config 3, 704 -> 1024 (and 12 -> 16 wavefronts) on
+    // config 5, 1024 -> 1264 on config 2; measured -12 % / -15 % / -3 % kernel time.
+    static constexpr uint32_t NHOT = 3u;
+    static constexpr uint32_t NCOLD = POL ? 4u : 2u;
+    static constexpr uint32_t NCH = NHOT; // state chunks per photon in LDS
+    static constexpr uint32_t NSC = 2u;                                 // scratch chunks per photon
     // ring capacity of a queue: power of two >= pool (the TS ring takes two of them)
     static constexpr uint32_t qcap(uint32_t pool) {
         uint32_t c = 64;
@@ -77,18 +89,29 @@ struct StagedLayout {
     }
     // largest pool (multiple of 16, <= 1024) that fits `budget` bytes of LDS
     static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes = 0) {
-        uint32_t p = 1024;
+        uint32_t p = THX_POOL_MAX;
         while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, ldsNodes) > budget) p -= 16;
         return p;
     }
+    // bytes of global memory one workgroup needs for its cold chunks
+    static constexpr size_t coldBytes(uint32_t pool) { return (size_t)NCOLD * pool * 16; }
 };
 
 template <class V>
 struct Pool {
-    float4* st;       // [NCH][P]
-    float4* sc;       // [NSC][P]
+    using Lay = StagedLayout<V::POL>;
+    float4* st;       // LDS [NHOT][P]: chunk 0 (position, time), 1 (direction, wavelength), 2 (meta)
+    float4* sc;       // LDS [NSC][P]
     uint16_t* q;      // rings
     uint32_t* ctr;    // counters
+    typedef float vec4 __attribute__((ext_vector_type(4))); // (HIP's float4 has no constructors for address-space qualified objects)
+    THX_GLOBAL vec4* cold; // global [NCOLD][P] of this workgroup
+    // cold chunk k: 0 {lin, log, medium}, 1 {n, vg, mu_s, mu_e}, 2 {stokes}, 3 {polRef}
+    THX_DEV float4 ldCold(uint32_t k, uint32_t slot) const {
+        const vec4 v = cold[k * P + slot];
+        return make_float4(v.x, v.y, v.z, v.w);
+    }
+    THX_DEV void stCold(uint32_t k, uint32_t slot, float4 v) const { cold[k * P + slot] = vec4{v.x, v.y, v.z, v.w}; }
     uint32_t P, cap, capShift; // pool size, ring capacity (power of two >= P) and its log2
     // ring s holds slot ids; the TS ring (last) has room for 2 cap entries (two shadow rays per photon)
     uint32_t qHalf, ctrWord; // LDS half-word index of ring 0, LDS word index of the counters
@@ -98,7 +121,7 @@ struct Pool {
     // lap tag of ring position `pos` (bit 14 of the cell): a claimer never takes the entry of
     // the previous lap for its own, however late that lap's claimer empties the cell
     THX_DEV uint32_t lapTag(int s, uint32_t pos) const { return ((pos >> (s == S_TS ? capShift + 1u : capShift)) & 1u) << 14; }
-    THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[4 * P + slot]) + 2; }
+    THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[2 * P + slot]) + 2; }
 };
 
 // Scheduler accesses to LDS that other wavefronts change concurrently: relaxed atomics on
@@ -112,12 +135,11 @@ THX_DEV void ldsWrite32(uint32_t word, uint32_t v) { __atomic_store_n(reinterpre
 constexpr uint32_t kNoCell = 0xFFFFFFFFu;
 
 // ---- state <-> registers -------------------------------------------------
-// chunk0 {pos.xyz, time} chunk1 {dir.xyz, wavelength} chunk2 {lin, log, medium lo, hi}
-// chunk3 {n, vg, mu_s, mu_e} chunk4 {local idx, dim, flags, distShadow}
-// chunk5 {stokes} chunk6 {polRef.xyz, -}
+// hot 0 {pos.xyz, time}  hot 1 {dir.xyz, wavelength}  hot 2 {local idx, dim, flags, distShadow}
+// cold 0 {lin, log, medium lo, hi}  cold 1 {n, vg, mu_s, mu_e}  cold 2 {stokes}  cold 3 {polRef.xyz, -}
 template <class V>
 THX_DEV Ray loadRay(const Pool<V>& p, uint32_t s) {
-    float4 c0 = p.st[0 * p.P + s], c1 = p.st[1 * p.P + s], c2 = p.st[2 * p.P + s], c3 = p.st[3 * p.P + s];
+    const float4 c0 = p.st[0 * p.P + s], c1 = p.st[1 * p.P + s], c2 = p.ldCold(0, s), c3 = p.ldCold(1, s);
     Ray r;
     r.position = f3{c0.x, c0.y, c0.z};
     r.time = c0.w;
@@ -130,7 +152,7 @@ THX_DEV Ray loadRay(const Pool<V>& p, uint32_t s) {
     r.stokes = f4{1, 0, 0, 0};
     r.polRef = f3{0, 0, 0};
     if constexpr (V::POL) {
-        float4 c5 = p.st[5 * p.P + s], c6 = p.st[6 * p.P + s];
+        const float4 c5 = p.ldCold(2, s), c6 = p.ldCold(3, s);
         r.stokes = f4{c5.x, c5.y, c5.z, c5.w};
         r.polRef = f3{c6.x, c6.y, c6.z};
     }
@@ -140,12 +162,11 @@ template <class V>
 THX_DEV void storeRay(const Pool<V>& p, uint32_t s, const Ray& r) {
     p.st[0 * p.P + s] = make_float4(r.position.x, r.position.y, r.position.z, r.time);
     p.st[1 * p.P + s] = make_float4(r.direction.x, r.direction.y, r.direction.z, r.wavelength);
-    p.st[2 * p.P + s] = make_float4(r.lin_contrib, r.log_contrib, __uint_as_float((uint32_t)r.medium),
-                                    __uint_as_float((uint32_t)(r.medium >> 32)));
-    p.st[3 * p.P + s] = make_float4(r.constants.n, r.constants.vg, r.constants.mu_s, r.constants.mu_e);
+    p.stCold(0, s, make_float4(r.lin_contrib, r.log_contrib, __uint_as_float((uint32_t)r.medium), __uint_as_float((uint32_t)(r.medium >> 32))));
+    p.stCold(1, s, make_float4(r.constants.n, r.constants.vg, r.constants.mu_s, r.constants.mu_e));
     if constexpr (V::POL) {
-        p.st[5 * p.P + s] = make_float4(r.stokes.x, r.stokes.y, r.stokes.z, r.stokes.w);
-        p.st[6 * p.P + s] = make_float4(r.polRef.x, r.polRef.y, r.polRef.z, 0.0f);
+        p.stCold(2, s, make_float4(r.stokes.x, r.stokes.y, r.stokes.z, r.stokes.w));
+        p.stCold(3, s, make_float4(r.polRef.x, r.polRef.y, r.polRef.z, 0.0f));
     }
 }
 
@@ -155,12 +176,12 @@ struct Meta {
 };
 template <class V>
 THX_DEV Meta loadMeta(const Pool<V>& p, uint32_t s) {
-    float4 c = p.st[4 * p.P + s];
+    float4 c = p.st[2 * p.P + s];
     return Meta{__float_as_uint(c.x), __float_as_uint(c.y), __float_as_uint(c.z), c.w};
 }
 template <class V>
 THX_DEV void storeMeta(const Pool<V>& p, uint32_t s, const Meta& m) {
-    p.st[4 * p.P + s] = make_float4(__uint_as_float(m.local), __uint_as_float(m.dim), __uint_as_float(m.flags), m.distShadow);
+    p.st[2 * p.P + s] = make_float4(__uint_as_float(m.local), __uint_as_float(m.dim), __uint_as_float(m.flags), m.distShadow);
 }
 template <class V>
 THX_DEV void bindLane(Lane<V>& L, const Meta& m) {
@@ -274,6 +295,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const uint32_t nodeWords = V::LDSBVH ? args.lds_nodes_count * 8u : 0u; // == args.lds_nodes_word - histWords
     pool.st = reinterpret_cast<float4*>(ldsWords() + histWords + nodeWords);
     pool.sc = pool.st + Lay::NCH * P;
+    pool.cold = (THX_GLOBAL typename Pool<V>::vec4*)(args.cold) + (size_t)blockIdx.x * Lay::NCOLD * P;
     const uint32_t stackWord0 = histWords + nodeWords + (Lay::NCH + Lay::NSC) * P * 4;
     if constexpr (V::LDSBVH) { // stage the node array (TLAS + every BLAS) into LDS, 16 B per lane
         const float4* src = reinterpret_cast<const float4*>(args.scene.nodes);
@@ -536,7 +558,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     float4 d = pool.sc[(which - 1u) * P + slot];
                     dir = f3{d.x, d.y, d.z};
                     weight = d.w;
-                    tmax = pool.st[4 * P + slot].w;
+                    tmax = pool.st[2 * P + slot].w;
                 }
 #ifdef THX_STAGE_PROFILE
                 const unsigned long long wt0 = __builtin_amdgcn_s_memtime();

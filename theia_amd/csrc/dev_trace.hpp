@@ -43,6 +43,7 @@ struct LaunchArgs {
     uint32_t lds_nodes_word;   // LDSBVH variants: LDS word offset of the staged node array
     uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
+    float* cold;               // staged kernel: [gridDim.x][2 or 4][pool] float4 = the cold chunks of the photon pools (dev_staged.hpp)
     uint32_t* hits;            // HitRecorder queue (response.queue.glsl layout) or null: histogram response
     uint32_t hit_capacity;     // entries per SoA column of the queue
     uint32_t hit_polarized;    // queue has the stokes / polRef columns (store-time queue: the objectId column)

@@ -32,6 +32,7 @@ size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThr
 uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes) {
     return polarized ? StagedLayout<true>::poolFor(n_bins, stackBytesPerThread, budget, threads, ldsNodes) : StagedLayout<false>::poolFor(n_bins, stackBytesPerThread, budget, threads, ldsNodes);
 }
+size_t stagedColdBytes(bool polarized, uint32_t pool) { return polarized ? StagedLayout<true>::coldBytes(pool) : StagedLayout<false>::coldBytes(pool); }
 static_assert(kStagedBlock == kSchedThreads, "staged block size");
 
 // estimator.reduce.glsl:17-35: out[b] = norm * sum_h slab[h][b] with compensated
