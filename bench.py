@@ -91,6 +91,17 @@ def priced(units: dict, bytes_per: dict, grid: int, n_bins: int, launches: int) 
     return sum(bytes_per[k] * units[k] for k in bytes_per) + launches * grid * n_bins * 4.0 * 2.0
 
 
+def allreduce(dist, t, op=None):
+    """in-place all-reduce; the gloo rehearsal (ranks sharing a GPU) goes through host memory"""
+    kw = {} if op is None else {"op": op}
+    if t.is_cuda and dist.get_backend() == "gloo":
+        c = t.cpu()
+        dist.all_reduce(c, **kw)
+        t.copy_(c)
+    else:
+        dist.all_reduce(t, **kw)
+
+
 class Measurement:
     """W warm-up + K timed batches of one workload on this rank's GPU, and the instrumented replay that
     counts their photon-steps and traversal units"""
@@ -140,7 +151,7 @@ class Measurement:
             step(k, scratch.data_ptr())
         if dist is not None:
             torch.cuda.synchronize()
-            dist.all_reduce(scratch)  # warm the communicator outside the timed region
+            allreduce(dist, scratch)  # warm the communicator outside the timed region
             dist.barrier()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -150,7 +161,7 @@ class Measurement:
             # the tracer works on the library's own (non-blocking) stream when torch's current stream
             # is the default one: finish the reductions into `curves` before RCCL reads them
             torch.cuda.synchronize()
-            dist.all_reduce(curves)  # the single collective: K x n_bins floats
+            allreduce(dist, curves)  # the single collective: K x n_bins floats
         torch.cuda.synchronize()
         if dist is not None:
             dist.barrier()
@@ -265,8 +276,8 @@ def main() -> None:
     t_max = torch.tensor([m.elapsed], dtype=torch.float64, device=dev)
     total_steps = torch.tensor([m.steps_local], dtype=torch.float64, device=dev)
     if dist is not None:
-        dist.all_reduce(t_max, op=dist.ReduceOp.MAX)
-        dist.all_reduce(total_steps, op=dist.ReduceOp.SUM)
+        allreduce(dist, t_max, dist.ReduceOp.MAX)
+        allreduce(dist, total_steps, dist.ReduceOp.SUM)
     elapsed = float(t_max.item())
     steps_all = float(total_steps.item())
     global_batch = B * world
@@ -305,7 +316,8 @@ def main() -> None:
             "photons_total": global_batch * K,
             "photon_steps_total": steps_all,
             "steps_per_photon": steps_all / (global_batch * K),
-            "sharding": f"photon index ranges x{world}, one RCCL all-reduce of {K}x{m.n_bins} f32" if world > 1 else "single GPU",
+            "sharding": (f"photon index ranges x{world}, one {'RCCL' if backend == 'nccl' else backend + ' (rehearsal: ranks share GPUs)'} "
+                         f"all-reduce of {K}x{m.n_bins} f32") if world > 1 else "single GPU",
             "launch": m.info,
             "scene": m.scene_info,
         },
