@@ -1,7 +1,8 @@
 """
-Analytic sphere detector of the volume tracer and sphere guide of the scene
-tracer (reference: src/theia/target.py:45-139, :440-525; device side
-shader/target.sphere.glsl, target_guide.sphere.glsl).
+Detector shapes: the analytic targets of the volume tracers (sphere seen from outside / inside, disk, rectangle) and
+the target guides of the scene tracers (sphere, disk, rectangle). Host side only: parameter blocks with the
+reference's layouts (src/theia/target.py:45-735) and their derived fields; the device side is
+`theia_amd/csrc/dev_trace.hpp` (shader/target.*.glsl, target_guide.*.glsl).
 """
 from __future__ import annotations
 
@@ -17,21 +18,57 @@ __all__ = ["Target", "SphereTarget", "InnerSphereTarget", "FlatTarget", "DiskTar
            "FlatTargetGuide", "DiskTargetGuide"]
 
 
-class Target(SourceCodeMixin):
-    name = "Target"
+class _Sampled(SourceCodeMixin):
+    """what targets and target guides have in common: a stage with parameter blocks that draws a fixed number of
+    random numbers per sample"""
 
     def __init__(self, *, nRNGSamples: int, params: dict = {}, extra: set = set()) -> None:
         super().__init__(params, extra)
-        self._nRNGSamples = nRNGSamples
+        self._draws = int(nRNGSamples)
 
-    @property
-    def nRNGSamples(self) -> int:
-        return self._nRNGSamples
+    nRNGSamples = property(lambda self: self._draws, doc="random numbers drawn per sample")
 
 
-class SphereTarget(Target):
-    """Sphere sampled over the cap visible from the observer; hits are reported
-    on the unit sphere of the target's local frame."""
+class Target(_Sampled):
+    """Detector shape of the volume tracers (reference target.py:45-75)."""
+
+    name = "Target"
+
+
+class TargetGuide(_Sampled):
+    """Shape the scene tracers aim their next-event samples at (reference target.py:440-467)."""
+
+    name = "Target Guide"
+
+
+def _frame(axis, up=None) -> np.ndarray:
+    """3x3 rotation whose columns are the x, y, z axes of an object frame in world space, z along `axis`. With `up`
+    the y axis is as close to it as possible (= the rotation part of `Transform.View`); without, x and y are the
+    branch-free orthonormal basis of Duff et al. 2017 -- the same one the shaders build (math.glsl:45-55)."""
+    z = np.asarray(axis, dtype=np.float64)
+    z = z / np.linalg.norm(z)
+    if up is not None:
+        x = np.cross(np.asarray(up, dtype=np.float64), z)
+        x /= np.linalg.norm(x)
+        y = np.cross(z, x)
+        return np.column_stack([x, y / np.linalg.norm(y), z])
+    s = np.copysign(1.0, z[2])
+    a = -1.0 / (s + z[2])
+    b = z[0] * z[1] * a
+    return np.column_stack([(1.0 + s * z[0] * z[0] * a, s * b, -s * z[0]), (b, s + z[1] * z[1] * a, -z[1]), z])
+
+
+class _SphereShape:
+    """`position`, `radius` and the unit-sphere frame `_invPos`, `_invRad` hits are reported in"""
+
+    def _unit_frame(self) -> dict:
+        r = self.getParam("radius")
+        return {"_invPos": tuple(-c / r for c in self.getParam("position")), "_invRad": 1.0 / r}
+
+
+class SphereTarget(_SphereShape, Target):
+    """Sphere seen from outside, sampled over the cap visible from the observer; hits are reported on the unit sphere
+    of the target's own frame. Reference target.py:78-139, shader/target.sphere.glsl."""
 
     name = "Sphere Target"
 
@@ -39,19 +76,18 @@ class SphereTarget(Target):
         _fields_ = [("position", vec3), ("radius", c_float), ("_invPos", vec3), ("_invRad", c_float), ("_hemisphereProb", c_float)]
 
     def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams})
+        Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams})
         self.setParams(position=position, radius=radius)
 
     def _finishParams(self, i: int) -> None:
-        r = self.getParam("radius")
-        x, y, z = self.getParam("position")
-        self.setParams(_hemisphereProb=1.0 / (2.0 * np.pi * r**2), _invPos=(-x / r, -y / r, -z / r), _invRad=1.0 / r)
+        half_area = 2.0 * np.pi * self.getParam("radius") ** 2
+        self.setParams(_hemisphereProb=1.0 / half_area, **self._unit_frame())
 
 
-class InnerSphereTarget(Target):
-    """Sphere seen from the inside (the light is inside the target); sampled uniformly over its
-    surface. Hits are reported on the unit sphere of the target's local frame with the normal
-    pointing to the centre. Reference: target.py:142-199, shader/target.sphere.inner.glsl."""
+class InnerSphereTarget(_SphereShape, Target):
+    """Sphere seen from the inside (the light is inside the target), sampled uniformly over its whole surface; hits on
+    the unit sphere of the target's own frame, normal towards the centre. Reference target.py:142-199,
+    shader/target.sphere.inner.glsl."""
 
     name = "Inner Sphere Target"
 
@@ -59,39 +95,29 @@ class InnerSphereTarget(Target):
         _fields_ = [("position", vec3), ("radius", c_float), ("_invPos", vec3), ("_invRad", c_float), ("_prob", c_float)]
 
     def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams})
+        Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams})
         self.setParams(position=position, radius=radius)
 
     def _finishParams(self, i: int) -> None:
-        r = self.getParam("radius")
-        x, y, z = self.getParam("position")
-        self.setParams(_prob=1.0 / (4.0 * np.pi * r**2), _invPos=(-x / r, -y / r, -z / r), _invRad=1.0 / r)
+        area = 4.0 * np.pi * self.getParam("radius") ** 2
+        self.setParams(_prob=1.0 / area, **self._unit_frame())
 
 
-def _viewMatrix(direction, up) -> np.ndarray:
-    """inner (rotation) matrix of `Transform.View(direction=direction, up=up)`: columns x, y, z of the
-    object frame in world space; `up=None`: any frame around `direction` (PBRT 4th ed., ch. 3.3.3)"""
-    unit = lambda v: v / np.sqrt(np.square(v).sum(-1))
-    z = unit(np.array(direction, dtype=np.float64))
-    if up is None:
-        vx, vy, vz = z
-        sign = np.copysign(1.0, vz)
-        a = -1.0 / (sign + vz)
-        b = vx * vy * a
-        x = np.array([1.0 + sign * vx**2 * a, sign * b, -sign * vx])
-        y = np.array([b, sign + vy**2 * a, -vy])
-    else:
-        x = unit(np.cross(np.array(up, dtype=np.float64), z))
-        y = unit(np.cross(z, x))
-    return np.stack([x, y, z], -1)
+class _PlaneShape:
+    """flat shapes: the object frame (z = normal) as a column-major 3x3 block plus the uniform density 1 / area"""
+
+    def _plane(self, axis, up, area: float, *, transposed: bool = True) -> None:
+        m = _frame(axis, up)
+        self.setParams(_objToWorld=m.T if transposed else m, _normal=m[:, 2], _prob=1.0 / area)
 
 
-class FlatTarget(Target):
+class FlatTarget(_PlaneShape, Target):
     """
     Rectangular target: in its local frame it lies in the xy plane centred at the origin, `width`
     along x, `length` along y, the normal `direction` along +z, `up` along +y; both sides detect
     and are told apart by the sign of the local normal. Parameters / stage parameters as in the
     reference (target.py:200-317, shader/target.flat.glsl): `width, length, position, direction, up`.
+    `missIsInfinite` is this backend's extension (see `targetFlags`).
     """
 
     name = "Flat Target"
@@ -102,25 +128,21 @@ class FlatTarget(Target):
 
     def __init__(self, *, width: float = 1.0 * u.cm, length: float = 1.0 * u.cm, position=(0.0, 0.0, 0.0),
                  direction=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), missIsInfinite: bool = False) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"direction", "up"})
-        self.missIsInfinite = missIsInfinite  # extension, see `targetFlags`
-        self.direction = direction
-        self.up = up
+        Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"direction", "up"})
+        self.missIsInfinite, self.direction, self.up = missIsInfinite, direction, up
         self.setParams(width=width, length=length, position=position)
 
     def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
-        m = _viewMatrix(self.direction, self.up)
-        self.setParam("_objToWorld", m.T)  # column major
-        self.setParam("_normal", m[:, 2])
-        self.setParam("_prob", 1.0 / (self.width * self.length))
+        Target._finishParams(self, i)
+        self._plane(self.direction, self.up, self.width * self.length)
 
 
-class DiskTarget(Target):
+class DiskTarget(_PlaneShape, Target):
     """
     Circular target: in its local frame it lies in the xy plane centred at the origin with the
-    `normal` along +z and `up` along +y; both sides detect. Parameters / stage parameters as in
-    the reference (target.py:320-425, shader/target.disk.glsl): `position, radius, normal, up`.
+    `normal` along +z and `up` along +y (None: any frame about the normal); both sides detect. Parameters / stage
+    parameters as in the reference (target.py:320-425, shader/target.disk.glsl): `position, radius, normal, up`.
+    `missIsInfinite` is this backend's extension (see `targetFlags`).
     """
 
     name = "Disk Target"
@@ -130,34 +152,18 @@ class DiskTarget(Target):
 
     def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m, normal=(0.0, 0.0, 1.0), up=None,
                  missIsInfinite: bool = False) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"normal", "up"})
-        self.missIsInfinite = missIsInfinite  # extension, see `targetFlags`
-        self.normal = normal
-        self.up = up
+        Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"normal", "up"})
+        self.missIsInfinite, self.normal, self.up = missIsInfinite, normal, up
         self.setParams(position=position, radius=radius)
 
     def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
-        m = _viewMatrix(self.normal, self.up)
-        self.setParam("_objToWorld", m.T)  # column major
-        self.setParam("_normal", m[:, 2])  # normalised
-        self.setParam("_prob", 1.0 / (np.pi * self.getParam("radius") ** 2))
-
-
-class TargetGuide(SourceCodeMixin):
-    name = "Target Guide"
-
-    def __init__(self, *, nRNGSamples: int, params: dict = {}, extra: set = set()) -> None:
-        super().__init__(params, extra)
-        self._nRNGSamples = nRNGSamples
-
-    @property
-    def nRNGSamples(self) -> int:
-        return self._nRNGSamples
+        Target._finishParams(self, i)
+        self._plane(self.normal, self.up, np.pi * self.getParam("radius") ** 2)
 
 
 class SphereTargetGuide(TargetGuide):
-    """Guides scattered rays into the cone subtended by a sphere (samples its far side)."""
+    """Guides scattered rays into the cone a sphere subtends (samples its far side). Reference target.py:470-525,
+    shader/target_guide.sphere.glsl."""
 
     name = "Sphere Target Guide"
 
@@ -165,15 +171,14 @@ class SphereTargetGuide(TargetGuide):
         _fields_ = [("position", vec3), ("radius", c_float), ("_prob", c_float)]
 
     def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams})
+        TargetGuide.__init__(self, nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams})
         self.setParams(position=position, radius=radius)
 
     def _finishParams(self, i: int) -> None:
-        r = self.getParam("radius")
-        self.setParam("_prob", 1.0 / (2.0 * np.pi * r**2))
+        self.setParam("_prob", 1.0 / (2.0 * np.pi * self.getParam("radius") ** 2))
 
 
-class FlatTargetGuide(TargetGuide):
+class FlatTargetGuide(_PlaneShape, TargetGuide):
     """
     Rectangular target guide (`width` orthogonal to `normal` and `up`, `height` along `up`); only
     the face the normal points to is sampled -- from behind it the next event estimate is skipped.
@@ -189,24 +194,22 @@ class FlatTargetGuide(TargetGuide):
 
     def __init__(self, *, width: float = 1.0 * u.m, height: float = 1.0 * u.m, position=(0.0, 0.0, 0.0),
                  normal=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0)) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams}, extra={"normal", "up"})
-        self.normal = normal
-        self.up = up
+        TargetGuide.__init__(self, nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams}, extra={"normal", "up"})
+        self.normal, self.up = normal, up
         self.setParams(width=width, height=height, position=position)
 
     def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
-        m = _viewMatrix(self.normal, self.up)
-        self.setParam("_objToWorld", m.T)  # column major
-        self.setParam("_normal", m[:, 2])
-        self.setParam("_prob", 1.0 / (self.width * self.height))
+        TargetGuide._finishParams(self, i)
+        self._plane(self.normal, self.up, self.width * self.height)
 
 
-class DiskTargetGuide(TargetGuide):
+class DiskTargetGuide(_PlaneShape, TargetGuide):
     """
     Circular target guide; only the face the `normal` points to is sampled. Parameters / stage
     parameters as in the reference (target.py:639-735, shader/target_guide.disk.glsl):
-    `position, radius, normal`.
+    `position, radius, normal`. The frame matrix is handed to the device UNtransposed, unlike in every other
+    plane shape: that is what the reference does (target.py:734-735), kept bug for bug -- it only matters for
+    normals with a z component.
     """
 
     name = "Disk Target Guide"
@@ -215,16 +218,12 @@ class DiskTargetGuide(TargetGuide):
         _fields_ = [("position", vec3), ("radius", c_float), ("_normal", vec3), ("_prob", c_float), ("_objToWorld", mat3)]
 
     def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m, normal=(0.0, 0.0, 1.0)) -> None:
-        super().__init__(nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams}, extra={"normal"})
+        TargetGuide.__init__(self, nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams}, extra={"normal"})
         self.normal = normal
         self.setParams(position=position, radius=radius)
 
     def _finishParams(self, i: int) -> None:
-        r = self.getParam("radius")
-        self.setParam("_prob", 1.0 / (np.pi * r**2))
-        m = _viewMatrix(self.normal, None)
-        self.setParam("_normal", m[:, 2])
-        self.setParam("_objToWorld", m)  # as the reference passes it (target.py:734-735)
+        self._plane(self.normal, None, np.pi * self.getParam("radius") ** 2, transposed=False)
 
 
 # ---- what the HIP backend needs to know about targets and guides -----------------------------
