@@ -26,36 +26,24 @@ __all__ = ["HitItem", "PolarizedHitItem", "HitTimeItem", "HitTimeAndIdItem", "Tr
            "KernelHistogramHitResponse"]
 
 
-class HitItem(Structure):
-    """One hit in the object space of the detector it happened on (response.py:27-70,
-    shader/response.common.glsl:4-19)."""
+def _hit_columns(polarized: bool) -> list:
+    """columns of a hit in queue order (shader/response.common.glsl:4-19, response.queue.glsl:6-33): geometry in the
+    object space of the detector, [Stokes vector and its reference direction,] wavelength, time, contribution, id"""
+    geometry = [(name, c_float * 3) for name in ("position", "direction", "normal")]
+    polarization = [("stokes", c_float * 4), ("polarizationRef", c_float * 3)] if polarized else []
+    return geometry + polarization + [("wavelength", c_float), ("time", c_float), ("contrib", c_float), ("objectId", c_int32)]
 
-    _fields_ = [
-        ("position", c_float * 3),
-        ("direction", c_float * 3),
-        ("normal", c_float * 3),
-        ("wavelength", c_float),
-        ("time", c_float),
-        ("contrib", c_float),
-        ("objectId", c_int32),
-    ]
+
+class HitItem(Structure):
+    """One hit in the object space of the detector it happened on (response.py:27-70)."""
+
+    _fields_ = _hit_columns(polarized=False)
 
 
 class PolarizedHitItem(Structure):
-    """`HitItem` with the (normalised) Stokes vector and its reference direction
-    (response.py:73-92)."""
+    """`HitItem` with the (normalised) Stokes vector and its reference direction (response.py:73-92)."""
 
-    _fields_ = [
-        ("position", c_float * 3),
-        ("direction", c_float * 3),
-        ("normal", c_float * 3),
-        ("stokes", c_float * 4),
-        ("polarizationRef", c_float * 3),
-        ("wavelength", c_float),
-        ("time", c_float),
-        ("contrib", c_float),
-        ("objectId", c_int32),
-    ]
+    _fields_ = _hit_columns(polarized=True)
 
 
 @dataclass
@@ -71,34 +59,32 @@ class TraceConfig:
 
 
 class HitResponse(SourceCodeMixin):
-    """Base class of responses consuming the hits a tracer produces."""
+    """Base class of responses consuming the hits a tracer produces. A tracer calls `prepare(config)` once when it is
+    built and `updateConfig(config)` whenever its batch size changes (response.py:125-188)."""
 
     name = "Hit Response"
 
     def __init__(self, params: dict = {}, extra: set = set(), *, nRNGSamples: int = 0) -> None:
         super().__init__(params, extra)
-        self._nRNGSamples = nRNGSamples
+        self._draws = nRNGSamples
 
-    @property
-    def nRNGSamples(self) -> int:
-        """random numbers drawn per hit"""
-        return self._nRNGSamples
+    nRNGSamples = property(lambda self: self._draws, doc="random numbers drawn per hit")
 
     def prepare(self, config: TraceConfig) -> None:
-        """Called once by every tracer using this response during its construction."""
+        pass
 
     def updateConfig(self, config: TraceConfig) -> None:
-        """Called by the tracer whenever its configuration changes."""
+        pass
 
 
 class EmptyResponse(HitResponse):
     """Ignores all hits (response.empty.glsl). Runs as a one-bin histogram nobody reads."""
 
+    def __init__(self) -> None:
+        HitResponse.__init__(self)
+
     def run(self, i: int):
         return []
-
-    def __init__(self) -> None:
-        super().__init__()
 
 
 class HitRecorder(HitResponse):
@@ -116,46 +102,34 @@ class HitRecorder(HitResponse):
     name = "Hit Recorder"
 
     def __init__(self, *, capacity: int = 0, polarized: bool = False) -> None:
-        super().__init__()
-        self._capacity = capacity
-        self._polarized = polarized
+        HitResponse.__init__(self)
+        self._wanted, self._polarized, self._program = int(capacity), bool(polarized), None
         self._queue = IOQueue(PolarizedHitItem if polarized else HitItem, mode="retrieve")
-        self._program = None
-        if capacity > 0:
-            self._queue.initialize(capacity)
+        if self._wanted > 0:
+            self._queue.initialize(self._wanted)
+
+    capacity = property(lambda self: self._wanted, doc="maximum number of hits kept per batch")
+    polarized = property(lambda self: self._polarized, doc="the queue has the Stokes / reference columns")
+    queue = property(lambda self: self._queue, doc="IOQueue the hits of a batch are retrieved into")
+
+    def _fit(self, worst_case: int) -> None:
+        """a tracer can produce `worst_case` hits per batch: grow the (not yet allocated) queue, or say it is too small"""
+        if not self._queue.initialized:
+            self._wanted = max(self._wanted, worst_case)
+        elif worst_case > self._wanted:
+            warn(f"tracer reported maxHits: {worst_case}, but response was initialized with capacity: {self._wanted}")
 
     def prepare(self, config: TraceConfig) -> None:
-        maxHits = config.maxHitsPerThread * config.capacity
-        if self.queue.initialized and maxHits > self.capacity:
-            warn(f"tracer reported maxHits: {maxHits}, but response was initialized with capacity: {self.capacity}")
-        elif not self.queue.initialized:
-            self._capacity = max(self._capacity, maxHits)  # worst case over all tracers
+        self._fit(config.capacity * config.maxHitsPerThread)
 
     def updateConfig(self, config: TraceConfig) -> None:
-        maxHits = config.batchSize * config.maxHitsPerThread
-        if not self.queue.initialized:
-            self._capacity = max(maxHits, self._capacity)
-        elif maxHits > self.capacity:
-            warn(f"tracer reported maxHits: {maxHits}, but response was initialized with capacity: {self.capacity}")
-
-    @property
-    def capacity(self) -> int:
-        """maximum number of hits kept per batch"""
-        return self._capacity
-
-    @property
-    def polarized(self) -> bool:
-        return self._polarized
-
-    @property
-    def queue(self) -> IOQueue:
-        return self._queue
+        self._fit(config.batchSize * config.maxHitsPerThread)
 
     def _bindParams(self, program, i: int) -> None:
-        if not self.queue.initialized:
-            if self.capacity <= 0:
-                raise RuntimeError(f"Cannot create a queue of size {self.capacity}")
-            self.queue.initialize(self.capacity)
+        if not self._queue.initialized:
+            if self._wanted <= 0:
+                raise RuntimeError(f"Cannot create a queue of size {self._wanted}")
+            self._queue.initialize(self._wanted)
         super()._bindParams(program, i)
         self._program = program
 
@@ -163,7 +137,7 @@ class HitRecorder(HitResponse):
         def retrieve() -> None:
             if self._program is None:
                 raise RuntimeError("HitRecorder is not bound to a tracer")
-            self._program.read_hits(self.queue.buffer(i), clear=True)
+            self._program.read_hits(self._queue.buffer(i), clear=True)
 
         return [retrieve]
 
@@ -298,48 +272,24 @@ class HistogramHitResponse(HitResponse):
                 f"{type(response).__name__} has no compiled kernel variant (GLSL injection is not supported)")
         if nBins > self.MAX_SHARED_MEMORY_BINS:
             raise NotImplementedError(f"nBins > {self.MAX_SHARED_MEMORY_BINS} does not fit the LDS histogram")
-        self._response = response
         self.setParams(t0=t0, binSize=binSize)
-        self._nBins = nBins
-        self._normalization = normalization
+        self.normalization = normalization  # plain attribute: None = the tracer's 1 / batchSize
+        self._fixed = {"response": response, "nBins": int(nBins), "retrieve": bool(retrieve), "reduceBlockSize": int(reduceBlockSize),
+                       "useSharedMemory": bool(useSharedMemory)}
+        self._response, self._nBins, self._retrieve, self._updateResponse = response, int(nBins), bool(retrieve), updateResponse
         self._requestedNorm = 1.0
-        self._retrieve = retrieve
-        self._reduceBlockSize = reduceBlockSize
-        self._updateResponse = updateResponse
-        self._useSharedMemory = useSharedMemory
         self._nHistMax = 0
         self._program = None  # set by the tracer (bindParams)
         self._norm = [1.0, 1.0]
         self._buffer = [np.zeros(nBins, dtype=np.float32) for _ in range(2)]
         self._prepared = False
 
-    @property
-    def nBins(self) -> int:
-        return self._nBins
-
-    @property
-    def normalization(self) -> float | None:
-        return self._normalization
-
-    @normalization.setter
-    def normalization(self, value: float | None) -> None:
-        self._normalization = value
-
-    @property
-    def reduceBlockSize(self) -> int:
-        return self._reduceBlockSize
-
-    @property
-    def response(self) -> ValueResponse:
-        return self._response
-
-    @property
-    def retrieve(self) -> bool:
-        return self._retrieve
-
-    @property
-    def useSharedMemory(self) -> bool:
-        return self._useSharedMemory
+    # read-only views of what the response was built with
+    nBins = property(lambda self: self._fixed["nBins"], doc="number of time bins")
+    response = property(lambda self: self._fixed["response"], doc="value response weighting the hits")
+    retrieve = property(lambda self: self._fixed["retrieve"], doc="whether results are copied to the host")
+    reduceBlockSize = property(lambda self: self._fixed["reduceBlockSize"], doc="kept for API parity: the slab reducer here uses one wavefront per bin")
+    useSharedMemory = property(lambda self: self._fixed["useSharedMemory"], doc="kept for API parity: the histogram always lives in LDS")
 
     def result(self, i: int) -> np.ndarray | None:
         """Histogram of the most recent batch run with config `i` (valid until
@@ -364,7 +314,7 @@ class HistogramHitResponse(HitResponse):
 
     def update(self, i: int) -> None:
         super().update(i)
-        self._norm[i] = self._normalization if self._normalization is not None else self._requestedNorm
+        self._norm[i] = self.normalization if self.normalization is not None else self._requestedNorm
         if self._updateResponse:
             self._response.update(i)
 
