@@ -63,6 +63,8 @@ struct thx_tracer {
     bool staged = false;          // staged (regrouped-in-LDS) scene kernel
     uint32_t mode = 0;            // bit 0 instrumented, bit 1 staged
     uint32_t stackDepth = kStackDepth;
+    uint32_t stackLds = kStackDepth; // entries of the traversal stack kept in LDS; the rest of stackDepth spills to `spill`
+    uint32_t* spill = nullptr;
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
     uint32_t ldsNodes = 0;        // staged kernel: BVH nodes staged in LDS (0 = walk reads HBM/L2)
@@ -236,7 +238,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     THX_HIP(hipSetDevice(ctx->device));
     BuiltScene built;
     try {
-        built = buildScene(meshes, n_meshes, instances, n_instances, kStackDepth);
+        built = buildScene(meshes, n_meshes, instances, n_instances, kTreeDepth);
     } catch (const std::exception& e) {
         return fail(THX_ERR_INVALID, e.what());
     }
@@ -391,7 +393,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     t->block = replay ? kReplayBlock : kTraceBlock;
     if (scene) {
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
-        t->stack16 = scene->nPairs < 8190 && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
+        t->stack16 = scene->nPairs < 8190 * kRecordSlots && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
         // test hook: a stack shallower than the scene needs (the walk then flags ERROR_CODE_TRACE_ABORT)
         if (const char* env = std::getenv("THX_STACK_DEPTH")) t->stackDepth = (uint32_t)std::min<int>(kStackDepth, std::max(1, std::atoi(env)));
@@ -408,7 +410,11 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (const char* env = std::getenv("THX_THREADS")) t->block = (uint32_t)std::min<int>(kStagedBlock, std::max(64, std::atoi(env) / 64 * 64));
         size_t budget = (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor - 2048; // whole CU, one workgroup
         if (const char* env = std::getenv("THX_POOL_LDS_KB")) budget = (size_t)std::max(16, std::atoi(env)) * 1024;
-        const uint32_t stackBytes = t->stackDepth * (t->stack16 ? 2u : 4u);
+        // Deep hierarchies: rays use the worst-case depth rarely, so only the first kStackLds entries (THX_STACK_LDS)
+        // come out of LDS and the rest lives in global memory (dev_trace.hpp: Walker::push)
+        t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
+        if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
+        const uint32_t stackBytes = t->stackLds * (t->stack16 ? 2u : 4u);
         // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %,
         // nodes gathered from LDS instead of the vector cache 4.5 %. So the node array is
         // staged in LDS only when that costs no pool slot (THX_LDS_NODES=<max nodes> forces it).
@@ -433,11 +439,12 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(4080, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
     } else {
+        t->stackLds = t->stackDepth;
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
     }
     if (std::getenv("THX_VERBOSE"))
-        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u stack16=%d ldsNodes=%u\n",
-                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, (int)t->stack16, t->ldsNodes);
+        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u (LDS %u) stack16=%d ldsNodes=%u\n",
+                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, t->stackLds, (int)t->stack16, t->ldsNodes);
     // replay streams its queue once: a few workgroups per CU hide the load latency
     int perCU = replay ? 8 : t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
@@ -460,6 +467,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     if (e == hipSuccess && t->staged) {
         const size_t nb = stagedColdBytes(pol, t->pool) * t->gridMax;
         if (nb) e = hipMalloc((void**)&t->cold, nb);
+        const size_t sb = sizeof(uint32_t) * 64u * (t->block / 64u) * (size_t)(t->stackDepth - t->stackLds) * t->gridMax;
+        if (e == hipSuccess && sb) e = hipMalloc((void**)&t->spill, sb);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
     if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
@@ -524,6 +533,7 @@ int thx_tracer_destroy(thx_tracer* t) {
     }
     if (t->stats) (void)hipFree(t->stats);
     if (t->cold) (void)hipFree(t->cold);
+    if (t->spill) (void)hipFree(t->spill);
     if (t->prof) (void)hipFree(t->prof);
     if (t->devError) (void)hipFree(t->devError);
     if (t->track) (void)hipFree(t->track);
@@ -591,7 +601,9 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.n_bins = t->desc.n_bins;
     a.track_events = t->trackEvents;
     a.stack_depth = t->stackDepth;
-    a.stack_wave_words = t->stackDepth * (t->stack16 ? 32u : 64u);
+    a.stack_lds = t->stackLds;
+    a.stack_wave_words = t->stackLds * (t->stack16 ? 32u : 64u);
+    a.spill = t->spill;
     a.stack16 = t->stack16 ? 1u : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;

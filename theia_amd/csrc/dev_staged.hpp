@@ -571,6 +571,17 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     atomicAdd(&profLds[8], wt1 - wt0);
                     atomicAdd(&profLds[10], 1ull);
                 }
+                { // trips per ray: sums and per-batch maxima by ray kind (0 primary, 1 shadow); histogram of trips
+                    const uint32_t kind = which == 0 ? 0u : 1u;
+                    atomicAdd(&profLds[40 + 2 * kind], 1ull);
+                    atomicAdd(&profLds[41 + 2 * kind], (unsigned long long)h.trips);
+                    uint32_t mAll = h.trips;
+                    for (int o = 32; o > 0; o >>= 1) mAll = max(mAll, (uint32_t)__shfl_xor((int)mAll, o));
+                    const unsigned long long first = __ballot(1);
+                    if ((tid & 63u) == (uint32_t)__builtin_ctzll(first)) atomicAdd(&profLds[44], (unsigned long long)mAll);
+                    const uint32_t bin = h.trips <= 4 ? 0u : (h.trips <= 16 ? 1u : (h.trips <= 32 ? 2u : 3u));
+                    if (bin < 3) atomicAdd(&profLds[45 + bin], 1ull); // <= 4 / 5-16 / 17-32; the rest follows from the totals
+                }
 #endif
                 if (which == 0) {
                     if (h.aborted) { // the traversal stack overflowed: ERROR_CODE_TRACE_ABORT ends the photon

@@ -35,14 +35,16 @@ struct LaunchArgs {
     uint32_t n_bins;
     uint32_t photons_per_wave; // contiguous photon range owned by one wavefront
     uint32_t track_events;
-    uint32_t stack_depth;      // LDS traversal stack entries per lane
-    uint32_t stack_wave_words; // LDS words of one wavefront's stack block (depth*64, or depth*32 for 16-bit entries)
+    uint32_t stack_depth;      // traversal stack entries per lane
+    uint32_t stack_lds;        // the first stack_lds of them live in LDS, deeper ones in `spill` (== stack_depth: all in LDS)
+    uint32_t stack_wave_words; // LDS words of one wavefront's stack block (stack_lds*64, or stack_lds*32 for 16-bit entries)
     uint32_t stack16;          // 1: stack entries are 16 bit (scene has < 8190 nodes/triangles)
     uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active
     uint32_t pool;             // staged kernel: photons held in LDS per workgroup
     uint32_t lds_nodes_word;   // LDSBVH variants: LDS word offset of the staged node array
     uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
+    uint32_t* spill;           // [waves of the grid][stack_depth - stack_lds][64] deep stack entries, or null
     float* cold;               // staged kernel: [gridDim.x][2 or 4][pool] float4 = the cold chunks of the photon pools (dev_staged.hpp)
     uint32_t* hits;            // HitRecorder queue (response.queue.glsl layout) or null: histogram response
     uint32_t hit_capacity;     // entries per SoA column of the queue
@@ -921,6 +923,9 @@ struct QueryHit {
     bool aborted = false; // the traversal stack overflowed: the result is not the closest hit (ERROR_CODE_TRACE_ABORT)
     uint32_t instance, prim;
     float t, b1, b2; // b1, b2 = barycentric weights of v1, v2
+#ifdef THX_STAGE_PROFILE
+    uint32_t trips = 0; // inner-node trips of this lane's own ray
+#endif
 };
 
 struct WoopRay {
@@ -1039,6 +1044,11 @@ THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
     return tn <= tf * 1.0000004f ? tn : -1.0f;
 }
+// the same with a miss at infinity (what the 4-wide visit sorts by)
+THX_DEV float slabChildFar(const float4 c, const QRay& r, float tmax) {
+    const float t = slabChild(c, r, tmax);
+    return t >= 0.0f ? t : INFINITY;
+}
 // the root box of a tree = its whole frame, q = 0 .. 65535
 THX_DEV bool slabRoot(const QRay& r, float tmax) {
     const v2f t0 = r.b_xy;
@@ -1083,8 +1093,9 @@ struct Walker {
     Lane<V>& L;
     const float4* nodes;
     const float4* tris;
-    uint32_t depth;
+    uint32_t depth, ldsN;
     bool s16;
+    THX_GLOBAL uint32_t* spill; // this wavefront's deep entries (beyond ldsN): entry e of lane l at e * 64 + l (wave-uniform: lives in SGPRs)
     uint32_t* stack32;
     uint16_t* stack16;
     uint32_t sp, cur, curInst;
@@ -1096,12 +1107,17 @@ struct Walker {
     QueryHit h;
 #ifdef THX_STAGE_PROFILE
     unsigned long long pInner = 0, pLeaf = 0, pOther = 0, pRounds = 0, pTrips = 0;
+    uint32_t pLane = 0;
 #endif
 
     THX_DEV explicit Walker(Lane<V>& lane) : L(lane) {
         nodes = walkNodes(L);
         tris = reinterpret_cast<const float4*>(L.a->scene.tris);
         depth = L.a->stack_depth;
+        ldsN = L.a->stack_lds;
+        // Deep entries: the host sizes the LDS part for what rays typically use and lets the rest of the worst case
+        // live in global memory (L2), so the depth of a scene's hierarchy does not come out of the photon pool.
+        spill = (THX_GLOBAL uint32_t*)(L.a->spill) + (size_t)((blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * (depth - ldsN)) * 64u;
         // 16-bit entries when the scene is small enough (halves the LDS footprint).
         // (Storing entry distances for pop-time culling was measured slower: -10 % node
         // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
@@ -1123,13 +1139,15 @@ struct Walker {
     // ERROR_CODE_TRACE_ABORT, counted like every other device error (callback.stat.glsl:66-69).
     THX_DEV void push(uint32_t v) {
         if (sp >= depth) { overflow = true; return; }
-        if (s16) stack16[sp * 64] = (uint16_t)v;
+        if (sp >= ldsN) spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)] = v;
+        else if (s16) stack16[sp * 64] = (uint16_t)v;
         else stack32[sp * 64] = v;
         ++sp;
     }
     THX_DEV uint32_t pop() {
         if (sp == 0) return WALK_DONE;
         --sp;
+        if (sp >= ldsN) return spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)];
         if (s16) {
             uint32_t v = stack16[sp * 64];
             return v == 0xFFFEu ? WALK_SENTINEL : v;
@@ -1193,6 +1211,7 @@ struct Walker {
         const uint32_t innerKeep = ((uint32_t)__popcll(__ballot((cur & 7u) == 0u)) * (uint32_t)THX_INNER_KEEP) >> 3;
         while ((cur & 7u) == 0u) {
 #ifdef THX_STAGE_PROFILE
+            pLane += 1;
             pTrips += 1; // lane 0's count is what gets reported: trips of the wave while lane 0 is in the loop
             {
                 const unsigned long long m = __ballot(1);
@@ -1202,6 +1221,29 @@ struct Walker {
                 }
             }
 #endif
+#ifdef THX_BVH4
+            // 4-wide record: four children (box + ref each), hit ones visited nearest first
+            const uint32_t quad = cur >> 3;
+            const float4 c0 = nodes[4 * quad], c1 = nodes[4 * quad + 1], c2 = nodes[4 * quad + 2], c3 = nodes[4 * quad + 3];
+            uint32_t r0 = __float_as_uint(c0.w), r1 = __float_as_uint(c1.w), r2 = __float_as_uint(c2.w), r3 = __float_as_uint(c3.w);
+            L.cnt.add(ST_NODES, 2u + (r2 != WALK_DONE ? 1u : 0u) + (r3 != WALK_DONE ? 1u : 0u));
+            float t0 = slabChildFar(c0, sr, h.t), t1 = slabChildFar(c1, sr, h.t);
+            float t2 = r2 != WALK_DONE ? slabChildFar(c2, sr, h.t) : INFINITY;
+            float t3 = r3 != WALK_DONE ? slabChildFar(c3, sr, h.t) : INFINITY;
+            // sorting network on (distance, ref); a miss is at infinity
+#define THX_CSWAP(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; \
+                                    const uint32_t rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
+#ifdef THX_BVH4_NEAREST_ONLY // the nearest child first, the others in storage order
+            THX_CSWAP(t0, r0, t1, r1) THX_CSWAP(t2, r2, t3, r3) THX_CSWAP(t0, r0, t2, r2)
+#else
+            THX_CSWAP(t0, r0, t1, r1) THX_CSWAP(t2, r2, t3, r3) THX_CSWAP(t0, r0, t2, r2) THX_CSWAP(t1, r1, t3, r3) THX_CSWAP(t1, r1, t2, r2)
+#endif
+#undef THX_CSWAP
+            if (t3 < INFINITY) push(r3);
+            if (t2 < INFINITY) push(r2);
+            if (t1 < INFINITY) push(r1);
+            cur = t0 < INFINITY ? r0 : pop();
+#else
             const uint32_t pair = cur >> 3;
             const float4 lc = nodes[2 * pair], rc = nodes[2 * pair + 1];
             L.cnt.add(ST_NODES, 2);
@@ -1233,6 +1275,7 @@ struct Walker {
             } else {
                 cur = pop();
             }
+#endif
             if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
         }
 #ifdef THX_STAGE_PROFILE
@@ -1298,6 +1341,7 @@ THX_DEV QueryHit rayQuery(Lane<V>& L, f3 org, f3 dir, float tmax) {
     if (wk.h.valid) L.cnt.add(ST_HITS);
     wk.h.aborted = wk.overflow;
 #ifdef THX_STAGE_PROFILE
+    wk.h.trips = wk.pLane;
     if ((threadIdx.x & 63u) == 0u && L.prof != nullptr) { // wave-level sums (s_memtime is uniform)
         atomicAdd(&L.prof[24], wk.pInner); atomicAdd(&L.prof[25], wk.pLeaf); atomicAdd(&L.prof[26], wk.pOther);
         atomicAdd(&L.prof[27], wk.pRounds); atomicAdd(&L.prof[28], wk.pTrips);

@@ -7,7 +7,16 @@
 namespace thx {
 
 constexpr uint32_t kTraceBlock = 256;  // threads per tracing workgroup (4 wavefronts)
-constexpr uint32_t kStackDepth = 32;   // LDS traversal stack entries per lane
+constexpr uint32_t kTreeDepth = 32;    // depth bound of the binary trees the builder makes (TLAS + deepest BLAS + 2)
+#ifdef THX_BVH4
+constexpr uint32_t kStackDepth = 2 * kTreeDepth; // a 4-wide visit pushes up to three entries per level
+constexpr uint32_t kRecordSlots = 2;             // NodePair slots per record of the walk
+#else
+constexpr uint32_t kStackDepth = kTreeDepth;     // traversal stack entries per lane
+constexpr uint32_t kRecordSlots = 1;
+#endif
+constexpr uint32_t kStackLds16 = 16;   // staged kernel: entries of them kept in LDS (16-bit / 32-bit entries), the rest in global memory;
+constexpr uint32_t kStackLds32 = 10;   // measured on MI355X (profiles/r02_stack_spill.txt): 81 920 triangles 7.27 -> 6.06 ms, 5.2 M triangles 13.2 -> 10.9 ms
 
 // dynamic LDS bytes of a tracing workgroup (lane kernel)
 inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block, uint32_t depth, bool stack16) {

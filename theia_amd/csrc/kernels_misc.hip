@@ -451,6 +451,7 @@ hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, f
     std::memset(&a, 0, sizeof(a));
     a.scene = scene;
     a.stack_depth = kStackDepth;
+    a.stack_lds = kStackDepth;
     a.stack_wave_words = kStackDepth * 64;
     a.stack16 = 0;
     a.n_bins = 0;
@@ -461,6 +462,7 @@ hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, f
     if (const char* e = std::getenv("THX_QUERY_DEPTH")) { // development: smaller u16 stacks -> more waves per CU
         uint32_t d = std::min(32, std::max(4, std::atoi(e)));
         a.stack_depth = d;
+        a.stack_lds = d;
         a.stack16 = 1;
         a.stack_wave_words = d * 32;
         lds = (size_t)(block / 64) * d * 128;

@@ -42,3 +42,9 @@ if out[27]:
 if out[30]:
     print(f"walk occupancy: lanes per round={int(out[29]) / int(out[30]):.1f} of 64 (wave rounds per batch={int(out[30]) / max(int(out[10]), 1):.1f}), "
           f"lanes per inner trip={int(out[31]) / max(int(out[39]), 1):.1f} (wave trips per batch={int(out[39]) / max(int(out[10]), 1):.1f})")
+
+if out[40] or out[42]:
+    rays = int(out[40]) + int(out[42]); w = max(int(out[10]), 1)
+    print(f"trips per ray: primary {int(out[41]) / max(int(out[40]), 1):.1f} ({int(out[40]) / rays:.0%} of the rays), shadow {int(out[43]) / max(int(out[42]), 1):.1f}; "
+          f"longest ray of a batch {int(out[44]) / w:.1f}; rays with <=4 / 5-16 / 17-32 / >32 trips: "
+          f"{int(out[45]) / rays:.0%} / {int(out[46]) / rays:.0%} / {int(out[47]) / rays:.0%} / {(rays - int(out[45]) - int(out[46]) - int(out[47])) / rays:.0%}")
