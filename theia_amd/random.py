@@ -28,8 +28,8 @@ class RNG(SourceCodeMixin):
 
     name = "RNG"
 
-    def __init__(self, params: dict = {}, extras: set = set()) -> None:
-        super().__init__(params, extras)
+    def __init__(self, params={}, extras=set()):
+        SourceCodeMixin.__init__(self, params, extras)
 
 
 class _WideUInt(Structure):
@@ -72,26 +72,23 @@ class PhiloxRNG(RNG):
     class PhiloxParams(Structure):
         _fields_ = [("key", Key), ("offset", Counter)]
 
-    def __init__(self, *, key: int | None = None, offset: int = 0, autoAdvance: int = 0) -> None:
-        super().__init__({"PhiloxParams": self.PhiloxParams}, {"autoAdvance"})
+    def __init__(self, *, offset=0, autoAdvance=0, key=None):
+        RNG.__init__(self, {"PhiloxParams": self.PhiloxParams}, {"autoAdvance"})
         self._step = 0
         if key is None:
             key = int.from_bytes(urandom(8), "little")
             warnings.warn(f"PhiloxRNG without a key: drew 0x{key:016X} from the OS")
         self.setParams(key=key, offset=offset, autoAdvance=autoAdvance)
 
-    @property
-    def autoAdvance(self) -> int:
-        return self._step
-
-    @autoAdvance.setter
-    def autoAdvance(self, amount: int) -> None:
+    def _set_step(self, amount):
         self._step = int(amount)
 
-    def _finishParams(self, i: int) -> None:
+    autoAdvance = property(lambda self: self._step, _set_step, doc="how far `offset` moves on each update()")
+
+    def _finishParams(self, i):
         if self._step:
             self.setParam("offset", self.getParam("offset") + self._step)  # wraps at 2^128 in Counter.value
-        super()._finishParams(i)
+        RNG._finishParams(self, i)
 
 
 class SobolQRNG(RNG):
@@ -109,9 +106,9 @@ class SobolQRNG(RNG):
     class SobolParams(Structure):
         _fields_ = [("seed", c_uint32), ("offset", c_uint32)]
 
-    def __init__(self, *, seed: int | None = None, offset: int = 0, advanceSeed: int | None = None) -> None:
-        super().__init__({"SobolParams": self.SobolParams}, {"advanceSeed"})
-        if seed is None and advanceSeed is None:
+    def __init__(self, *, offset=0, advanceSeed=None, seed=None):
+        RNG.__init__(self, {"SobolParams": self.SobolParams}, {"advanceSeed"})
+        if advanceSeed is None and seed is None:
             seed = int.from_bytes(urandom(4), "big")
             warnings.warn(f"Random RNG seed generated: 0x{seed:04X}")
         self._hostRNG = None
@@ -124,11 +121,12 @@ class SobolQRNG(RNG):
     advanceSeed = property(lambda self: self._advance, _reseed,
                            doc="seed of the host generator that draws a new `seed` per update (None: keep the seed)")
 
-    def _finishParams(self, i: int) -> None:
-        if self._hostRNG is not None:
-            fresh = self._hostRNG.bytes(4)
-            self.setParam("seed", int.from_bytes(fresh, "big"))
-        super()._finishParams(i)
+    def _finishParams(self, i):
+        if self._hostRNG is None:
+            return RNG._finishParams(self, i)
+        fresh = self._hostRNG.bytes(4)
+        self.setParam("seed", int.from_bytes(fresh, "big"))
+        RNG._finishParams(self, i)
 
 
 class RNGBufferSink(PipelineStage):
@@ -140,9 +138,8 @@ class RNGBufferSink(PipelineStage):
 
     name = "RNG Sink"
 
-    def __init__(self, generator: RNG, streams: int, samples: int, *, baseStream: int = 0, baseCount: int = 0,
-                 sampleDim: int = 1) -> None:
-        super().__init__({})
+    def __init__(self, generator, streams, samples, *, sampleDim=1, baseStream=0, baseCount=0):
+        PipelineStage.__init__(self, {})
         if not isinstance(generator, (PhiloxRNG, SobolQRNG)):
             raise NotImplementedError("PhiloxRNG and SobolQRNG are supported by the HIP backend")
         if sampleDim not in (1, 2):
@@ -156,9 +153,7 @@ class RNGBufferSink(PipelineStage):
 
     capacity = property(lambda self: self._streams * self._samples * self._sampleDim, doc="total number of floats drawn")
 
-    @property
-    def generator(self) -> RNG:
-        return self._generator
+    generator = property(lambda self: self._generator, doc="the generator the samples are drawn from")
 
     def numpy(self, i: int) -> np.ndarray:
         """float32 samples of config i, shape (streams, samples)"""

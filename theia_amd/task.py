@@ -10,8 +10,6 @@ from __future__ import annotations
 
 import math
 import warnings
-from typing import Callable
-
 import numpy as np
 
 from .hp.pipeline import DynamicTask
@@ -55,57 +53,36 @@ class ConvergeHistogramTask(DynamicTask):
     `error` the standard error of its integral. `finishedCallback(task)` runs at the end.
     """
 
-    def __init__(self, response: HistogramHitResponse, params: dict, pipeline: str | None = None, *,
-                 initialBatchCount: int = 4, extraBatchCount: int = 2, maxBatchCount: int = 50, atol: float = 0.1,
-                 rtol: float = 5e-5, finishedCallback: Callable[["ConvergeHistogramTask"], None] | None = None) -> None:
+    def __init__(self, response, params, pipeline=None, *, atol=0.1, rtol=5e-5, initialBatchCount=4,
+                 extraBatchCount=2, maxBatchCount=50, finishedCallback=None):
+        # response: HistogramHitResponse, params: dict of stage parameters, pipeline: name or None,
+        # finishedCallback: callable taking the task
         for name, least, given in (("initialBatchCount", 2, initialBatchCount), ("extraBatchCount", 1, extraBatchCount)):
             if given < least:
                 raise ValueError(f"{name} = {given} is too small (minimum {least})")
         if not response.retrieve:
             raise ValueError("the response does not copy its histogram to the host (retrieve=False)")
-        super().__init__(params, pipeline, initialBatchCount=initialBatchCount)
+        DynamicTask.__init__(self, params, pipeline, initialBatchCount=initialBatchCount)
         self._response = response
         self._policy = {"extra": int(extraBatchCount), "limit": int(maxBatchCount), "atol": float(atol), "rtol": float(rtol)}
         self._notify = finishedCallback
         self._stat = _RunningCurve(response.nBins)
         self._done = False
 
-    @property
-    def response(self) -> HistogramHitResponse:
-        return self._response
-
-    @property
-    def atol(self) -> float:
-        return self._policy["atol"]
-
-    @property
-    def rtol(self) -> float:
-        return self._policy["rtol"]
-
-    @property
-    def batchCountLimit(self) -> int:
-        return self._policy["limit"]
-
-    @property
-    def totalBatches(self) -> int:
-        return self._stat.count
-
-    @property
-    def converged(self) -> bool:
-        return self._done
-
-    @property
-    def result(self) -> np.ndarray:
-        return self._stat.mean
-
-    @property
-    def error(self) -> float:
-        return self._stat.standard_error()
+    # read-only views
+    response = property(lambda self: self._response, doc="the histogram response the curves come from")
+    atol = property(lambda self: self._policy["atol"], doc="absolute part of the error threshold")
+    rtol = property(lambda self: self._policy["rtol"], doc="relative part of the error threshold")
+    batchCountLimit = property(lambda self: self._policy["limit"], doc="most batches the task will issue")
+    totalBatches = property(lambda self: self._stat.count, doc="batches averaged so far")
+    converged = property(lambda self: self._done, doc="True once the error fell below the threshold")
+    result = property(lambda self: self._stat.mean, doc="mean light curve")
+    error = property(lambda self: self._stat.standard_error(), doc="standard error of the curve's integral")
 
     def _threshold(self) -> float:
         return self.atol + self.rtol * self._stat.integral
 
-    def processBatch(self, config: int) -> int:
+    def processBatch(self, config):
         curve = self._response.result(config)
         if curve is None:
             raise RuntimeError("the response returned no histogram for a finished batch")
