@@ -7,7 +7,6 @@ shader/lightsource.spherical.glsl, wavelengthsource.{const,uniform}.glsl).
 from __future__ import annotations
 
 from ctypes import Structure, c_float, c_int64, c_uint32
-from typing import Callable
 from warnings import warn
 
 import numpy as np
@@ -27,23 +26,60 @@ __all__ = ["WavelengthSource", "WavelengthSampleItem", "HostWavelengthSource", "
            "SphericalLightSource", "PencilLightSource"]
 
 
+def _layout(**columns) -> list:
+    """ctypes `_fields_` from keyword arguments (their order is the memory order)"""
+    return list(columns.items())
+
+
+def _xyz(n: int = 3):
+    return c_float * n
+
+
 class WavelengthSampleItem(Structure):
     """one sampled wavelength and its contribution (light.py:79-84)"""
 
-    _fields_ = [("wavelength", c_float), ("contrib", c_float)]
+    _fields_ = _layout(wavelength=c_float, contrib=c_float)
 
 
 class LightSampleItem(Structure):
     """one sample of a light source (light.py:463-471, shader/lightsource.queue.glsl)"""
 
-    _fields_ = [("position", c_float * 3), ("direction", c_float * 3), ("startTime", c_float), ("contrib", c_float)]
+    _fields_ = _layout(position=_xyz(), direction=_xyz(), startTime=c_float, contrib=c_float)
 
 
 class PolarizedLightSampleItem(Structure):
     """`LightSampleItem` with the Stokes vector and its reference direction (light.py:474-489)"""
 
-    _fields_ = [("position", c_float * 3), ("direction", c_float * 3), ("stokes", c_float * 4),
-                ("polarizationRef", c_float * 3), ("startTime", c_float), ("contrib", c_float)]
+    _fields_ = _layout(position=_xyz(), direction=_xyz(), stokes=_xyz(4), polarizationRef=_xyz(), startTime=c_float,
+                       contrib=c_float)
+
+
+class _Budgeted:
+    """sources whose photons share a total `budget` (a plain stage parameter kept on the host side)"""
+
+    _budget = 1.0
+
+    def _set_budget(self, total) -> None:
+        self._budget = total
+
+    budget = property(lambda self: self._budget, _set_budget, doc="total contribution shared by the sampled photons")
+
+
+class _Fed:
+    """sources fed from the host: a queue of `capacity` items uploaded with every batch; `updateFn(source, i)`
+    runs before a batch with config `i` is assembled and may refill it"""
+
+    def _initFeed(self, item, capacity, updateFn) -> None:
+        self._feed = (IOQueue(item, capacity, mode="update", skipCounter=True), capacity, updateFn)
+
+    capacity = property(lambda self: self._feed[1], doc="most samples a run can draw")
+    queue = property(lambda self: self._feed[0], doc="the items of the next batch")
+
+    def update(self, i):
+        refill = self._feed[2]
+        if refill is not None:
+            refill(self, i)
+        SourceCodeMixin.update(self, i)
 
 
 class WavelengthSource(SourceCodeMixin):
@@ -51,16 +87,14 @@ class WavelengthSource(SourceCodeMixin):
 
     name = "Wavelength Sampler"
 
-    def __init__(self, *, nRNGSamples: int = 0, params: dict = {}, extra: set = set()) -> None:
-        super().__init__(params, extra)
-        self._nRNGSamples = nRNGSamples
+    def __init__(self, *, params={}, extra=set(), nRNGSamples=0):
+        SourceCodeMixin.__init__(self, params, extra)
+        self._draws = nRNGSamples
 
-    @property
-    def nRNGSamples(self) -> int:
-        return self._nRNGSamples
+    nRNGSamples = property(lambda self: self._draws, doc="random numbers drawn per photon")
 
 
-class HostWavelengthSource(WavelengthSource):
+class HostWavelengthSource(_Fed, WavelengthSource):
     """
     Wavelength source passing samples from the host to the device (light.py:87-150,
     shader/wavelengthsource.host.glsl): photon `k` of a batch gets item `k` of
@@ -71,20 +105,9 @@ class HostWavelengthSource(WavelengthSource):
 
     name = "Host Wavelength Source"
 
-    def __init__(self, capacity: int, *, updateFn: Callable[["HostWavelengthSource", int], None] | None = None,
-                 extra: set = set()) -> None:
-        super().__init__(extra=extra)
-        self._capacity = capacity
-        self._updateFn = updateFn
-        self._queue = IOQueue(WavelengthSampleItem, capacity, mode="update", skipCounter=True)
-
-    capacity = property(lambda self: self._capacity, doc="maximum number of samples that can be drawn per run")
-    queue = property(lambda self: self._queue, doc="queue containing the data for the next batch")
-
-    def update(self, i: int) -> None:
-        if self._updateFn is not None:
-            self._updateFn(self, i)
-        super().update(i)
+    def __init__(self, capacity, *, extra=set(), updateFn=None):
+        WavelengthSource.__init__(self, extra=extra)
+        self._initFeed(WavelengthSampleItem, capacity, updateFn)
 
 
 class _StreamMixin:
@@ -94,52 +117,43 @@ class _StreamMixin:
     _sizeField = ""
     _label = ""
 
-    def _initStream(self, fields: set, ignoreContrib: bool, data) -> None:
-        self._dataFields = set(fields)
+    def _initStream(self, columns, ignoreContrib, data) -> None:
+        self._wanted = set(columns)
         if ignoreContrib:
-            self._dataFields.discard("contrib")
-            self.queue.view(0)["contrib"] = 1.0
-            self.queue.view(1)["contrib"] = 1.0
+            self._wanted.discard("contrib")
+            for cfg in (0, 1):
+                self.queue.view(cfg)["contrib"] = 1.0
         self.data = data
 
-    @property
-    def data(self):
-        """data used as streaming source"""
-        return self._data
-
-    @data.setter
-    def data(self, value) -> None:
-        self._offset = 0
-        self._dataSize = 0
-        if value is None:
-            self._data = None
+    def _rewind(self, table) -> None:
+        self._cursor, self._rows, self._table = 0, 0, None
+        if table is None:
             return
-        if not self._dataFields.issubset(value.keys()):
-            raise ValueError(f"provided data misses expected fields: {self._dataFields.difference(value.keys())}")
-        self._dataSize = np.size(value[self._sizeField], 0)
-        for field in self._dataFields:
-            if np.size(value[field], 0) != self._dataSize:
-                raise ValueError("fields of provided data differ in size!")
-        self._data = {f: np.asarray(value[f]) for f in self._dataFields}
+        absent = self._wanted.difference(table.keys())
+        if absent:
+            raise ValueError(f"provided data misses expected fields: {absent}")
+        columns = {name: np.asarray(table[name]) for name in self._wanted}
+        rows = np.size(table[self._sizeField], 0)
+        if any(np.size(col, 0) != rows for col in columns.values()):
+            raise ValueError("the fields of the provided data differ in length")
+        self._rows, self._table = rows, columns
 
-    @data.deleter
-    def data(self) -> None:
-        self.data = None
+    data = property(lambda self: self._table, _rewind, lambda self: self._rewind(None), doc="data used as streaming source")
 
     @staticmethod
-    def _updateData(source, i: int) -> None:
-        if source.data is None:
+    def _updateData(source, i) -> None:
+        if source._table is None:
             warn(f"{source._label}: New data was requested but no source was given!")
             return
-        if source._offset >= source._dataSize:
+        first = source._cursor
+        if first >= source._rows:
             warn(f"{source._label} ran out of data!")
             return
-        start = source._offset
-        end = min(source._offset + source.capacity, source._dataSize)
-        source._offset = end
-        view = source.queue.view(i)
-        for field in source._dataFields:
-            view[field][: end - start] = source.data[field][start:end]
+        take = min(source.capacity, source._rows - first)
+        source._cursor = first + take
+        target = source.queue.view(i)
+        for name, column in source._table.items():
+            target[name][:take] = column[first:first + take]
 
 
 class StreamingHostWavelengthSource(_StreamMixin, HostWavelengthSource):
@@ -150,8 +164,8 @@ class StreamingHostWavelengthSource(_StreamMixin, HostWavelengthSource):
     _sizeField = "wavelength"
     _label = "StreamingHostWavelengthSource"
 
-    def __init__(self, batchSize: int, *, data=None, ignoreContrib: bool = False) -> None:
-        super().__init__(batchSize, updateFn=self._updateData, extra={"data"})
+    def __init__(self, batchSize, *, ignoreContrib=False, data=None):
+        HostWavelengthSource.__init__(self, batchSize, updateFn=self._updateData, extra={"data"})
         self._initStream({"wavelength", "contrib"}, ignoreContrib, data)
 
 
@@ -166,27 +180,24 @@ class FunctionWavelengthSource(WavelengthSource):
     name = "Function Wavelength Source"
 
     class WavelengthParams(Structure):
-        _fields_ = [("_table", c_int64), ("_contrib", c_float)]
+        _fields_ = _layout(_table=c_int64, _contrib=c_float)
 
-    def __init__(self, fn: Callable[[float], float], *, lambdaRange=(300.0, 700.0) * u.nm, numSamples: int = 1024) -> None:
-        super().__init__(nRNGSamples=1, params={"WavelengthParams": self.WavelengthParams})
+    def __init__(self, fn, *, numSamples=1024, lambdaRange=(300.0, 700.0) * u.nm):
+        WavelengthSource.__init__(self, nRNGSamples=1, params={"WavelengthParams": self.WavelengthParams})
+        import warnings
+
         from scipy.integrate import quad
         from scipy.stats.sampling import NumericalInversePolynomial
 
-        contrib, _ = quad(fn, *lambdaRange)
+        class _Density:
+            pdf = staticmethod(fn)
 
-        class Dist:
-            def pdf(self, x):
-                return fn(x)
-
-        import warnings
-
+        total = quad(fn, *lambdaRange)[0]
         with warnings.catch_warnings():  # scipy notes that it moved the expansion centre into the domain
             warnings.simplefilter("ignore", RuntimeWarning)
-            inv_cdf = NumericalInversePolynomial(Dist(), domain=tuple(lambdaRange))
-        x = inv_cdf.ppf(np.linspace(0.0, 1.0, numSamples))
-        self._tableMemory, [table_adr] = uploadTables([x])
-        self.setParams(_table=table_adr, _contrib=contrib)
+            quantile = NumericalInversePolynomial(_Density(), domain=tuple(lambdaRange)).ppf
+        self._tableMemory, (address,) = uploadTables([quantile(np.linspace(0.0, 1.0, numSamples))])
+        self.setParams(_table=address, _contrib=total)
 
 
 class ConstWavelengthSource(WavelengthSource):
@@ -195,10 +206,10 @@ class ConstWavelengthSource(WavelengthSource):
     name = "Const Wavelength Source"
 
     class WavelengthParams(Structure):
-        _fields_ = [("wavelength", c_float)]
+        _fields_ = _layout(wavelength=c_float)
 
-    def __init__(self, wavelength: float = 600.0 * u.nm) -> None:
-        super().__init__(params={"WavelengthParams": self.WavelengthParams})
+    def __init__(self, wavelength=600.0 * u.nm):
+        WavelengthSource.__init__(self, params={"WavelengthParams": self.WavelengthParams})
         self.setParams(wavelength=wavelength)
 
 
@@ -209,27 +220,18 @@ class UniformWavelengthSource(WavelengthSource):
     name = "Uniform Wavelength Source"
 
     class SourceParams(Structure):
-        _fields_ = [("lambdaRange", vec2), ("_contrib", c_float)]
+        _fields_ = _layout(lambdaRange=vec2, _contrib=c_float)
 
-    def __init__(self, *, lambdaRange: tuple[float, float] = (300.0, 700.0), normalize: bool = True) -> None:
-        super().__init__(nRNGSamples=1, params={"WavelengthParams": self.SourceParams}, extra={"normalize"})
+    normalize = True  # plain attribute, also a stage parameter
+
+    def __init__(self, *, normalize=True, lambdaRange=(300.0, 700.0)):
+        WavelengthSource.__init__(self, nRNGSamples=1, params={"WavelengthParams": self.SourceParams}, extra={"normalize"})
         self.setParams(lambdaRange=lambdaRange, normalize=normalize)
 
-    @property
-    def normalize(self) -> bool:
-        return self._normalize
-
-    @normalize.setter
-    def normalize(self, value: bool) -> None:
-        self._normalize = value
-
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         lo, hi = self.getParam("lambdaRange")
-        width = hi - lo
-        contrib = 1.0
-        if width != 0.0 and not self.normalize:
-            contrib *= abs(width)
-        self.setParam("_contrib", contrib)
+        width = abs(hi - lo)
+        self.setParam("_contrib", 1.0 if self.normalize or width == 0.0 else width)
 
 
 class LightSource(SourceCodeMixin):
@@ -237,30 +239,17 @@ class LightSource(SourceCodeMixin):
 
     name = "Light Source"
 
-    def __init__(self, *, supportForward: bool, supportBackward: bool, nRNGForward: int = 0, nRNGBackward: int = 0,
-                 params: dict = {}, extra: set = set()) -> None:
-        super().__init__(params, extra)
-        self._forward, self._backward = supportForward, supportBackward
-        self._rngForward, self._rngBackward = nRNGForward, nRNGBackward
+    def __init__(self, *, supportForward, supportBackward, params={}, extra=set(), nRNGForward=0, nRNGBackward=0):
+        SourceCodeMixin.__init__(self, params, extra)
+        self._modes = {"forward": (bool(supportForward), nRNGForward), "backward": (bool(supportBackward), nRNGBackward)}
 
-    @property
-    def supportForward(self) -> bool:
-        return self._forward
-
-    @property
-    def supportBackward(self) -> bool:
-        return self._backward
-
-    @property
-    def nRNGForward(self) -> int:
-        return self._rngForward
-
-    @property
-    def nRNGBackward(self) -> int:
-        return self._rngBackward
+    supportForward = property(lambda self: self._modes["forward"][0], doc="can start photons (forward tracing)")
+    supportBackward = property(lambda self: self._modes["backward"][0], doc="can be sampled by backward tracers")
+    nRNGForward = property(lambda self: self._modes["forward"][1], doc="draws per photon in forward mode")
+    nRNGBackward = property(lambda self: self._modes["backward"][1], doc="draws per sample in backward mode")
 
 
-class SphericalLightSource(LightSource):
+class SphericalLightSource(_Budgeted, LightSource):
     """Isotropic, unpolarized point source: `position`, emission window
     `timeRange`, total `budget` shared by the sampled photons. 3 draws (direction
     2, start time 1)."""
@@ -268,27 +257,17 @@ class SphericalLightSource(LightSource):
     name = "Spherical Light Source"
 
     class LightParams(Structure):
-        _fields_ = [("position", vec3), ("_contribFwd", c_float), ("_contribBwd", c_float), ("timeRange", vec2)]
+        _fields_ = _layout(position=vec3, _contribFwd=c_float, _contribBwd=c_float, timeRange=vec2)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), timeRange=(0.0, 100.0) * u.ns, budget: float = 1.0) -> None:
-        super().__init__(supportForward=True, supportBackward=True, nRNGForward=3, nRNGBackward=1,
-                         params={"LightParams": SphericalLightSource.LightParams}, extra={"budget"})
-        self.budget = budget
-        self.setParams(position=position, timeRange=timeRange)
+    def __init__(self, *, budget=1.0, timeRange=(0.0, 100.0) * u.ns, position=(0.0, 0.0, 0.0)):
+        LightSource.__init__(self, supportForward=True, supportBackward=True, nRNGForward=3, nRNGBackward=1,
+                             params={"LightParams": self.LightParams}, extra={"budget"})
+        self.setParams(position=position, timeRange=timeRange, budget=budget)
 
-    @property
-    def budget(self) -> float:
-        return self._budget
-
-    @budget.setter
-    def budget(self, value: float) -> None:
-        self._budget = value
-
-    def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
-        self.setParam("_contribFwd", self.budget)
+    def _finishParams(self, i):
+        LightSource._finishParams(self, i)
         # backward mode integrates over the sphere of directions
-        self.setParam("_contribBwd", self.budget / (4.0 * np.pi))
+        self.setParams(_contribFwd=self.budget, _contribBwd=self.budget / (4.0 * np.pi))
 
 
 class PencilLightSource(LightSource):
@@ -300,18 +279,21 @@ class PencilLightSource(LightSource):
     name = "Pencil Light Source"
 
     class LightParams(Structure):
-        _fields_ = [("position", vec3), ("direction", vec3), ("budget", c_float), ("timeRange", vec2), ("stokes", vec4),
-                    ("polarizationRef", vec3)]
+        _fields_ = _layout(position=vec3, direction=vec3, budget=c_float, timeRange=vec2, stokes=vec4, polarizationRef=vec3)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), direction=(0.0, 0.0, 1.0), timeRange=(0.0, 100.0) * u.ns,
-                 budget: float = 1.0, stokes=(1.0, 0.0, 0.0, 0.0), polarizationRef=(0.0, 1.0, 0.0)) -> None:
-        super().__init__(supportForward=True, supportBackward=False, nRNGForward=1, nRNGBackward=0,
-                         params={"LightParams": PencilLightSource.LightParams})
-        self.setParams(position=position, direction=direction, timeRange=timeRange, budget=budget, stokes=stokes,
-                       polarizationRef=polarizationRef)
+    def __init__(self, **beam):
+        LightSource.__init__(self, supportForward=True, supportBackward=False, nRNGForward=1, nRNGBackward=0,
+                             params={"LightParams": self.LightParams})
+        given = dict(position=(0.0, 0.0, 0.0), direction=(0.0, 0.0, 1.0), timeRange=(0.0, 100.0) * u.ns, budget=1.0,
+                     stokes=(1.0, 0.0, 0.0, 0.0), polarizationRef=(0.0, 1.0, 0.0))
+        unknown = set(beam) - set(given)
+        if unknown:
+            raise TypeError(f"PencilLightSource() got unexpected keyword arguments {sorted(unknown)}")
+        given.update(beam)
+        self.setParams(**given)
 
 
-class ConeLightSource(LightSource):
+class ConeLightSource(_Budgeted, LightSource):
     """
     Point source radiating uniformly into the cone around `direction` with `cosOpeningAngle`;
     optionally polarized with a constant `stokes` vector whose reference `polarizationReference`
@@ -322,41 +304,33 @@ class ConeLightSource(LightSource):
     name = "Cone Light Source"
 
     class LightParams(Structure):
-        _fields_ = [("position", vec3), ("direction", vec3), ("cosOpeningAngle", c_float), ("_contribFwd", c_float),
-                    ("_contribBwd", c_float), ("timeRange", vec2), ("polarizationReference", vec3), ("stokes", vec4)]
+        _fields_ = _layout(position=vec3, direction=vec3, cosOpeningAngle=c_float, _contribFwd=c_float, _contribBwd=c_float,
+                           timeRange=vec2, polarizationReference=vec3, stokes=vec4)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), direction=(1.0, 0.0, 0.0), timeRange=(0.0, 100.0) * u.ns,
-                 cosOpeningAngle: float = 0.5, budget: float = 1.0, polarizationReference=(0.0, 1.0, 0.0),
-                 stokes=(1.0, 0.0, 0.0, 0.0), polarized: bool = True) -> None:
-        super().__init__(supportForward=True, supportBackward=True, nRNGForward=3, nRNGBackward=1,
-                         params={"LightParams": ConeLightSource.LightParams}, extra={"budget"})
-        self._polarized = polarized
-        self.budget = budget
-        self.setParams(position=position, direction=direction, timeRange=timeRange, cosOpeningAngle=cosOpeningAngle,
-                       polarizationReference=polarizationReference, stokes=stokes)
-        if abs(sum(direction[k] * polarizationReference[k] for k in range(3))) > 1.0 - 1e-5:
+    def __init__(self, *, polarized=True, budget=1.0, cosOpeningAngle=0.5, timeRange=(0.0, 100.0) * u.ns,
+                 position=(0.0, 0.0, 0.0), direction=(1.0, 0.0, 0.0), stokes=(1.0, 0.0, 0.0, 0.0),
+                 polarizationReference=(0.0, 1.0, 0.0)):
+        along = float(np.dot(np.asarray(direction, dtype=float), np.asarray(polarizationReference, dtype=float)))
+        if abs(along) > 1.0 - 1e-5:
             raise ValueError("direction and polarizationReference cannot be parallel!")
-        if self._polarized and cosOpeningAngle <= 0.0:
+        if polarized and cosOpeningAngle <= 0.0:
             raise ValueError("Opening angles for polarized cone lights must be smaller 90 degrees!")
+        LightSource.__init__(self, supportForward=True, supportBackward=True, nRNGForward=3, nRNGBackward=1,
+                             params={"LightParams": self.LightParams}, extra={"budget"})
+        self._polarized = bool(polarized)
+        self.setParams(budget=budget, position=position, direction=direction, timeRange=timeRange, stokes=stokes,
+                       cosOpeningAngle=cosOpeningAngle, polarizationReference=polarizationReference)
 
     polarized = property(lambda self: self._polarized, doc="whether stokes / polarizationReference are used")
 
-    @property
-    def budget(self) -> float:
-        return self._budget
-
-    @budget.setter
-    def budget(self, value: float) -> None:
-        self._budget = value
-
-    def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
-        self.setParam("_contribFwd", self.budget)
+    def _finishParams(self, i):
+        LightSource._finishParams(self, i)
         # backward: divide by the solid angle of the cone
-        self.setParam("_contribBwd", self.budget / (2.0 * np.pi * (1.0 - self.cosOpeningAngle)))
+        cone = 2.0 * np.pi * (1.0 - self.cosOpeningAngle)
+        self.setParams(_contribFwd=self.budget, _contribBwd=self.budget / cone)
 
 
-class HostLightSource(LightSource):
+class HostLightSource(_Fed, LightSource):
     """
     Light source passing samples from the host to the device (light.py:692-772,
     shader/lightsource.host.glsl): photon `k` of a batch starts as item `k` of `queue.view(i)`
@@ -368,22 +342,12 @@ class HostLightSource(LightSource):
 
     name = "Host Light Source"
 
-    def __init__(self, capacity: int, *, polarized: bool = False,
-                 updateFn: Callable[["HostLightSource", int], None] | None = None, extra: set = set()) -> None:
-        super().__init__(supportForward=True, supportBackward=False, extra=extra)
-        self._capacity = capacity
-        self._polarized = polarized
-        self._updateFn = updateFn
-        self._queue = IOQueue(PolarizedLightSampleItem if polarized else LightSampleItem, capacity, mode="update", skipCounter=True)
+    def __init__(self, capacity, *, extra=set(), updateFn=None, polarized=False):
+        LightSource.__init__(self, supportForward=True, supportBackward=False, extra=extra)
+        self._polarized = bool(polarized)
+        self._initFeed(PolarizedLightSampleItem if polarized else LightSampleItem, capacity, updateFn)
 
-    capacity = property(lambda self: self._capacity, doc="maximum number of samples that can be drawn per run")
     polarized = property(lambda self: self._polarized, doc="whether the host also provides polarization information")
-    queue = property(lambda self: self._queue, doc="queue holding the samples for the next batch")
-
-    def update(self, i: int) -> None:
-        if self._updateFn is not None:
-            self._updateFn(self, i)
-        super().update(i)
 
 
 class StreamingHostLightSource(_StreamMixin, HostLightSource):
@@ -394,9 +358,9 @@ class StreamingHostLightSource(_StreamMixin, HostLightSource):
     _sizeField = "startTime"
     _label = "StreamingHostLightSource"
 
-    def __init__(self, batchSize: int, *, data=None, polarized: bool = False, ignoreContrib: bool = False) -> None:
-        super().__init__(batchSize, polarized=polarized, updateFn=self._updateData, extra={"data"})
-        self._initStream(set(self.queue.view(0).fields), ignoreContrib, data)
+    def __init__(self, batchSize, *, ignoreContrib=False, polarized=False, data=None):
+        HostLightSource.__init__(self, batchSize, polarized=polarized, updateFn=self._updateData, extra={"data"})
+        self._initStream(self.queue.view(0).fields, ignoreContrib, data)
 
 
 # ---- what the HIP backend needs to know about a (light source, wavelength source) pair --------
@@ -478,15 +442,13 @@ class LightSampler(PipelineStage):
     name = "Light Sampler"
 
     class SampleParams(Structure):
-        _fields_ = [("count", c_uint32), ("baseCount", c_uint32), ("medium", buffer_reference)]
+        _fields_ = _layout(count=c_uint32, baseCount=c_uint32, medium=buffer_reference)
 
-    def __init__(self, source: LightSource, wavelengthSource: WavelengthSource, capacity: int, *, rng=None,
-                 medium: int | None = None, polarized: bool = False, retrieve: bool = True, scene=None, batchSize: int = 128,
-                 code: bytes | None = None) -> None:
-        needRNG = source.nRNGForward > 0 or wavelengthSource.nRNGSamples > 0
-        if needRNG and rng is None:
+    def __init__(self, source, wavelengthSource, capacity, *, batchSize=128, polarized=False, retrieve=True, rng=None,
+                 scene=None, medium=None, code=None):
+        if rng is None and source.nRNGForward + wavelengthSource.nRNGSamples > 0:
             raise ValueError("Light source requires a RNG but none was given!")
-        super().__init__({"SampleParams": self.SampleParams})
+        PipelineStage.__init__(self, {"SampleParams": self.SampleParams})
         if not isinstance(source, _LIGHTS):
             raise NotImplementedError(f"{type(source).__name__} is not supported as light source by the HIP backend "
                                       f"(supported: {', '.join(c.__name__ for c in _LIGHTS)})")
@@ -497,8 +459,9 @@ class LightSampler(PipelineStage):
             # the reference's shader refuses to compile: "mismatch in light queue definition"
             # (lightsource.sample.glsl:28-33)
             raise RuntimeError("mismatch in light queue definition: HostLightSource and LightSampler differ in polarization")
-        if medium is None:
-            medium = 0 if scene is None else scene.medium
+        if medium is None and scene is not None:
+            medium = scene.medium
+        medium = medium or 0
         self._batchSize, self._capacity, self._scene, self._source = batchSize, capacity, scene, source
         self._retrieve, self._polarized, self._rng, self._wavelengthSource = retrieve, polarized, rng, wavelengthSource
         self._code = b"" if code is None else code
@@ -527,10 +490,9 @@ class LightSampler(PipelineStage):
     wavelengthQueue = property(lambda self: self._lamQueue, doc="queue holding the sampled wavelengths")
     program = property(lambda self: self._program)
 
-    def collectStages(self) -> list[PipelineStage]:
-        stages = [] if self.rng is None else [self.rng]
-        stages.extend([self.wavelengthSource, self.source, self])
-        return stages
+    def collectStages(self):
+        chain = [self._wavelengthSource, self._source, self]
+        return chain if self._rng is None else [self._rng] + chain
 
     def _assemble(self, i: int) -> capi.RunParams:
         P = capi.RunParams()
