@@ -24,7 +24,7 @@ from . import _capi as capi
 from . import units as u
 from .hp.glsl import buffer_reference, vec3
 from .hp.pipeline import PipelineStage, SourceCodeMixin
-from .light import (_LIGHTS, _WAVELENGTHS, HostLightSource, HostWavelengthSource, fillSourceParams, sourceSpec, uploadSourceQueues,
+from .light import (_LIGHTS, _layout, _WAVELENGTHS, HostLightSource, HostWavelengthSource, fillSourceParams, sourceSpec, uploadSourceQueues,
                     ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
                     WavelengthSource)
 from .random import RNG, PhiloxRNG, SobolQRNG, fillRngParams, rngFlags
@@ -45,15 +45,12 @@ class TraceEventCallback(SourceCodeMixin):
 
     name = "Trace Event Callback"
 
-    def __init__(self, *, params: dict = {}, extra: set = set()) -> None:
-        super().__init__(params, extra)
+    def __init__(self, *, extra=set(), params={}):
+        SourceCodeMixin.__init__(self, params, extra)
 
 
 class EmptyEventCallback(TraceEventCallback):
     """Ignores all events (the production kernels carry no callback code)."""
-
-    def __init__(self) -> None:
-        super().__init__()
 
 
 class EventStatisticCallback(TraceEventCallback):
@@ -66,8 +63,8 @@ class EventStatisticCallback(TraceEventCallback):
     name = "Event Statistic"
     _FIELDS = ("created", "scattered", "hit", "detected", "volume", "lost", "decayed", "absorbed", "missed", "maxIter", "error", "mismatch")
 
-    def __init__(self) -> None:
-        super().__init__()
+    def __init__(self):
+        TraceEventCallback.__init__(self)
         self._program = None
         self._cache = np.zeros(capi.N_STATS, dtype=np.uint64)
 
@@ -118,8 +115,8 @@ class TrackRecordCallback(TraceEventCallback):
 
     name = "Track Recorder"
 
-    def __init__(self, capacity: int, length: int, *, polarized: bool = False, retrieve: bool = True) -> None:
-        super().__init__()
+    def __init__(self, capacity, length, *, retrieve=True, polarized=False):
+        TraceEventCallback.__init__(self)
         self._capacity, self._length, self._polarized, self._retrieve = capacity, length, polarized, retrieve
         self._program = None
         self._batch = [0, 0]
@@ -164,26 +161,22 @@ class TrackRecordCallback(TraceEventCallback):
         return self._result[i]
 
 
-class EventResultCode(IntEnum):
-    """Result codes passed to event callbacks; negative codes stop the photon
-    (shader/result.glsl:10-28)."""
+# Result codes passed to event callbacks; negative codes stop the photon (shader/result.glsl:10-28).
+# ERROR_CODE_MAX_VALUE is an alias of ERROR_UNKNOWN: every code at or below it is an error.
+EventResultCode = IntEnum("EventResultCode", dict(
+    SUCCESS=0, RAY_CREATED=1, RAY_SCATTERED=2, RAY_HIT=3, RAY_DETECTED=4, VOLUME_HIT=5,
+    RAY_LOST=-1, RAY_DECAYED=-2, RAY_ABSORBED=-3, RAY_MISSED=-4, MAX_ITER=-5,
+    ERROR_CODE_MAX_VALUE=-10, ERROR_UNKNOWN=-10, ERROR_MEDIA_MISMATCH=-11, ERROR_TRACE_ABORT=-12, ERROR_RAY_BAD=-13))
+EventResultCode.__module__ = __name__
 
-    SUCCESS = 0
-    RAY_CREATED = 1
-    RAY_SCATTERED = 2
-    RAY_HIT = 3
-    RAY_DETECTED = 4
-    VOLUME_HIT = 5
-    RAY_LOST = -1
-    RAY_DECAYED = -2
-    RAY_ABSORBED = -3
-    RAY_MISSED = -4
-    MAX_ITER = -5
-    ERROR_CODE_MAX_VALUE = -10
-    ERROR_UNKNOWN = -10
-    ERROR_MEDIA_MISMATCH = -11
-    ERROR_TRACE_ABORT = -12
-    ERROR_RAY_BAD = -13
+
+def _flagsIf(*pairs) -> int:
+    """OR of the flag bits whose condition holds"""
+    bits = 0
+    for condition, bit in pairs:
+        if condition:
+            bits |= bit
+    return bits
 
 
 def _unsupported(role: str, obj, supported: str):
@@ -198,103 +191,76 @@ class Tracer(PipelineStage):
     name = "Tracer"
 
     class DispatchParams(Structure):
-        _fields_ = [("_batchSize", c_uint32), ("_groupCountX", c_uint32), ("_groupCountY", c_uint32), ("_groupCountZ", c_uint32)]
+        _fields_ = _layout(_batchSize=c_uint32, _groupCountX=c_uint32, _groupCountY=c_uint32, _groupCountZ=c_uint32)
 
-    def __init__(self, response: HitResponse, params: dict = {}, extra: set = set(), *, batchSize: int, blockSize: int,
-                 capacity: int | None, nRNGSamples: int, maxHitsPerThread: int, polarized: bool = False) -> None:
-        params = {**params, "DispatchParams": self.DispatchParams}
-        extra = {*extra, "batchSize", "photonOffset"}
-        super().__init__(params, extra)
-        self._blockSize = blockSize
-        self._capacity = batchSize if capacity is None else capacity
+    def __init__(self, response, params={}, extra=set(), *, batchSize, blockSize, capacity, maxHitsPerThread, nRNGSamples,
+                 polarized=False):
+        PipelineStage.__init__(self, dict(params, DispatchParams=self.DispatchParams), set(extra) | {"batchSize", "photonOffset"})
+        self._fixed = {"blockSize": blockSize, "capacity": batchSize if capacity is None else capacity, "polarized": polarized}
         self._response = response
         self._maxHitsPerThread = maxHitsPerThread
         self._nRNGSamples = nRNGSamples
-        self._polarized = polarized
         self._photonOffset = 0
-        self._program: _Program | None = None
-        self.setParams(batchSize=batchSize, _groupCountY=1, _groupCountZ=1)
+        self._program = None
+        self.setParams(_groupCountY=1, _groupCountZ=1, batchSize=batchSize)
         response.prepare(self._getTraceConfig())
 
-    @property
-    def batchSize(self) -> int:
-        """photons per run"""
-        return self.getParam("_batchSize")
+    def _resize(self, photons) -> None:
+        if not 0 <= photons <= self.capacity:
+            raise ValueError("batchSize must be at least zero!" if photons < 0 else "batchSize cannot be larger than capacity!")
+        self.setParams(_batchSize=photons, _groupCountX=max(1, -(-photons // self.blockSize)))
 
-    @batchSize.setter
-    def batchSize(self, value: int) -> None:
-        if value < 0:
-            raise ValueError("batchSize must be at least zero!")
-        if value > self.capacity:
-            raise ValueError("batchSize cannot be larger than capacity!")
-        groups = max(-(value // -self.blockSize), 1)
-        self.setParams(_batchSize=value, _groupCountX=groups)
+    def _shift(self, first) -> None:
+        self._photonOffset = int(first)
 
-    @property
-    def photonOffset(self) -> int:
-        """Index (= RNG stream) of the first photon of a batch. Extension of this
-        backend used to shard one logical batch over several GPUs."""
-        return self._photonOffset
+    batchSize = property(lambda self: self.getParam("_batchSize"), _resize, doc="photons per run")
+    photonOffset = property(lambda self: self._photonOffset, _shift,
+                            doc="index (= RNG stream) of the first photon of a batch; extension of this backend used to "
+                                "shard one logical batch over several GPUs")
+    blockSize = property(lambda self: self._fixed["blockSize"], doc="work group size the reference would dispatch with")
+    capacity = property(lambda self: self._fixed["capacity"], doc="largest batchSize the tracer was prepared for")
+    polarized = property(lambda self: self._fixed["polarized"], doc="whether polarization is simulated")
+    maxHitsPerThread = property(lambda self: self._maxHitsPerThread, doc="most hits a single photon can produce")
+    maxHits = property(lambda self: self._maxHitsPerThread * self.batchSize, doc="most hits a batch can produce")
+    normalization = property(lambda self: 1.0 / self.batchSize, doc="factor turning accumulated contributions into an estimate")
+    nRNGSamples = property(lambda self: self._nRNGSamples, doc="random numbers budgeted per photon (use as `rng.autoAdvance`)")
+    response = property(lambda self: self._response, doc="response stage processing the hits")
+    program = property(lambda self: self._program, doc="handle of the compiled kernel variant")
 
-    @photonOffset.setter
-    def photonOffset(self, value: int) -> None:
-        self._photonOffset = int(value)
-
-    @property
-    def blockSize(self) -> int:
-        return self._blockSize
-
-    @property
-    def capacity(self) -> int:
-        return self._capacity
-
-    @property
-    def maxHits(self) -> int:
-        return self.maxHitsPerThread * self.batchSize
-
-    @property
-    def maxHitsPerThread(self) -> int:
-        return self._maxHitsPerThread
-
-    @property
-    def normalization(self) -> float:
-        """factor turning accumulated contributions into an estimate"""
-        return 1.0 / self.batchSize
-
-    @property
-    def nRNGSamples(self) -> int:
-        """random numbers budgeted per photon (use as `rng.autoAdvance`)"""
-        return self._nRNGSamples
-
-    @property
-    def polarized(self) -> bool:
-        return self._polarized
-
-    @property
-    def response(self) -> HitResponse:
-        return self._response
-
-    @property
-    def program(self) -> _Program:
-        return self._program
-
-    def collectStages(self, *, useOriginalNames: bool = False) -> list[tuple[str, PipelineStage]]:
-        """All stages of this tracer in pipeline order."""
-        stages = self._collectStages()
-        if useOriginalNames:
-            return [(s.name, s) for _, s in stages]
-        return stages
+    def collectStages(self, *, useOriginalNames=False):
+        """All stages of this tracer in pipeline order as (name, stage) pairs."""
+        named = self._collectStages()
+        return [(stage.name, stage) for _, stage in named] if useOriginalNames else named
 
     @abstractmethod
-    def _collectStages(self) -> list[tuple[str, PipelineStage]]:
+    def _collectStages(self):
         ...
 
-    def _getTraceConfig(self) -> TraceConfig:
-        return TraceConfig(self.batchSize, self.blockSize, self.capacity, self.maxHitsPerThread, self.normalization, self.polarized)
+    def _getTraceConfig(self):
+        fixed = self._fixed
+        return TraceConfig(self.batchSize, fixed["blockSize"], fixed["capacity"], self._maxHitsPerThread, self.normalization,
+                           fixed["polarized"])
 
-    def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
-        self.response.updateConfig(self._getTraceConfig())
+    def run(self, i):
+        self._bindShared(i)
+
+        def launch() -> None:
+            # stages may be shared between several tracers / pipelines (examples/03): bind them to
+            # THIS tracer again when the batch actually runs, so that the response stage that
+            # follows reduces and retrieves this tracer's result
+            self._bindShared(i)
+            uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
+            self._program.run(i, self._assemble(i))
+
+        return [launch]
+
+    def _bindShared(self, i) -> None:
+        for stage in (self._callback, self._response):
+            stage.bindParams(self._program, i)
+
+    def _finishParams(self, i):
+        PipelineStage._finishParams(self, i)
+        self._response.updateConfig(self._getTraceConfig())
         self._offsets = getattr(self, "_offsets", [0, 0])
         self._offsets[i] = self._photonOffset
 
@@ -364,85 +330,65 @@ class VolumeForwardTracer(Tracer):
     name = "Volume Forward Tracer"
 
     class TraceParams(Structure):
-        _fields_ = [
-            ("medium", buffer_reference), ("objectId", c_int32), ("scatterCoefficient", c_float),
-            ("lowerBBoxCorner", vec3), ("upperBBoxCorner", vec3), ("maxTime", c_float), ("_maxDist", c_float),
-        ]
+        _fields_ = _layout(medium=buffer_reference, objectId=c_int32, scatterCoefficient=c_float, lowerBBoxCorner=vec3,
+                           upperBBoxCorner=vec3, maxTime=c_float, _maxDist=c_float)
 
-    def __init__(self, batchSize: int, source: LightSource, target: Target, wavelengthSource: WavelengthSource,
-                 response: HitResponse, rng: RNG, *, medium: int, objectId: int = 0, capacity: int | None = None,
-                 callback: TraceEventCallback | None = None, nScattering: int = 6,
-                 scatterCoefficient: float = float("NaN"),
-                 traceBBox: RectBBox | None = None, maxTime: float = 1000.0 * u.ns, polarized: bool = False,
-                 disableDirectLighting: bool = False, disableTargetSampling: bool = False, blockSize: int = 128,
-                 code: bytes | None = None, trackEvents: bool = False) -> None:
-        if callback is None:
-            callback = EmptyEventCallback()
+    def __init__(self, batchSize, source, target, wavelengthSource, response, rng, *, medium, objectId=0, capacity=None,
+                 callback=None, traceBBox=None, nScattering=6, scatterCoefficient=float("NaN"), maxTime=1000.0 * u.ns,
+                 polarized=False, disableTargetSampling=False, disableDirectLighting=False, blockSize=128, code=None,
+                 trackEvents=False):
+        callback = EmptyEventCallback() if callback is None else callback
         if traceBBox is None:
-            traceBBox = RectBBox((-1.0 * u.km,) * 3, (1.0 * u.km,) * 3)
+            half = 1.0 * u.km
+            traceBBox = RectBBox((-half, -half, -half), (half, half, half))
         self._checkComponents(source, wavelengthSource, response, rng, callback)
         if not isinstance(target, _TARGETS):
             raise _unsupported("target", target, ", ".join(c.__name__ for c in _TARGETS))
-        # hits: one per scatter (+ one MIS sample each) + the direct one
-        maxHitsPerThread = nScattering
-        if not disableTargetSampling:
-            maxHitsPerThread *= 2
-        if not disableDirectLighting:
-            maxHitsPerThread += 1
-        # with MIS the last scatter happens inside the MIS step -> one trace less
-        pathLength = nScattering if disableTargetSampling else nScattering - 1
-        rngStride = 3 if disableTargetSampling else 7
-        nRNG = source.nRNGForward + wavelengthSource.nRNGSamples
-        nRNG += rngStride * pathLength
-        nRNG += maxHitsPerThread * response.nRNGSamples
-        super().__init__(response, {"TraceParams": self.TraceParams}, batchSize=batchSize, blockSize=blockSize,
-                         capacity=capacity, nRNGSamples=nRNG, maxHitsPerThread=maxHitsPerThread, polarized=polarized)
-        self._source, self._wavelengthSource, self._rng = source, wavelengthSource, rng
-        self._target, self._callback = target, callback
-        self._nScattering = nScattering
-        self._directLightingDisabled = disableDirectLighting
-        self._targetSamplingDisabled = disableTargetSampling
-        self.setParams(scatterCoefficient=scatterCoefficient, medium=medium, objectId=objectId,
-                       lowerBBoxCorner=traceBBox.lowerCorner, upperBBoxCorner=traceBBox.upperCorner,
-                       maxTime=maxTime, _maxDist=traceBBox.diagonal)
-        flags = 0
-        flags |= capi.FLAG_POLARIZED if polarized else 0
-        flags |= capi.FLAG_DISABLE_DIRECT if disableDirectLighting else 0
-        flags |= capi.FLAG_DISABLE_MIS if disableTargetSampling else 0
-        flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
-        flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
-        flags |= targetFlags(target)
+        mis, direct = not disableTargetSampling, not disableDirectLighting
+        # hits: one per scatter, doubled by the MIS sample of each, + the direct one. With MIS the last scatter
+        # happens inside the MIS step (one trace less), and a step draws 7 numbers instead of 3.
+        hits = nScattering * (2 if mis else 1) + (1 if direct else 0)
+        steps = nScattering - 1 if mis else nScattering
+        draws = source.nRNGForward + wavelengthSource.nRNGSamples + (7 if mis else 3) * steps + hits * response.nRNGSamples
+        Tracer.__init__(self, response, {"TraceParams": self.TraceParams}, batchSize=batchSize, blockSize=blockSize,
+                        capacity=capacity, nRNGSamples=draws, maxHitsPerThread=hits, polarized=polarized)
+        self._source, self._wavelengthSource, self._rng, self._target, self._callback = source, wavelengthSource, rng, target, callback
+        self._switches = {"nScattering": nScattering, "direct": direct, "mis": mis}
+        self.setParams(medium=medium, objectId=objectId, maxTime=maxTime, scatterCoefficient=scatterCoefficient)
+        self._setBox(traceBBox)
         srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
-        flags |= srcFlags | rngFlags(rng)
-        flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
-        self._code = b"" if code is None else code
-        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, pathLength, blockSize, *self._responseSpec(response),
+        flags = srcFlags | rngFlags(rng) | targetFlags(target) | _flagsIf(
+            (polarized, capi.FLAG_POLARIZED), (disableDirectLighting, capi.FLAG_DISABLE_DIRECT),
+            (disableTargetSampling, capi.FLAG_DISABLE_MIS), (isinstance(callback, EventStatisticCallback), capi.FLAG_STATISTICS),
+            (trackEvents or isinstance(callback, TrackRecordCallback), capi.FLAG_TRACK),
+            (isinstance(response, KernelHistogramHitResponse), capi.FLAG_KERNEL_HISTOGRAM))
+        self._code = code or b""
+        self._program = _Program(_backend.TracerSpec(capi.TRACER_VOLUME_FORWARD, flags, steps, blockSize, *self._responseSpec(response),
                                                      light_queue_capacity=lightCap, wavelength_queue_capacity=lamCap), None)
 
     callback = property(lambda self: self._callback, doc="callback called for each tracing event")
     code = property(lambda self: self._code, doc="kept for API parity; kernels are precompiled")
-    directLightingDisabled = property(lambda self: self._directLightingDisabled)
-    nScattering = property(lambda self: self._nScattering)
+    directLightingDisabled = property(lambda self: not self._switches["direct"])
+    nScattering = property(lambda self: self._switches["nScattering"])
     rng = property(lambda self: self._rng)
     source = property(lambda self: self._source)
     target = property(lambda self: self._target)
-    targetSamplingDisabled = property(lambda self: self._targetSamplingDisabled)
+    targetSamplingDisabled = property(lambda self: not self._switches["mis"])
     wavelengthSource = property(lambda self: self._wavelengthSource)
 
-    @property
-    def traceBBox(self) -> RectBBox:
-        return RectBBox(self.getParam("lowerBBoxCorner"), self.getParam("upperBBoxCorner"))
+    def _setBox(self, box) -> None:
+        self.setParams(_maxDist=box.diagonal, upperBBoxCorner=box.upperCorner, lowerBBoxCorner=box.lowerCorner)
 
-    @traceBBox.setter
-    def traceBBox(self, value: RectBBox) -> None:
-        self.setParams(lowerBBoxCorner=value.lowerCorner, upperBBoxCorner=value.upperCorner, _maxDist=value.diagonal)
+    traceBBox = property(lambda self: RectBBox(*(self.getParam(side + "BBoxCorner") for side in ("lower", "upper"))), _setBox,
+                         doc="box photons are traced in; leaving it ends a path (RAY_LOST)")
 
     def _collectStages(self):
-        return [("rng", self.rng), ("photons", self.wavelengthSource), ("lightSource", self.source),
-                ("target", self.target), ("tracer", self), ("callback", self.callback), ("response", self.response)]
+        order = ("rng", "photons", "lightSource", "target", "tracer", "callback", "response")
+        parts = (self._rng, self._wavelengthSource, self._source, self._target, self, self._callback, self._response)
+        return list(zip(order, parts))
 
-    def _finishParams(self, i: int) -> None:
-        super()._finishParams(i)
+    def _finishParams(self, i):
+        Tracer._finishParams(self, i)
         self.setParam("_maxDist", self.traceBBox.diagonal)
 
     def _assemble(self, i: int) -> capi.RunParams:
@@ -454,20 +400,6 @@ class VolumeForwardTracer(Tracer):
         fillTargetParams(P.target, self._target, i)
         return P
 
-    def run(self, i: int):
-        self.callback.bindParams(self._program, i)
-        self.response.bindParams(self._program, i)
-
-        def launch() -> None:
-            # stages may be shared between several tracers / pipelines (examples/03): bind them to
-            # THIS tracer again when the batch actually runs, so that the response stage that
-            # follows reduces and retrieves this tracer's result
-            self.callback.bindParams(self._program, i)
-            self.response.bindParams(self._program, i)
-            uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
-            self._program.run(i, self._assemble(i))
-
-        return [launch]
 
 
 class SceneForwardTracer(Tracer):
@@ -485,86 +417,65 @@ class SceneForwardTracer(Tracer):
     name = "Scene Forward Tracer"
 
     class TraceParams(Structure):
-        _fields_ = [
-            ("targetId", c_int32), ("sourceMedium", buffer_reference), ("scatterCoefficient", c_float),
-            ("_lowerBBoxCorner", vec3), ("_upperBBoxCorner", vec3), ("maxTime", c_float), ("_maxDist", c_float),
-        ]
+        _fields_ = _layout(targetId=c_int32, sourceMedium=buffer_reference, scatterCoefficient=c_float, _lowerBBoxCorner=vec3,
+                           _upperBBoxCorner=vec3, maxTime=c_float, _maxDist=c_float)
 
-    def __init__(self, batchSize: int, source: LightSource, wavelengthSource: WavelengthSource, response: HitResponse,
-                 rng: RNG, scene: Scene, *, capacity: int | None = None, callback: TraceEventCallback | None = None,
-                 maxPathLength: int = 6, targetId: int = -1, targetGuide: TargetGuide | None = None,
-                 scatterCoefficient: float = float("NaN"), sourceMedium: int | None = None,
-                 maxTime: float = 1000.0 * u.ns, polarized: bool = False, disableDirectLighting: bool = False,
-                 disableTransmission: bool = False, disableVolumeBorder: bool = False,
-                 useRefractedHitDir: bool = False, blockSize: int = 128, code: bytes | None = None,
-                 trackEvents: bool = False) -> None:
-        if callback is None:
-            callback = EmptyEventCallback()
+    def __init__(self, batchSize, source, wavelengthSource, response, rng, scene, *, capacity=None, callback=None,
+                 targetGuide=None, targetId=-1, sourceMedium=None, maxPathLength=6, scatterCoefficient=float("NaN"),
+                 maxTime=1000.0 * u.ns, polarized=False, disableDirectLighting=False, disableTransmission=False,
+                 disableVolumeBorder=False, useRefractedHitDir=False, blockSize=128, code=None, trackEvents=False):
+        callback = EmptyEventCallback() if callback is None else callback
         self._checkComponents(source, wavelengthSource, response, rng, callback)
-        if targetGuide is not None and not isinstance(targetGuide, _GUIDES):
+        guided = targetGuide is not None
+        if guided and not isinstance(targetGuide, _GUIDES):
             raise _unsupported("target guide", targetGuide, ", ".join(c.__name__ for c in _GUIDES) + ", None")
-        if targetGuide is not None and response.nRNGSamples > 0:
+        if guided and response.nRNGSamples > 0:
             raise NotImplementedError("responses that draw random numbers (StoreTimeHitResponse) are not available together "
                                       "with a target guide on the HIP backend")
-        maxHits = maxPathLength - 1
-        rngStride = 4
-        if targetGuide is not None:
-            maxHits *= 2
-            rngStride += targetGuide.nRNGSamples
-        if not disableDirectLighting:
-            maxHits += 1
-        nRNG = source.nRNGForward + wavelengthSource.nRNGSamples
-        nRNG += rngStride * maxPathLength
-        nRNG += maxHits * response.nRNGSamples
-        super().__init__(response, {"TraceParams": self.TraceParams}, batchSize=batchSize, blockSize=blockSize,
-                         capacity=capacity, maxHitsPerThread=maxHits, nRNGSamples=nRNG, polarized=polarized)
-        if sourceMedium is None:
-            sourceMedium = scene.medium
+        # hits: one per step but the first, doubled by the guide's shadow rays, + the direct one;
+        # a step draws 4 numbers + what the guide needs
+        hits = (maxPathLength - 1) * (2 if guided else 1) + (0 if disableDirectLighting else 1)
+        perStep = 4 + (targetGuide.nRNGSamples if guided else 0)
+        draws = source.nRNGForward + wavelengthSource.nRNGSamples + perStep * maxPathLength + hits * response.nRNGSamples
+        Tracer.__init__(self, response, {"TraceParams": self.TraceParams}, batchSize=batchSize, blockSize=blockSize,
+                        capacity=capacity, maxHitsPerThread=hits, nRNGSamples=draws, polarized=polarized)
         self._source, self._wavelengthSource, self._callback, self._rng = source, wavelengthSource, callback, rng
         self._scene, self._targetGuide = scene, targetGuide
-        self._maxPathLength = maxPathLength
-        self._directLightingDisabled = disableDirectLighting
-        self._transmissionDisabled = disableTransmission
-        self._volumeBorderDisabled = disableVolumeBorder
-        self._useRefractedHitDir = useRefractedHitDir
-        self.setParams(targetId=targetId, scatterCoefficient=scatterCoefficient, sourceMedium=sourceMedium, maxTime=maxTime,
-                       _lowerBBoxCorner=scene.bbox.lowerCorner, _upperBBoxCorner=scene.bbox.upperCorner,
-                       _maxDist=scene.bbox.diagonal)
-        flags = 0
-        flags |= capi.FLAG_POLARIZED if polarized else 0
-        flags |= capi.FLAG_DISABLE_DIRECT if disableDirectLighting else 0
-        flags |= capi.FLAG_DISABLE_MIS if targetGuide is None else guideFlags(targetGuide)
-        flags |= capi.FLAG_DISABLE_TRANSMISSION if disableTransmission else 0
-        flags |= capi.FLAG_DISABLE_VOLUME_BORDER if disableVolumeBorder else 0
-        flags |= capi.FLAG_HIT_USE_TRANSMITTED if useRefractedHitDir else 0
-        flags |= capi.FLAG_STATISTICS if isinstance(callback, EventStatisticCallback) else 0
-        flags |= capi.FLAG_TRACK if (trackEvents or isinstance(callback, TrackRecordCallback)) else 0
+        self._switches = {"maxPathLength": maxPathLength, "noDirect": bool(disableDirectLighting),
+                          "noTransmission": bool(disableTransmission), "noBorder": bool(disableVolumeBorder),
+                          "refractedDir": bool(useRefractedHitDir)}
+        box = scene.bbox
+        self.setParams(sourceMedium=scene.medium if sourceMedium is None else sourceMedium, targetId=targetId, maxTime=maxTime,
+                       scatterCoefficient=scatterCoefficient, _maxDist=box.diagonal, _lowerBBoxCorner=box.lowerCorner,
+                       _upperBBoxCorner=box.upperCorner)
         srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
-        flags |= srcFlags | rngFlags(rng)
-        flags |= capi.FLAG_KERNEL_HISTOGRAM if isinstance(response, KernelHistogramHitResponse) else 0
-        self._code = b"" if code is None else code
+        flags = srcFlags | rngFlags(rng) | (guideFlags(targetGuide) if guided else capi.FLAG_DISABLE_MIS) | _flagsIf(
+            (polarized, capi.FLAG_POLARIZED), (disableDirectLighting, capi.FLAG_DISABLE_DIRECT),
+            (disableTransmission, capi.FLAG_DISABLE_TRANSMISSION), (disableVolumeBorder, capi.FLAG_DISABLE_VOLUME_BORDER),
+            (useRefractedHitDir, capi.FLAG_HIT_USE_TRANSMITTED), (isinstance(callback, EventStatisticCallback), capi.FLAG_STATISTICS),
+            (trackEvents or isinstance(callback, TrackRecordCallback), capi.FLAG_TRACK),
+            (isinstance(response, KernelHistogramHitResponse), capi.FLAG_KERNEL_HISTOGRAM))
+        self._code = code or b""
         self._program = _Program(_backend.TracerSpec(capi.TRACER_SCENE_FORWARD, flags, maxPathLength, blockSize, *self._responseSpec(response),
                                                      light_queue_capacity=lightCap, wavelength_queue_capacity=lamCap), scene)
 
     callback = property(lambda self: self._callback)
     code = property(lambda self: self._code)
-    directLightingDisabled = property(lambda self: self._directLightingDisabled)
-    hitsUseRefractedDir = property(lambda self: self._useRefractedHitDir)
-    maxPathLength = property(lambda self: self._maxPathLength)
+    directLightingDisabled = property(lambda self: self._switches["noDirect"])
+    hitsUseRefractedDir = property(lambda self: self._switches["refractedDir"])
+    maxPathLength = property(lambda self: self._switches["maxPathLength"])
     rng = property(lambda self: self._rng)
     scene = property(lambda self: self._scene)
     source = property(lambda self: self._source)
     targetGuide = property(lambda self: self._targetGuide)
-    transmissionDisabled = property(lambda self: self._transmissionDisabled)
-    volumeBorderDisabled = property(lambda self: self._volumeBorderDisabled)
+    transmissionDisabled = property(lambda self: self._switches["noTransmission"])
+    volumeBorderDisabled = property(lambda self: self._switches["noBorder"])
     wavelengthSource = property(lambda self: self._wavelengthSource)
 
     def _collectStages(self):
-        stages = [("rng", self.rng), ("photons", self.wavelengthSource), ("lightSource", self.source)]
-        if self.targetGuide is not None:
-            stages.append(("guide", self.targetGuide))
-        stages += [("tracer", self), ("callback", self.callback), ("response", self.response)]
-        return stages
+        guide = [] if self._targetGuide is None else [("guide", self._targetGuide)]
+        front = [("rng", self._rng), ("photons", self._wavelengthSource), ("lightSource", self._source)]
+        return front + guide + [("tracer", self), ("callback", self._callback), ("response", self._response)]
 
     def _assemble(self, i: int) -> capi.RunParams:
         P = self._commonParams(i, self._rng, self._source, self._wavelengthSource, self._response)
@@ -576,20 +487,6 @@ class SceneForwardTracer(Tracer):
             fillGuideParams(P.guide, self._targetGuide, i)
         return P
 
-    def run(self, i: int):
-        self.callback.bindParams(self._program, i)
-        self.response.bindParams(self._program, i)
-
-        def launch() -> None:
-            # stages may be shared between several tracers / pipelines (examples/03): bind them to
-            # THIS tracer again when the batch actually runs, so that the response stage that
-            # follows reduces and retrieves this tracer's result
-            self.callback.bindParams(self._program, i)
-            self.response.bindParams(self._program, i)
-            uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
-            self._program.run(i, self._assemble(i))
-
-        return [launch]
 
 
 class ScenePhotonTracer(SceneForwardTracer):
@@ -610,14 +507,12 @@ class ScenePhotonTracer(SceneForwardTracer):
 
     name = "Scene Photon Tracer"
 
-    def __init__(self, batchSize: int, source: LightSource, wavelengthSource: WavelengthSource, response: HitResponse,
-                 rng: RNG, scene: Scene, *, capacity: int | None = None, callback: TraceEventCallback | None = None,
-                 targetId: int = -1, sourceMedium: int | None = None, maxTime: float = 1.0 * u.ms,
-                 nScatteringPerRun: int = 10, nRuns: int = 10, polarized: bool = False, disableTransmission: bool = False,
-                 disableVolumeBorder: bool = False, useRefractedHitDir: bool = False, blockSize: int = 128) -> None:
+    def __init__(self, batchSize, source, wavelengthSource, response, rng, scene, *, nRuns=10, nScatteringPerRun=10,
+                 capacity=None, callback=None, targetId=-1, sourceMedium=None, maxTime=1.0 * u.ms, polarized=False,
+                 disableTransmission=False, disableVolumeBorder=False, useRefractedHitDir=False, blockSize=128):
         self._nRuns, self._nScatteringPerRun = nRuns, nScatteringPerRun
-        self._nRNGPerRun = 5 * nScatteringPerRun + response.nRNGSamples
-        super().__init__(batchSize, source, wavelengthSource, response, rng, scene, capacity=capacity, callback=callback,
+        self._nRNGPerRun = response.nRNGSamples + 5 * nScatteringPerRun
+        SceneForwardTracer.__init__(self, batchSize, source, wavelengthSource, response, rng, scene, capacity=capacity, callback=callback,
                          maxPathLength=nRuns * nScatteringPerRun, targetId=targetId, targetGuide=None,
                          scatterCoefficient=float("NaN"), sourceMedium=sourceMedium, maxTime=maxTime, polarized=polarized,
                          disableDirectLighting=False, disableTransmission=disableTransmission,
@@ -652,14 +547,12 @@ class VolumePhotonTracer(VolumeForwardTracer):
 
     name = "Volume Photon Tracer"
 
-    def __init__(self, batchSize: int, source: LightSource, target: Target, wavelengthSource: WavelengthSource,
-                 response: HitResponse, rng: RNG, *, medium: int, objectId: int = 0, capacity: int | None = None,
-                 callback: TraceEventCallback | None = None, traceBBox: RectBBox | None = None,
-                 maxTime: float = 1000.0 * u.ns, nScatteringPerRun: int = 10, nRuns: int = 10, polarized: bool = False,
-                 blockSize: int = 128, code: bytes | None = None) -> None:
+    def __init__(self, batchSize, source, target, wavelengthSource, response, rng, *, medium, nRuns=10, nScatteringPerRun=10,
+                 objectId=0, capacity=None, callback=None, traceBBox=None, maxTime=1000.0 * u.ns, polarized=False,
+                 blockSize=128, code=None):
         self._nRuns, self._nScatteringPerRun = nRuns, nScatteringPerRun
-        self._nRNGPerRun = 4 * nScatteringPerRun + response.nRNGSamples
-        super().__init__(batchSize, source, target, wavelengthSource, response, rng, medium=medium, objectId=objectId,
+        self._nRNGPerRun = response.nRNGSamples + 4 * nScatteringPerRun
+        VolumeForwardTracer.__init__(self, batchSize, source, target, wavelengthSource, response, rng, medium=medium, objectId=objectId,
                          capacity=capacity, callback=callback, nScattering=nRuns * nScatteringPerRun,
                          scatterCoefficient=float("NaN"), traceBBox=traceBBox, maxTime=maxTime, polarized=polarized,
                          disableDirectLighting=True, disableTargetSampling=True, blockSize=blockSize, code=code)
