@@ -84,3 +84,8 @@ class buffer_reference(Structure):
     def value(self, address: int) -> None:
         self.lo = address & 0xFFFFFFFF
         self.hi = (address >> 32) & 0xFFFFFFFF
+
+
+def _layout(**columns) -> list:
+    """ctypes `_fields_` from keyword arguments (their order is the memory order)"""
+    return list(columns.items())

@@ -15,7 +15,7 @@ from . import _backend
 from . import _capi as capi
 from . import units as u
 from ._program import _Program
-from .hp.glsl import buffer_reference, vec2, vec3, vec4
+from .hp.glsl import _layout, buffer_reference, vec2, vec3, vec4
 from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .hp.queue import IOQueue
 from .lookup import uploadTables
@@ -24,11 +24,6 @@ __all__ = ["WavelengthSource", "WavelengthSampleItem", "HostWavelengthSource", "
            "ConstWavelengthSource", "UniformWavelengthSource", "FunctionWavelengthSource", "LightSource", "LightSampleItem",
            "PolarizedLightSampleItem", "LightSampler", "HostLightSource", "StreamingHostLightSource", "ConeLightSource",
            "SphericalLightSource", "PencilLightSource"]
-
-
-def _layout(**columns) -> list:
-    """ctypes `_fields_` from keyword arguments (their order is the memory order)"""
-    return list(columns.items())
 
 
 def _xyz(n: int = 3):

@@ -10,7 +10,7 @@ a slab; the reducer Kahan-sums the slabs and applies the normalisation.
 from __future__ import annotations
 
 from ctypes import Structure, c_float, c_int32
-from dataclasses import dataclass
+from dataclasses import make_dataclass
 from warnings import warn
 
 import numpy as np
@@ -18,6 +18,7 @@ import numpy as np
 from . import units as u
 from . import _capi as capi
 from ._program import _Program
+from .hp.glsl import _layout
 from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .hp.queue import IOQueue
 
@@ -46,16 +47,11 @@ class PolarizedHitItem(Structure):
     _fields_ = _hit_columns(polarized=True)
 
 
-@dataclass
-class TraceConfig:
-    """What a tracer tells its response about itself (response.py:95-122)."""
-
-    batchSize: int
-    blockSize: int
-    capacity: int
-    maxHitsPerThread: int = 1
-    normalization: float = 1.0
-    polarized: bool = False
+# What a tracer tells its response about itself (response.py:95-122): batchSize, blockSize, capacity [photons],
+# maxHitsPerThread, normalization (factor applied to accumulated contributions), polarized
+TraceConfig = make_dataclass("TraceConfig", [("batchSize", int), ("blockSize", int), ("capacity", int),
+                                             ("maxHitsPerThread", int, 1), ("normalization", float, 1.0), ("polarized", bool, False)])
+TraceConfig.__module__ = __name__
 
 
 class HitResponse(SourceCodeMixin):
@@ -64,26 +60,26 @@ class HitResponse(SourceCodeMixin):
 
     name = "Hit Response"
 
-    def __init__(self, params: dict = {}, extra: set = set(), *, nRNGSamples: int = 0) -> None:
+    def __init__(self, params={}, extra=set(), *, nRNGSamples=0):
         super().__init__(params, extra)
         self._draws = nRNGSamples
 
     nRNGSamples = property(lambda self: self._draws, doc="random numbers drawn per hit")
 
-    def prepare(self, config: TraceConfig) -> None:
+    def prepare(self, config):
         pass
 
-    def updateConfig(self, config: TraceConfig) -> None:
+    def updateConfig(self, config):
         pass
 
 
 class EmptyResponse(HitResponse):
     """Ignores all hits (response.empty.glsl). Runs as a one-bin histogram nobody reads."""
 
-    def __init__(self) -> None:
+    def __init__(self):
         HitResponse.__init__(self)
 
-    def run(self, i: int):
+    def run(self, i):
         return []
 
 
@@ -101,7 +97,7 @@ class HitRecorder(HitResponse):
 
     name = "Hit Recorder"
 
-    def __init__(self, *, capacity: int = 0, polarized: bool = False) -> None:
+    def __init__(self, *, capacity=0, polarized=False):
         HitResponse.__init__(self)
         self._wanted, self._polarized, self._program = int(capacity), bool(polarized), None
         self._queue = IOQueue(PolarizedHitItem if polarized else HitItem, mode="retrieve")
@@ -119,13 +115,13 @@ class HitRecorder(HitResponse):
         elif worst_case > self._wanted:
             warn(f"tracer reported maxHits: {worst_case}, but response was initialized with capacity: {self._wanted}")
 
-    def prepare(self, config: TraceConfig) -> None:
+    def prepare(self, config):
         self._fit(config.capacity * config.maxHitsPerThread)
 
-    def updateConfig(self, config: TraceConfig) -> None:
+    def updateConfig(self, config):
         self._fit(config.batchSize * config.maxHitsPerThread)
 
-    def _bindParams(self, program, i: int) -> None:
+    def _bindParams(self, program, i):
         if not self._queue.initialized:
             if self._wanted <= 0:
                 raise RuntimeError(f"Cannot create a queue of size {self._wanted}")
@@ -133,7 +129,7 @@ class HitRecorder(HitResponse):
         super()._bindParams(program, i)
         self._program = program
 
-    def run(self, i: int):
+    def run(self, i):
         def retrieve() -> None:
             if self._program is None:
                 raise RuntimeError("HitRecorder is not bound to a tracer")
@@ -147,35 +143,30 @@ class ValueResponse(SourceCodeMixin):
 
     name = "Value Response"
 
-    def __init__(self, params: dict = {}, extra: set = set(), *, nRNGSamples: int = 0) -> None:
-        super().__init__(params, extra)
-        self._nRNGSamples = nRNGSamples
+    def __init__(self, params={}, extra=set(), *, nRNGSamples=0):
+        SourceCodeMixin.__init__(self, params, extra)
+        self._draws = nRNGSamples
 
-    @property
-    def nRNGSamples(self) -> int:
-        return self._nRNGSamples
+    nRNGSamples = property(lambda self: self._draws, doc="random numbers drawn per hit")
 
-    def prepare(self, config: TraceConfig) -> None:
-        pass
+    def prepare(self, config):
+        """called by the stage owning this response once the tracer's configuration is known"""
 
 
 class UniformValueResponse(ValueResponse):
     """Perfect isotropic detector: value = contribution of the hit."""
 
-    def __init__(self) -> None:
-        super().__init__()
-
 
 class HitTimeItem(Structure):
     """queue item of `StoreTimeHitResponse(storeObjectId=False)` (response.py:626-629)"""
 
-    _fields_ = [("time", c_float)]
+    _fields_ = _layout(time=c_float)
 
 
 class HitTimeAndIdItem(Structure):
     """queue item of `StoreTimeHitResponse` (response.py:632-638)"""
 
-    _fields_ = [("time", c_float), ("objectId", c_int32)]
+    _fields_ = _layout(time=c_float, objectId=c_int32)
 
 
 class StoreTimeHitResponse(HitResponse):
@@ -190,8 +181,8 @@ class StoreTimeHitResponse(HitResponse):
 
     name = "Store Time Hit Response"
 
-    def __init__(self, response: ValueResponse, queue=None, *, retrieve: bool = True, storeObjectId: bool = True,
-                 updateResponse: bool = True) -> None:
+    def __init__(self, response, queue=None, *, retrieve=True, storeObjectId=True,
+                 updateResponse=True):
         super().__init__(nRNGSamples=response.nRNGSamples + 1)
         if not isinstance(response, UniformValueResponse):
             raise NotImplementedError("The HIP backend implements StoreTimeHitResponse(UniformValueResponse())")
@@ -211,7 +202,7 @@ class StoreTimeHitResponse(HitResponse):
     capacity = property(lambda self: self._capacity, doc="maximum number of hits kept per batch")
     queue = property(lambda self: self._queue)
 
-    def prepare(self, config: TraceConfig) -> None:
+    def prepare(self, config):
         self._response.prepare(config)
         maxHits = config.maxHitsPerThread * config.capacity
         if self._queue is None:
@@ -221,23 +212,23 @@ class StoreTimeHitResponse(HitResponse):
         elif self._capacity < maxHits:
             warn(f"The queue's capacity ({self._capacity}) is less than the max hit count reported by the tracer ({maxHits})")
 
-    def result(self, i: int):
+    def result(self, i):
         if not self._retrieve or self._queue is None:
             return None
         return self._queue.view(i)
 
-    def _bindParams(self, program, i: int) -> None:
+    def _bindParams(self, program, i):
         if self._queue is None:
             raise RuntimeError("Hit response has not been prepared")
         super()._bindParams(program, i)
         self._program = program
 
-    def update(self, i: int) -> None:
+    def update(self, i):
         super().update(i)
         if self._updateResponse:
             self._response.update(i)
 
-    def run(self, i: int):
+    def run(self, i):
         def retrieve() -> None:
             if self._program is None:
                 raise RuntimeError("StoreTimeHitResponse is not bound to a tracer")
@@ -260,11 +251,11 @@ class HistogramHitResponse(HitResponse):
     MAX_SHARED_MEMORY_BINS = 8192
 
     class Params(Structure):
-        _fields_ = [("t0", c_float), ("binSize", c_float)]
+        _fields_ = _layout(t0=c_float, binSize=c_float)
 
-    def __init__(self, response: ValueResponse, *, nBins: int = 100, t0: float = 0.0 * u.ns, binSize: float = 1.0 * u.ns,
-                 normalization: float | None = None, retrieve: bool = True, reduceBlockSize: int = 128,
-                 updateResponse: bool = True, useSharedMemory: bool = True) -> None:
+    def __init__(self, response, *, nBins=100, t0=0.0 * u.ns, binSize=1.0 * u.ns,
+                 normalization=None, retrieve=True, reduceBlockSize=128,
+                 updateResponse=True, useSharedMemory=True):
         super().__init__({"ResponseParams": self.Params}, {"normalization"}, nRNGSamples=response.nRNGSamples)
         if not isinstance(response, UniformValueResponse):
             raise NotImplementedError(
@@ -291,34 +282,34 @@ class HistogramHitResponse(HitResponse):
     reduceBlockSize = property(lambda self: self._fixed["reduceBlockSize"], doc="kept for API parity: the slab reducer here uses one wavefront per bin")
     useSharedMemory = property(lambda self: self._fixed["useSharedMemory"], doc="kept for API parity: the histogram always lives in LDS")
 
-    def result(self, i: int) -> np.ndarray | None:
+    def result(self, i):
         """Histogram of the most recent batch run with config `i` (valid until
         that config runs again)."""
         if not self._prepared or not self._retrieve:
             return None
         return self._buffer[i]
 
-    def prepare(self, config: TraceConfig) -> None:
+    def prepare(self, config):
         self._response.prepare(config)
         self._requestedNorm = config.normalization
         self._nHistMax = max(self._nHistMax, -(config.capacity // -config.blockSize))
         self._prepared = True
 
-    def updateConfig(self, config: TraceConfig) -> None:
+    def updateConfig(self, config):
         self._requestedNorm = config.normalization
 
-    def _bindParams(self, program, i: int) -> None:
+    def _bindParams(self, program, i):
         super()._bindParams(program, i)
         self._response.bindParams(program, i)
         self._program = program
 
-    def update(self, i: int) -> None:
+    def update(self, i):
         super().update(i)
         self._norm[i] = self.normalization if self.normalization is not None else self._requestedNorm
         if self._updateResponse:
             self._response.update(i)
 
-    def run(self, i: int):
+    def run(self, i):
         if not self._prepared:
             raise RuntimeError("Response has not been prepared")
 
@@ -344,12 +335,12 @@ class KernelHistogramHitResponse(HistogramHitResponse):
     name = "Kernel Histogram Hit Response"
 
     class Params(Structure):
-        _fields_ = [("t0", c_float), ("binSize", c_float), ("kernelBandwidth", c_float), ("kernelSupport", c_float)]
+        _fields_ = _layout(t0=c_float, binSize=c_float, kernelBandwidth=c_float, kernelSupport=c_float)
 
-    def __init__(self, response: ValueResponse, *, nBins: int = 100, t0: float = 0.0 * u.ns, binSize: float = 1.0 * u.ns,
-                 kernelBandwidth: float = 1.0 * u.ns, kernelSupport: float = 3.0 * u.ns, normalization: float | None = None,
-                 retrieve: bool = True, reduceBlockSize: int = 128, updateResponse: bool = True,
-                 useSharedMemory: bool = True) -> None:
+    def __init__(self, response, *, nBins=100, t0=0.0 * u.ns, binSize=1.0 * u.ns,
+                 kernelBandwidth=1.0 * u.ns, kernelSupport=3.0 * u.ns, normalization=None,
+                 retrieve=True, reduceBlockSize=128, updateResponse=True,
+                 useSharedMemory=True):
         super().__init__(response, nBins=nBins, t0=t0, binSize=binSize, normalization=normalization, retrieve=retrieve,
                          reduceBlockSize=reduceBlockSize, updateResponse=updateResponse, useSharedMemory=useSharedMemory)
         self.setParams(kernelBandwidth=kernelBandwidth, kernelSupport=kernelSupport)
@@ -370,8 +361,8 @@ class HitReplay(PipelineStage):
 
     name = "Hit Replay"
 
-    def __init__(self, capacity: int, response: HitResponse, *, rng=None, normalization: float = 1.0,
-                 polarized: bool = False, blockSize: int = 128, code: bytes | None = None) -> None:
+    def __init__(self, capacity, response, *, rng=None, normalization=1.0,
+                 polarized=False, blockSize=128, code=None):
         if response.nRNGSamples > 0 and rng is None:
             raise ValueError("response requires a rng but none was given!")
         super().__init__()
@@ -418,12 +409,12 @@ class HitReplay(PipelineStage):
     response = property(lambda self: self._response)
     program = property(lambda self: self._program)
 
-    def collectStages(self) -> list[PipelineStage]:
+    def collectStages(self):
         if self.rng is not None:
             return [self.rng, self, self.response]
         return [self, self.response]
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         super()._finishParams(i)
         self.response.updateConfig(self._config)
 
@@ -443,7 +434,7 @@ class HitReplay(PipelineStage):
                 P.response.kernelBandwidth, P.response.kernelSupport = rp.kernelBandwidth, rp.kernelSupport
         return P
 
-    def run(self, i: int):
+    def run(self, i):
         self.response.bindParams(self._program, i)
 
         def launch() -> None:

@@ -11,7 +11,7 @@ from ctypes import Structure, c_float
 import numpy as np
 
 from . import units as u
-from .hp.glsl import mat3, vec3
+from .hp.glsl import _layout, mat3, vec3
 from .hp.pipeline import SourceCodeMixin
 
 __all__ = ["Target", "SphereTarget", "InnerSphereTarget", "FlatTarget", "DiskTarget", "TargetGuide", "SphereTargetGuide",
@@ -22,7 +22,7 @@ class _Sampled(SourceCodeMixin):
     """what targets and target guides have in common: a stage with parameter blocks that draws a fixed number of
     random numbers per sample"""
 
-    def __init__(self, *, nRNGSamples: int, params: dict = {}, extra: set = set()) -> None:
+    def __init__(self, *, nRNGSamples, params={}, extra=set()):
         super().__init__(params, extra)
         self._draws = int(nRNGSamples)
 
@@ -73,13 +73,13 @@ class SphereTarget(_SphereShape, Target):
     name = "Sphere Target"
 
     class TargetParams(Structure):
-        _fields_ = [("position", vec3), ("radius", c_float), ("_invPos", vec3), ("_invRad", c_float), ("_hemisphereProb", c_float)]
+        _fields_ = _layout(position=vec3, radius=c_float, _invPos=vec3, _invRad=c_float, _hemisphereProb=c_float)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius=1.0 * u.m):
         Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams})
         self.setParams(position=position, radius=radius)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         half_area = 2.0 * np.pi * self.getParam("radius") ** 2
         self.setParams(_hemisphereProb=1.0 / half_area, **self._unit_frame())
 
@@ -92,13 +92,13 @@ class InnerSphereTarget(_SphereShape, Target):
     name = "Inner Sphere Target"
 
     class TargetParams(Structure):
-        _fields_ = [("position", vec3), ("radius", c_float), ("_invPos", vec3), ("_invRad", c_float), ("_prob", c_float)]
+        _fields_ = _layout(position=vec3, radius=c_float, _invPos=vec3, _invRad=c_float, _prob=c_float)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius=1.0 * u.m):
         Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams})
         self.setParams(position=position, radius=radius)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         area = 4.0 * np.pi * self.getParam("radius") ** 2
         self.setParams(_prob=1.0 / area, **self._unit_frame())
 
@@ -123,16 +123,15 @@ class FlatTarget(_PlaneShape, Target):
     name = "Flat Target"
 
     class TargetParams(Structure):
-        _fields_ = [("width", c_float), ("length", c_float), ("position", vec3), ("_normal", vec3), ("_prob", c_float),
-                    ("_objToWorld", mat3)]
+        _fields_ = _layout(width=c_float, length=c_float, position=vec3, _normal=vec3, _prob=c_float, _objToWorld=mat3)
 
-    def __init__(self, *, width: float = 1.0 * u.cm, length: float = 1.0 * u.cm, position=(0.0, 0.0, 0.0),
-                 direction=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), missIsInfinite: bool = False) -> None:
+    def __init__(self, *, width=1.0 * u.cm, length=1.0 * u.cm, position=(0.0, 0.0, 0.0),
+                 direction=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0), missIsInfinite=False):
         Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"direction", "up"})
         self.missIsInfinite, self.direction, self.up = missIsInfinite, direction, up
         self.setParams(width=width, length=length, position=position)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         Target._finishParams(self, i)
         self._plane(self.direction, self.up, self.width * self.length)
 
@@ -148,15 +147,15 @@ class DiskTarget(_PlaneShape, Target):
     name = "Disk Target"
 
     class TargetParams(Structure):
-        _fields_ = [("position", vec3), ("radius", c_float), ("_normal", vec3), ("_prob", c_float), ("_objToWorld", mat3)]
+        _fields_ = _layout(position=vec3, radius=c_float, _normal=vec3, _prob=c_float, _objToWorld=mat3)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m, normal=(0.0, 0.0, 1.0), up=None,
-                 missIsInfinite: bool = False) -> None:
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius=1.0 * u.m, normal=(0.0, 0.0, 1.0), up=None,
+                 missIsInfinite=False):
         Target.__init__(self, nRNGSamples=2, params={"TargetParams": self.TargetParams}, extra={"normal", "up"})
         self.missIsInfinite, self.normal, self.up = missIsInfinite, normal, up
         self.setParams(position=position, radius=radius)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         Target._finishParams(self, i)
         self._plane(self.normal, self.up, np.pi * self.getParam("radius") ** 2)
 
@@ -168,13 +167,13 @@ class SphereTargetGuide(TargetGuide):
     name = "Sphere Target Guide"
 
     class TargetGuideParams(Structure):
-        _fields_ = [("position", vec3), ("radius", c_float), ("_prob", c_float)]
+        _fields_ = _layout(position=vec3, radius=c_float, _prob=c_float)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m) -> None:
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius=1.0 * u.m):
         TargetGuide.__init__(self, nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams})
         self.setParams(position=position, radius=radius)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         self.setParam("_prob", 1.0 / (2.0 * np.pi * self.getParam("radius") ** 2))
 
 
@@ -189,16 +188,15 @@ class FlatTargetGuide(_PlaneShape, TargetGuide):
     name = "Flat Target Guide"
 
     class TargetGuideParams(Structure):
-        _fields_ = [("width", c_float), ("height", c_float), ("position", vec3), ("_normal", vec3), ("_prob", c_float),
-                    ("_objToWorld", mat3)]
+        _fields_ = _layout(width=c_float, height=c_float, position=vec3, _normal=vec3, _prob=c_float, _objToWorld=mat3)
 
-    def __init__(self, *, width: float = 1.0 * u.m, height: float = 1.0 * u.m, position=(0.0, 0.0, 0.0),
-                 normal=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0)) -> None:
+    def __init__(self, *, width=1.0 * u.m, height=1.0 * u.m, position=(0.0, 0.0, 0.0),
+                 normal=(0.0, 0.0, 1.0), up=(0.0, 1.0, 0.0)):
         TargetGuide.__init__(self, nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams}, extra={"normal", "up"})
         self.normal, self.up = normal, up
         self.setParams(width=width, height=height, position=position)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         TargetGuide._finishParams(self, i)
         self._plane(self.normal, self.up, self.width * self.height)
 
@@ -215,14 +213,14 @@ class DiskTargetGuide(_PlaneShape, TargetGuide):
     name = "Disk Target Guide"
 
     class TargetGuideParams(Structure):
-        _fields_ = [("position", vec3), ("radius", c_float), ("_normal", vec3), ("_prob", c_float), ("_objToWorld", mat3)]
+        _fields_ = _layout(position=vec3, radius=c_float, _normal=vec3, _prob=c_float, _objToWorld=mat3)
 
-    def __init__(self, *, position=(0.0, 0.0, 0.0), radius: float = 1.0 * u.m, normal=(0.0, 0.0, 1.0)) -> None:
+    def __init__(self, *, position=(0.0, 0.0, 0.0), radius=1.0 * u.m, normal=(0.0, 0.0, 1.0)):
         TargetGuide.__init__(self, nRNGSamples=2, params={"TargetGuideParams": self.TargetGuideParams}, extra={"normal"})
         self.normal = normal
         self.setParams(position=position, radius=radius)
 
-    def _finishParams(self, i: int) -> None:
+    def _finishParams(self, i):
         self._plane(self.normal, None, np.pi * self.getParam("radius") ** 2, transposed=False)
 
 
