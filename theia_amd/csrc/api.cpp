@@ -65,6 +65,7 @@ struct thx_tracer {
     uint32_t stackDepth = kStackDepth;
     uint32_t stackLds = kStackDepth; // entries of the traversal stack kept in LDS; the rest of stackDepth spills to `spill`
     uint32_t* spill = nullptr;
+    uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_trace.hpp: Walker::save)
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
     uint32_t ldsNodes = 0;        // staged kernel: BVH nodes staged in LDS (0 = walk reads HBM/L2)
@@ -436,7 +437,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
             t->pool = withNodes;
             t->mode |= 4u;
         }
-        if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(4080, std::max(64, std::atoi(env)));
+        if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(2048, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
     } else {
         t->stackLds = t->stackDepth;
@@ -469,6 +470,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (nb) e = hipMalloc((void**)&t->cold, nb);
         const size_t sb = sizeof(uint32_t) * 64u * (t->block / 64u) * (size_t)(t->stackDepth - t->stackLds) * t->gridMax;
         if (e == hipSuccess && sb) e = hipMalloc((void**)&t->spill, sb);
+        const size_t pb = sizeof(uint32_t) * 2u * (8u + t->stackDepth) * (size_t)t->pool * t->gridMax;
+        if (e == hipSuccess) e = hipMalloc((void**)&t->park, pb);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
     if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
@@ -534,6 +537,7 @@ int thx_tracer_destroy(thx_tracer* t) {
     if (t->stats) (void)hipFree(t->stats);
     if (t->cold) (void)hipFree(t->cold);
     if (t->spill) (void)hipFree(t->spill);
+    if (t->park) (void)hipFree(t->park);
     if (t->prof) (void)hipFree(t->prof);
     if (t->devError) (void)hipFree(t->devError);
     if (t->track) (void)hipFree(t->track);
@@ -604,6 +608,11 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stack_lds = t->stackLds;
     a.stack_wave_words = t->stackLds * (t->stack16 ? 32u : 64u);
     a.spill = t->spill;
+    a.park = t->park;
+    a.park_below = t->stackDepth > kParkDeepFrom ? kParkBelowDeep : kParkBelow;
+    a.park_rounds = kParkRounds;
+    if (const char* env = std::getenv("THX_PARK_BELOW")) a.park_below = (uint32_t)std::min(65, std::max(0, std::atoi(env)));
+    if (const char* env = std::getenv("THX_PARK_ROUNDS")) a.park_rounds = (uint32_t)std::max(1, std::atoi(env));
     a.stack16 = t->stack16 ? 1u : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;

@@ -32,9 +32,14 @@ namespace thx {
 
 constexpr uint32_t kSchedThreads = 1024; // upper bound of the workgroup size
 #ifndef THX_POOL_MAX
-#define THX_POOL_MAX 2048 // upper bound of the photon pool of a workgroup (ring entries carry 12-bit slot ids: < 4096)
+#define THX_POOL_MAX 2048 // upper bound of the photon pool of a workgroup (ring entries: 11-bit slot id, bit 11 = a walk taken up again)
 #endif
 constexpr uint32_t kHitMiss = 0xFFFFFFFFu;
+// Walk batches: the last rays of a batch are set aside (Walker::save) and go back into their ring once fewer than
+// LaunchArgs::park_below lanes are still walking after at least park_rounds rounds; a later batch takes them up again
+// together with fresh rays. A batch lasts as long as its longest ray: without this a wavefront spends the second half
+// of most batches on a handful of lanes.
+constexpr uint32_t E_RESUME = 1u << 11; // ring entry of a walk that was set aside
 
 // stage ids == queue ids. The BIRTH queue is the free list of pool slots.
 enum : int { S_BIRTH = 0, S_A = 1, S_T0 = 2, S_BM = 3, S_M = 4, S_TS = 5, S_C = 6, S_NUM = 7 };
@@ -276,6 +281,49 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
     m.dim = L.dim;
     storeMeta(pool, slot, m);
     return dest;
+}
+
+// The walk of one batch: one ray per lane, fresh (begin) or taken up again (restore), round by round until every
+// lane is through -- or until so few are left that they are set aside (`parked`, see LaunchArgs::park_below).
+template <class V>
+THX_DEV QueryHit walkBatch(Lane<V>& L, f3 org, f3 dir, float tmax, bool resumed, THX_GLOBAL uint32_t* area, bool& parked) {
+    Walker<V> wk(L);
+    if (__ballot(resumed) != 0ull) {
+        if (resumed) wk.restore(area, org, dir);
+        else wk.begin(org, dir, tmax);
+    } else {
+        wk.begin(org, dir, tmax);
+    }
+    uint32_t rounds = 0;
+    while (true) {
+        const unsigned long long walking = __ballot(!wk.done());
+        if (walking == 0ull) break;
+        if (rounds >= L.a->park_rounds && (uint32_t)__popcll(walking) < L.a->park_below) {
+            if (!wk.done()) {
+                wk.save(area);
+                parked = true;
+            }
+            break;
+        }
+#ifdef THX_STAGE_PROFILE
+        if (L.prof != nullptr && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1))) {
+            atomicAdd(&L.prof[29], (unsigned long long)__popcll(walking));
+            atomicAdd(&L.prof[30], 1ull);
+        }
+#endif
+        wk.advance();
+        ++rounds;
+    }
+    if (wk.h.valid && !parked) L.cnt.add(ST_HITS);
+    wk.h.aborted = wk.overflow;
+#ifdef THX_STAGE_PROFILE
+    wk.h.trips = wk.pLane;
+    if ((threadIdx.x & 63u) == 0u && L.prof != nullptr) { // wave-level sums (s_memtime is uniform)
+        atomicAdd(&L.prof[24], wk.pInner); atomicAdd(&L.prof[25], wk.pLeaf); atomicAdd(&L.prof[26], wk.pOther);
+        atomicAdd(&L.prof[27], wk.pRounds); atomicAdd(&L.prof[28], wk.pTrips);
+    }
+#endif
+    return wk.h;
 }
 
 template <class V>
@@ -543,7 +591,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
         case S_T0: { // closest-hit walks: primary rays (which 0; a surface hit is finished here,
                      // scene.traverse.glsl:312-351) and shadow rays (which 1, 2; :185-214)
-            const uint32_t slot = entry & 0xFFFu, which = entry >> 12;
+            const uint32_t slot = entry & 0x7FFu, which = entry >> 12;
+            const bool resumed = (entry & E_RESUME) != 0u;
+            bool parked = false;
             int dest = 0;
             bool lastShadow = false;
             if (act) {
@@ -563,7 +613,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
 #ifdef THX_STAGE_PROFILE
                 const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
 #endif
-                QueryHit h = rayQuery(L, f3{c0.x, c0.y, c0.z}, dir, tmax);
+                QueryHit h = walkBatch(L, f3{c0.x, c0.y, c0.z}, dir, tmax, resumed,
+                                       (THX_GLOBAL uint32_t*)(args.park) + ((size_t)(blockIdx.x * P + slot) * 2u + (which == 2u ? 1u : 0u)) * (8u + args.stack_depth),
+                                       parked);
 #ifdef THX_STAGE_PROFILE
                 // per wave: cycles until the first lane / the whole wave is through the walk
                 const unsigned long long wt1 = __builtin_amdgcn_s_memtime();
@@ -583,7 +635,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     if (bin < 3) atomicAdd(&profLds[45 + bin], 1ull); // <= 4 / 5-16 / 17-32; the rest follows from the totals
                 }
 #endif
-                if (which == 0) {
+                if (parked) {
+                    // nothing to finish yet: the ray goes back into its ring
+                } else if (which == 0) {
                     if (h.aborted) { // the traversal stack overflowed: ERROR_CODE_TRACE_ABORT ends the photon
                         Ray ray = loadRay(pool, slot);
                         Meta m = loadMeta(pool, slot);
@@ -617,6 +671,10 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             }
             entA = slot;
             dstA = dest == 4 ? S_BM : (dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : (dest == 3 ? S_BIRTH : (lastShadow ? S_C : -1))));
+            if (parked) {
+                dstA = which == 0u ? S_T0 : S_TS;
+                entA = slot | E_RESUME | (which << 12);
+            }
             break;
         }
         case S_BM: // primary rays whose walk found nothing: BM part below

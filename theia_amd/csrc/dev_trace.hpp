@@ -45,6 +45,9 @@ struct LaunchArgs {
     uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
     uint32_t* spill;           // [waves of the grid][stack_depth - stack_lds][64] deep stack entries, or null
+    uint32_t park_below;       // staged kernel: a walk batch sets its last rays aside once fewer than this many lanes walk (0: never)
+    uint32_t park_rounds;      // ... and it has run at least this many rounds
+    uint32_t* park;            // staged kernel: [gridDim.x][pool][2][8 + stack_depth] state of walks set aside half way (Walker::save)
     float* cold;               // staged kernel: [gridDim.x][2 or 4][pool] float4 = the cold chunks of the photon pools (dev_staged.hpp)
     uint32_t* hits;            // HitRecorder queue (response.queue.glsl layout) or null: histogram response
     uint32_t hit_capacity;     // entries per SoA column of the queue
@@ -1173,15 +1176,13 @@ struct Walker {
         if (cur != WALK_DONE && (cur & 7u) != 0u) enterInstance(cur >> 3);
     }
 
-    // TLAS leaves hold exactly one instance: transform the ray into its object space and dive
-    THX_DEV void enterInstance(uint32_t first) {
+    // object-space ray of instance `curInst`: ao, sr, w; returns the ref of the instance's BLAS root
+    THX_DEV uint32_t instanceFrame() {
         const SceneView& sc = L.a->scene;
-        curInst = sc.tlasInstance[first];
         const float4* rec = reinterpret_cast<const float4*>(sc.instances + curInst);
         float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
         const float4* frame = reinterpret_cast<const float4*>(sc.frames + __float_as_uint(rec[6].w));
         const float4 f0 = frame[0], f1 = frame[1];
-        L.cnt.add(ST_INSTANCES);
         ao = f3{m0.w + ((m0.x * org.x + m0.y * org.y) + m0.z * org.z),
                 m1.w + ((m1.x * org.x + m1.y * org.y) + m1.z * org.z),
                 m2.w + ((m2.x * org.x + m2.y * org.y) + m2.z * org.z)};
@@ -1190,13 +1191,56 @@ struct Walker {
                    (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
         sr = qRay(f0, f1, ao, od);
         w = woopSetup(od);
+        return __float_as_uint(f0.w);
+    }
+
+    // TLAS leaves hold exactly one instance: transform the ray into its object space and dive
+    THX_DEV void enterInstance(uint32_t first) {
+        curInst = L.a->scene.tlasInstance[first];
+        L.cnt.add(ST_INSTANCES);
+        const uint32_t root = instanceFrame();
         inBlas = true;
         push(WALK_SENTINEL);
         L.cnt.add(ST_NODES);
         if (slabRoot(sr, h.t))
-            cur = __float_as_uint(f0.w);
+            cur = root;
         else
             cur = pop(); // pops the sentinel
+    }
+
+    // A walk set aside between two rounds and taken up again later, by any lane of any wavefront of the workgroup
+    // (dev_staged.hpp: the walk stage parks the last few rays of a batch instead of running the wavefront nearly empty
+    // for them). What is kept: the best hit so far, the position in the hierarchy and the stack; the ray frames are
+    // computed again from the ray. The walk itself -- order of visits, arithmetic -- is the same as without the break.
+    THX_DEV void save(THX_GLOBAL uint32_t* a) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        *(THX_GLOBAL u4*)(a) = u4{__float_as_uint(h.t), __float_as_uint(h.b1), __float_as_uint(h.b2), h.prim};
+        *(THX_GLOBAL u4*)(a + 4) = u4{h.instance | (h.valid ? 0x80000000u : 0u), cur, sp | (inBlas ? 0x10000u : 0u) | (overflow ? 0x20000u : 0u), curInst};
+        for (uint32_t e = 0; e < sp; ++e) {
+            uint32_t v;
+            if (e >= ldsN) v = spill[(e - ldsN) * 64u + (threadIdx.x & 63u)];
+            else if (s16) { v = stack16[e * 64]; v = v == 0xFFFEu ? WALK_SENTINEL : v; }
+            else v = stack32[e * 64];
+            a[8 + e] = v;
+        }
+    }
+    THX_DEV void restore(const THX_GLOBAL uint32_t* a, f3 o, f3 d) {
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const SceneView& sc = L.a->scene;
+        const u4 r0 = *(const THX_GLOBAL u4*)(a), r1 = *(const THX_GLOBAL u4*)(a + 4);
+        org = o; dir = d;
+        h.t = __uint_as_float(r0.x); h.b1 = __uint_as_float(r0.y); h.b2 = __uint_as_float(r0.z); h.prim = r0.w;
+        h.instance = r1.x & 0x7FFFFFFFu; h.valid = (r1.x >> 31) != 0u;
+        cur = r1.y;
+        const uint32_t n = r1.z & 0xFFFFu;
+        inBlas = (r1.z & 0x10000u) != 0u; overflow = (r1.z & 0x20000u) != 0u;
+        curInst = r1.w;
+        ao = org;
+        wsr = qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir);
+        sr = wsr;
+        if (inBlas) instanceFrame();
+        sp = 0;
+        for (uint32_t e = 0; e < n; ++e) push(a[8 + e]);
     }
 
     // one round: inner nodes down to a leaf, then that leaf. No-op for a finished lane.

@@ -16,6 +16,10 @@ constexpr uint32_t kStackDepth = kTreeDepth;     // traversal stack entries per 
 constexpr uint32_t kRecordSlots = 1;
 #endif
 constexpr uint32_t kStackLds16 = 16;   // staged kernel: entries of them kept in LDS (16-bit / 32-bit entries), the rest in global memory;
+// staged kernel: a walk batch sets its last rays aside once fewer lanes than kParkBelow still walk (kParkBelowDeep for
+// hierarchies deeper than kParkDeepFrom, whose walks are long and spread more) after at least kParkRounds rounds
+// (dev_staged.hpp: walkBatch; measured: profiles/r02_park.txt)
+constexpr uint32_t kParkBelow = 10, kParkBelowDeep = 16, kParkDeepFrom = 16, kParkRounds = 2;
 constexpr uint32_t kStackLds32 = 10;   // measured on MI355X (profiles/r02_stack_spill.txt): 81 920 triangles 7.27 -> 6.06 ms, 5.2 M triangles 13.2 -> 10.9 ms
 
 // dynamic LDS bytes of a tracing workgroup (lane kernel)
