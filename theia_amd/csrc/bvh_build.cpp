@@ -1,4 +1,4 @@
-// Binned-SAH BVH2 builder (host). Leaves hold <= 4 triangles (BLAS) or exactly
+// Binned-SAH BVH2 builder (host). Leaves hold <= 2 or 3 triangles (BLAS, by mesh size; the walk takes up to 4) or exactly
 // one instance (TLAS). Children of an inner node are adjacent so the walk
 // fetches both with one 64-B access. Node boxes are padded by a few ulps so the
 // conservative slab test can never reject a point the watertight triangle test
@@ -15,6 +15,8 @@
 namespace thx {
 
 namespace {
+
+constexpr uint32_t kSmallMeshTriangles = 16384;
 
 struct Box {
     float lo[3], hi[3];
@@ -341,7 +343,10 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
             for (int k = 0; k < 3; ++k) p.cen[k] = 0.5f * (p.box.lo[k] + p.box.hi[k]);
         }
         std::vector<BvhNode> local;
-        uint32_t leafMax = 4; // the walk tests a leaf's triangles in two pairs
+        // The walk handles up to 4 triangles per leaf (two pairs), but a wavefront pays for the fullest leaf any of its
+        // lanes holds: small leaves win although they deepen the tree -- 2 on meshes whose hierarchy stays in the
+        // caches, 3 on larger ones where every extra level is a memory round trip (profiles/r02_park.txt).
+        uint32_t leafMax = md.n_triangles > kSmallMeshTriangles ? 3u : 2u;
         if (const char* e = std::getenv("THX_LEAF_MAX")) leafMax = std::min(4u, std::max(1u, (uint32_t)std::atoi(e)));
         auto [root, depth] = buildTree(prims, local, leafMax, blasLimit);
         (void)root;
