@@ -275,6 +275,30 @@ def test_config3_batches_through_the_scheduler(hip_backend):
     assert np.abs(alone - curves["hip"][2]).max() <= 1e-5 * alone.sum()
 
 
+@pytest.mark.parametrize("scene", ["suzanne-grid", "sphere-81920"])
+def test_parked_walks_change_nothing(hip_backend, scene, monkeypatch):
+    """A walk batch sets its last rays aside and a later batch takes them up again (dev_staged.hpp: walkBatch). Whether that
+    never happens, happens by the default policy or after every single round (each ray is saved and restored a dozen
+    times, stack entries in LDS and beyond): every photon's events are the same, bit for bit."""
+    make = {"suzanne-grid": lambda: S.config5_suzanne_grid(batch=20000, n_side=4, polarized=True, stats=True, track=True),
+            "sphere-81920": lambda: S.config2_sphere(batch=20000, subdivide=3, stats=True, track=True)}[scene]
+    runs = {}
+    for name, env in (("never", {"THX_PARK_BELOW": "0"}), ("default", {}), ("always", {"THX_PARK_BELOW": "65", "THX_PARK_ROUNDS": "1"}),
+                      ("always, 4 stack entries in LDS", {"THX_PARK_BELOW": "65", "THX_PARK_ROUNDS": "1", "THX_STACK_LDS": "4"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            sc = make()
+            hist = S.run_batches(sc, 1)[0]
+            runs[name] = (hist, sc.tracer.program.read_stats(), sc.tracer.program.read_track(sc.tracer.batchSize))
+    h0, s0, t0 = runs["never"]
+    assert h0.sum() > 0 and s0[0] == 20000
+    for name, (h, s, t) in runs.items():
+        assert np.array_equal(t0.view(np.uint32), t.view(np.uint32)), name
+        assert np.array_equal(s0[:20], s[:20]), name  # events, and queries / nodes / triangles / instances / hits: the same walk
+        assert np.abs(h - h0).max() <= 1e-5 * h0.sum(), name               # same hits, summed in another order
+
+
 def test_production_kernel_equals_instrumented(hip_backend):
     """the un-instrumented kernel (what bench.py times) produces the same light curve"""
     n = 50000
