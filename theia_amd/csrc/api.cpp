@@ -256,7 +256,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     UP(built.frames, frames, TreeFrame)
     UP(built.tris, tris, TriRecord)
     UP(built.instances, instances, InstanceRecord)
-    UP(built.tlasInstance, tlasInstance, uint32_t)
+    UP(built.walkInstances, walkInstances, WalkInstance)
 #undef UP
     // reference-layout vertex / index buffers (scene.types.glsl:6-14), one pair per mesh
     std::vector<uint64_t> vaddr(n_meshes), iaddr(n_meshes);
@@ -290,17 +290,16 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     s->info.bytes_triangles = built.tris.size() * sizeof(TriRecord);
     s->info.bytes_instances = built.instances.size() * sizeof(InstanceRecord);
     uint64_t total = s->info.bytes_nodes + s->info.bytes_triangles + s->info.bytes_instances +
-                     built.tlasInstance.size() * 4 + geo.size() * sizeof(GeometryGLSL);
+                     built.walkInstances.size() * sizeof(WalkInstance) + geo.size() * sizeof(GeometryGLSL);
     for (uint32_t m = 0; m < n_meshes; ++m)
         total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
     s->info.bytes_total = total;
     // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_trace.hpp: Walker,
-    // processRayQuery): half a NodePair per child box; a TriRecord; w2o (48) + the frame word's 16-B chunk +
-    // the TreeFrame (32) per instance entry; index triple (12) + three vertices (72) + Geometry (24) +
+    // processRayQuery): half a NodePair per child box; a TriRecord; a WalkInstance (80) per instance entry; index triple (12) + three vertices (72) + Geometry (24) +
     // Material (24) + the instance record (112) per reconstructed hit
     s->info.layout_box_bytes = sizeof(NodePair) / 2;
     s->info.layout_triangle_bytes = sizeof(TriRecord);
-    s->info.layout_instance_bytes = 48 + 16 + sizeof(TreeFrame);
+    s->info.layout_instance_bytes = sizeof(WalkInstance);
     s->info.layout_hit_bytes = 12 + 72 + sizeof(GeometryGLSL) + sizeof(MaterialGLSL) + sizeof(InstanceRecord);
     *out = s;
     return THX_OK;

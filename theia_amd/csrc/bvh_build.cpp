@@ -192,7 +192,7 @@ namespace {
 inline float dequant(uint32_t q, float step, float origin) { return std::fmaf((float)q, step, origin); }
 
 // returns the stack entries a walk of the tree needs (4-wide records; 0 for pair records: the depth of the tree, known to the caller)
-uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame) {
+uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame, bool tlas) {
     const BvhNode& rn = out.nodes[root];
     for (int k = 0; k < 3; ++k) {
         const float lo = rn.lo[k], hi = rn.hi[k];
@@ -220,7 +220,7 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame) {
     // inner nodes of this tree get consecutive pair indices in depth-first order
     auto refOf = [&](uint32_t node, auto&& self) -> uint32_t {
         const BvhNode& n = out.nodes[node];
-        if (n.count != 0) return (n.leftFirst << 3) | n.count; // leaf: as the walk's `cur`
+        if (n.count != 0) return ((tlas ? out.tlasInstance[n.leftFirst] : n.leftFirst) << 3) | n.count; // leaf: as the walk's `cur`
         const uint32_t index = (uint32_t)out.pairs.size();
         out.pairs.emplace_back();
         uint32_t w[8];
@@ -251,7 +251,7 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame) {
     auto refOf = [&](uint32_t node, uint32_t& need, auto&& self) -> uint32_t {
         const BvhNode& n = out.nodes[node];
         need = 0;
-        if (n.count != 0) return (n.leftFirst << 3) | n.count;
+        if (n.count != 0) return ((tlas ? out.tlasInstance[n.leftFirst] : n.leftFirst) << 3) | n.count;
         uint32_t ch[4] = {n.leftFirst, n.leftFirst + 1, 0, 0};
         int k = 2;
         while (k < 4) {
@@ -303,10 +303,20 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame) {
 void emitPairs(BuiltScene& out) {
     out.pairs.clear();
     out.frames.assign(1 + out.blasRoot.size(), TreeFrame{});
-    const uint32_t top = emitTree(out, out.tlasRoot, out.frames[0]);
+    const uint32_t top = emitTree(out, out.tlasRoot, out.frames[0], true);
     uint32_t deepest = 0;
-    for (size_t m = 0; m < out.blasRoot.size(); ++m) deepest = std::max(deepest, emitTree(out, out.blasRoot[m], out.frames[1 + m]));
+    for (size_t m = 0; m < out.blasRoot.size(); ++m) deepest = std::max(deepest, emitTree(out, out.blasRoot[m], out.frames[1 + m], false));
     if (out.pairs.empty()) out.pairs.resize(2); // single-leaf trees only: keep the array non-empty
+    out.walkInstances.resize(out.instances.size());
+    for (size_t k = 0; k < out.instances.size(); ++k) {
+        WalkInstance& w = out.walkInstances[k];
+        const TreeFrame& f = out.frames[out.instances[k].frame];
+        std::memcpy(w.w2o, out.instances[k].w2o, sizeof(w.w2o));
+        std::memcpy(w.origin, f.origin, sizeof(w.origin));
+        std::memcpy(w.step, f.step, sizeof(w.step));
+        w.rootRef = f.rootRef;
+        w.pad = 0;
+    }
 #ifdef THX_BVH4
     out.maxDepth = top + 1 + deepest;
 #else

@@ -17,7 +17,8 @@ struct BuiltScene {
     std::vector<TreeFrame> frames;      // quantisation frame + root ref per tree: [TLAS, BLAS 0, BLAS 1, ...]
     std::vector<TriRecord> tris;        // leaf order, all meshes
     std::vector<InstanceRecord> instances;
-    std::vector<uint32_t> tlasInstance; // TLAS leaf slot -> instance id
+    std::vector<uint32_t> tlasInstance; // TLAS leaf slot -> instance id (host only: the leaf refs of `pairs` hold the ids)
+    std::vector<WalkInstance> walkInstances; // by instance id
     uint32_t tlasRoot = 0;
     uint32_t maxDepth = 0;              // TLAS depth + 1 + deepest BLAS (stack bound)
     std::vector<uint32_t> blasRoot;     // per mesh

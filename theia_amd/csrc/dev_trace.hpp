@@ -1178,11 +1178,8 @@ struct Walker {
 
     // object-space ray of instance `curInst`: ao, sr, w; returns the ref of the instance's BLAS root
     THX_DEV uint32_t instanceFrame() {
-        const SceneView& sc = L.a->scene;
-        const float4* rec = reinterpret_cast<const float4*>(sc.instances + curInst);
-        float4 m0 = rec[0], m1 = rec[1], m2 = rec[2];
-        const float4* frame = reinterpret_cast<const float4*>(sc.frames + __float_as_uint(rec[6].w));
-        const float4 f0 = frame[0], f1 = frame[1];
+        const float4* rec = reinterpret_cast<const float4*>(L.a->scene.walkInstances + curInst);
+        const float4 m0 = rec[0], m1 = rec[1], m2 = rec[2], f0 = rec[3], f1 = rec[4];
         ao = f3{m0.w + ((m0.x * org.x + m0.y * org.y) + m0.z * org.z),
                 m1.w + ((m1.x * org.x + m1.y * org.y) + m1.z * org.z),
                 m2.w + ((m2.x * org.x + m2.y * org.y) + m2.z * org.z)};
@@ -1196,7 +1193,7 @@ struct Walker {
 
     // TLAS leaves hold exactly one instance: transform the ray into its object space and dive
     THX_DEV void enterInstance(uint32_t first) {
-        curInst = L.a->scene.tlasInstance[first];
+        curInst = first; // TLAS leaves hold instance ids
         L.cnt.add(ST_INSTANCES);
         const uint32_t root = instanceFrame();
         inBlas = true;

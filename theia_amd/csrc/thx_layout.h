@@ -63,6 +63,18 @@ struct alignas(16) InstanceRecord {
 };
 static_assert(sizeof(InstanceRecord) == 112, "instance record must be 112 B");
 
+// What the walk reads when it enters an instance, 80 B = five 16-B loads from one address: the world -> object
+// matrix and the quantisation frame of the instance's mesh. (A copy of what InstanceRecord and TreeFrame hold: read
+// through them, entering an instance is three dependent loads -- leaf slot -> instance id -> record -> frame.)
+struct alignas(16) WalkInstance {
+    float w2o[12];
+    float origin[3];
+    uint32_t rootRef;
+    float step[3];
+    uint32_t pad;
+};
+static_assert(sizeof(WalkInstance) == 80, "walk instance record must be 80 B");
+
 #pragma pack(push, 4)
 // reference: src/theia/material.py:122-140, shader/material.glsl:11-34
 struct MediumGLSL {
@@ -89,7 +101,7 @@ struct SceneView {
     const NodePair* nodes; // pair records of all trees
     const TriRecord* tris;
     const InstanceRecord* instances;
-    const uint32_t* tlasInstance; // TLAS leaf slot -> instance id
+    const WalkInstance* walkInstances; // by instance id (the TLAS leaves hold instance ids)
     const GeometryGLSL* geometries;
     const TreeFrame* frames;
     TreeFrame tlas; // frame 0 by value: every query starts with it
