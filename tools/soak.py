@@ -19,6 +19,14 @@ while time.time() - t0 < seconds:
     if name == "config2":
         kw["guide"] = bool(gen.integers(2))
         kw["maxPathLength"] = int(gen.integers(1, 30))
+    # scheduler knobs: how eagerly walk batches set their last rays aside, how much of the traversal stack lives in LDS
+    knobs = {}
+    if gen.integers(2):
+        knobs = {"THX_PARK_BELOW": str(int(gen.integers(0, 66))), "THX_PARK_ROUNDS": str(int(gen.integers(1, 5))),
+                 "THX_STACK_LDS": str(int(gen.integers(2, 33)))}
+    for k in ("THX_PARK_BELOW", "THX_PARK_ROUNDS", "THX_STACK_LDS"):
+        os.environ.pop(k, None)
+    os.environ.update(knobs)
     sc = make(batch=n, stats=True, key=int(gen.integers(1 << 40)), **kw)
     reps = int(gen.integers(1, 4))
     hists = S.run_batches(sc, reps)
@@ -26,8 +34,8 @@ while time.time() - t0 < seconds:
     ok = cb.created == reps * n and all(np.isfinite(h).all() for h in hists)
     launches += reps; photons += reps * n
     if not ok:
-        print(f"FAIL {name} n={n} {kw} created={cb.created} expected={reps * n}", flush=True)
+        print(f"FAIL {name} n={n} {kw} {knobs} created={cb.created} expected={reps * n}", flush=True)
         sys.exit(1)
     if launches % 50 < reps:
-        print(f"{time.time() - t0:6.0f} s  {launches} launches  {photons / 1e6:.0f} M photons  last: {name} n={n} {kw}", flush=True)
+        print(f"{time.time() - t0:6.0f} s  {launches} launches  {photons / 1e6:.0f} M photons  last: {name} n={n} {kw} {knobs}", flush=True)
 print(f"soak ok: {launches} launches, {photons / 1e6:.0f} M photons in {time.time() - t0:.0f} s")
