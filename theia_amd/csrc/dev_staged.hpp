@@ -283,17 +283,12 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
     return dest;
 }
 
-// The walk of one batch: one ray per lane, fresh (begin) or taken up again (restore), round by round until every
+// The walk of one batch: one ray per lane, fresh or taken up again (Walker::start), round by round until every
 // lane is through -- or until so few are left that they are set aside (`parked`, see LaunchArgs::park_below).
 template <class V>
 THX_DEV QueryHit walkBatch(Lane<V>& L, f3 org, f3 dir, float tmax, bool resumed, THX_GLOBAL uint32_t* area, bool& parked) {
     Walker<V> wk(L);
-    if (__ballot(resumed) != 0ull) {
-        if (resumed) wk.restore(area, org, dir);
-        else wk.begin(org, dir, tmax);
-    } else {
-        wk.begin(org, dir, tmax);
-    }
+    wk.start(org, dir, tmax, resumed, area);
     uint32_t rounds = 0;
     while (true) {
         const unsigned long long walking = __ballot(!wk.done());

@@ -1208,7 +1208,7 @@ struct Walker {
     // A walk set aside between two rounds and taken up again later, by any lane of any wavefront of the workgroup
     // (dev_staged.hpp: the walk stage parks the last few rays of a batch instead of running the wavefront nearly empty
     // for them). What is kept: the best hit so far, the position in the hierarchy and the stack; the ray frames are
-    // computed again from the ray. The walk itself -- order of visits, arithmetic -- is the same as without the break.
+    // computed again from the ray by start(). The walk itself -- order of visits, arithmetic -- is the same as without the break.
     THX_DEV void save(THX_GLOBAL uint32_t* a) {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         *(THX_GLOBAL u4*)(a) = u4{__float_as_uint(h.t), __float_as_uint(h.b1), __float_as_uint(h.b2), h.prim};
@@ -1221,22 +1221,49 @@ struct Walker {
             a[8 + e] = v;
         }
     }
-    THX_DEV void restore(const THX_GLOBAL uint32_t* a, f3 o, f3 d) {
+    // A batch of the staged kernel's walk stage holds fresh rays (what begin() does for one ray) and rays taken up again (what save() wrote). Their
+    // expensive parts are the same -- the world-space slab ray, and the object-space frames of the instance a ray is
+    // in (the one it was set aside in, or the only instance of the scene, which begin enters at once) -- so the lanes of
+    // both kinds go through them together instead of one kind after the other.
+    THX_DEV void start(f3 o, f3 d, float tmax, bool resumed, const THX_GLOBAL uint32_t* a) {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         const SceneView& sc = L.a->scene;
-        const u4 r0 = *(const THX_GLOBAL u4*)(a), r1 = *(const THX_GLOBAL u4*)(a + 4);
         org = o; dir = d;
-        h.t = __uint_as_float(r0.x); h.b1 = __uint_as_float(r0.y); h.b2 = __uint_as_float(r0.z); h.prim = r0.w;
-        h.instance = r1.x & 0x7FFFFFFFu; h.valid = (r1.x >> 31) != 0u;
-        cur = r1.y;
-        const uint32_t n = r1.z & 0xFFFFu;
-        inBlas = (r1.z & 0x10000u) != 0u; overflow = (r1.z & 0x20000u) != 0u;
-        curInst = r1.w;
-        ao = org;
         wsr = qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir);
         sr = wsr;
-        if (inBlas) instanceFrame();
+        ao = org;
+        uint32_t n = 0;       // stack entries to refill (a ray taken up again)
+        bool enter = false;   // fresh ray of a one-instance scene: goes straight into the instance
+        if (resumed) {
+            const u4 r0 = *(const THX_GLOBAL u4*)(a), r1 = *(const THX_GLOBAL u4*)(a + 4);
+            h.t = __uint_as_float(r0.x); h.b1 = __uint_as_float(r0.y); h.b2 = __uint_as_float(r0.z); h.prim = r0.w;
+            h.instance = r1.x & 0x7FFFFFFFu; h.valid = (r1.x >> 31) != 0u;
+            cur = r1.y;
+            n = r1.z & 0xFFFFu;
+            inBlas = (r1.z & 0x10000u) != 0u; overflow = (r1.z & 0x20000u) != 0u;
+            curInst = r1.w;
+        } else {
+            h.valid = false; h.instance = 0; h.prim = 0; h.t = tmax; h.b1 = 0.0f; h.b2 = 0.0f;
+            L.cnt.add(ST_QUERIES);
+            inBlas = false; curInst = 0; overflow = false;
+            L.cnt.add(ST_NODES);
+            cur = slabRoot(wsr, h.t) ? sc.tlas.rootRef : WALK_DONE;
+            enter = cur != WALK_DONE && (cur & 7u) != 0u;
+            if (enter) {
+                curInst = cur >> 3;
+                L.cnt.add(ST_INSTANCES);
+            }
+        }
         sp = 0;
+        if (inBlas || enter) {
+            const uint32_t root = instanceFrame();
+            if (enter) { // what enterInstance does after the frames
+                inBlas = true;
+                push(WALK_SENTINEL);
+                L.cnt.add(ST_NODES);
+                cur = slabRoot(sr, h.t) ? root : pop();
+            }
+        }
         for (uint32_t e = 0; e < n; ++e) push(a[8 + e]);
     }
 

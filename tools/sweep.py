@@ -11,6 +11,7 @@ from theia_amd.hp.pipeline import Pipeline
 MAKE = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid,
         "mid": lambda batch: S.config2_sphere(batch, subdivide=3), "bigmesh": lambda batch: S.config2_sphere(batch, subdivide=6)}
 n = int(sys.argv[1])
+WARM = int(os.environ.get("SWEEP_WARMUP", "10"))
 names = sys.argv[2].split(",")
 axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[3:]]
 for name in names:
@@ -23,10 +24,10 @@ for name in names:
         sc = MAKE[name](batch=n)
         pipe = Pipeline(sc.stages())
         ms = []
-        for k in range(5):
+        for k in range(WARM + 5):  # the clocks of a fresh GPU take a second of work to settle
             pipe.run(k % 2)
             ms.append(sc.tracer.program.last_kernel_ms(k % 2))
         info = sc.tracer.program.launch_info(n)
         tag = " ".join(f"{k}={v}" for (k, _), v in zip(axes, combo))
-        print(f"{name:8s} {tag:40s} kernel ms = {np.median(ms[2:]):8.3f}   block={info['block']} lds={info['lds_bytes']}", flush=True)
+        print(f"{name:8s} {tag:40s} kernel ms = {np.median(ms[-5:]):8.3f}   block={info['block']} lds={info['lds_bytes']}", flush=True)
         del sc, pipe
