@@ -1027,6 +1027,12 @@ THX_DEV float slabNode(const float4 a, const float4 b, const SlabRay& r, float t
 struct QRay {
     v2f a_xy, b_xy;
     float a_z, b_z;
+#ifndef THX_SLAB_MINMAX
+    // byte selectors (v_perm_b32) that pick a box's near planes by the signs of the ray: sxy from the {lo.x|lo.y,
+    // hi.x|hi.y} word pair (the far planes come out of the same selector with the operands swapped), sz puts
+    // {near z | far z} of the lo.z|hi.z word in order
+    uint32_t sxy, sz;
+#endif
 };
 THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origin, rootRef}, f1 = {step, -}
     const float ix = slabInv(d.x), iy = slabInv(d.y), iz = slabInv(d.z);
@@ -1035,17 +1041,34 @@ THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origi
     r.b_xy = v2f{__builtin_fmaf(f0.x, ix, -(o.x * ix)), __builtin_fmaf(f0.y, iy, -(o.y * iy))};
     r.a_z = f1.z * iz;
     r.b_z = __builtin_fmaf(f0.z, iz, -(o.z * iz));
+#ifndef THX_SLAB_MINMAX
+    r.sxy = (r.a_xy.x < 0.0f ? 0x0504u : 0x0100u) | (r.a_xy.y < 0.0f ? 0x07060000u : 0x03020000u);
+    r.sz = r.a_z < 0.0f ? 0x01000302u : 0x03020100u;
+#endif
     return r;
 }
 // one child of a pair record: c.x = lo.x | lo.y << 16, c.y = hi.x | hi.y << 16, c.z = lo.z | hi.z << 16
 THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
+#ifndef THX_SLAB_MINMAX
+    // Near and far plane of every axis picked by the sign of the ray (one v_perm_b32 per word) instead of computing
+    // both distances and taking min / max: t = q a + b is monotonic in q, so the values are the same ones.
+    const uint32_t nxy = __builtin_amdgcn_perm(wh, wl, r.sxy), fxy = __builtin_amdgcn_perm(wl, wh, r.sxy);
+    const uint32_t nfz = __builtin_amdgcn_perm(wz, wz, r.sz);
+    const v2f tn_xy = __builtin_elementwise_fma(v2f{(float)(nxy & 0xFFFFu), (float)(nxy >> 16)}, r.a_xy, r.b_xy);
+    const v2f tf_xy = __builtin_elementwise_fma(v2f{(float)(fxy & 0xFFFFu), (float)(fxy >> 16)}, r.a_xy, r.b_xy);
+    const float tn_z = __builtin_fmaf((float)(nfz & 0xFFFFu), r.a_z, r.b_z), tf_z = __builtin_fmaf((float)(nfz >> 16), r.a_z, r.b_z);
+    const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
+    const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
+    return tn <= tf * 1.0000004f ? tn : -1.0f;
+#else
     const v2f t0 = __builtin_elementwise_fma(v2f{(float)(wl & 0xFFFFu), (float)(wl >> 16)}, r.a_xy, r.b_xy);
     const v2f t1 = __builtin_elementwise_fma(v2f{(float)(wh & 0xFFFFu), (float)(wh >> 16)}, r.a_xy, r.b_xy);
     const float tz0 = __builtin_fmaf((float)(wz & 0xFFFFu), r.a_z, r.b_z), tz1 = __builtin_fmaf((float)(wz >> 16), r.a_z, r.b_z);
     float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
     return tn <= tf * 1.0000004f ? tn : -1.0f;
+#endif
 }
 // the same with a miss at infinity (what the 4-wide visit sorts by)
 THX_DEV float slabChildFar(const float4 c, const QRay& r, float tmax) {
