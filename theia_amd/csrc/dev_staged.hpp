@@ -397,6 +397,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const bool birthLane = qLane == (uint32_t)S_BIRTH;
 
 #ifdef THX_STAGE_PROFILE
+    const unsigned long long profWg0 = __builtin_amdgcn_s_memrealtime();
     unsigned long long profIdle0 = __builtin_amdgcn_s_memtime();
     unsigned long long* const profLds = reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF);
     L.prof = profLds;
@@ -812,6 +813,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     if (aborted && tid == 0 && args.error != nullptr) atomicOr(args.error, THX_DEVERR_WATCHDOG);
 #ifdef THX_STAGE_PROFILE
     if (tid < 48 && args.prof) atomicAdd(&args.prof[tid], reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF)[tid]);
+    if (tid == 0 && args.prof) { // how evenly the workgroups finish: sum and maximum of their run times (100 MHz ticks)
+        const unsigned long long ticks = __builtin_amdgcn_s_memrealtime() - profWg0;
+        atomicAdd(&args.prof[15], ticks);
+        atomicMax(&args.prof[23], ticks);
+    }
 #endif
     float* slab = args.slabs + (size_t)blockIdx.x * n_bins;
     for (uint32_t i = tid; i < n_bins; i += T) slab[i] = aborted ? __uint_as_float(0x7FC00000u) : hist[i];

@@ -48,3 +48,8 @@ if out[40] or out[42]:
     print(f"trips per ray: primary {int(out[41]) / max(int(out[40]), 1):.1f} ({int(out[40]) / rays:.0%} of the rays), shadow {int(out[43]) / max(int(out[42]), 1):.1f}; "
           f"longest ray of a batch {int(out[44]) / w:.1f}; rays with <=4 / 5-16 / 17-32 / >32 trips: "
           f"{int(out[45]) / rays:.0%} / {int(out[46]) / rays:.0%} / {int(out[47]) / rays:.0%} / {(rays - int(out[45]) - int(out[46]) - int(out[47])) / rays:.0%}")
+
+if out[23]:
+    g = info["grid"]
+    print(f"workgroup run times: mean {int(out[15]) / g / 100.0:.1f} us, longest {int(out[23]) / 100.0:.1f} us "
+          f"(+{int(out[23]) * g / max(int(out[15]), 1) - 1.0:.1%})")
