@@ -1219,13 +1219,15 @@ struct Walker {
         curInst = first; // TLAS leaves hold instance ids
         L.cnt.add(ST_INSTANCES);
         const uint32_t root = instanceFrame();
-        inBlas = true;
-        push(WALK_SENTINEL);
         L.cnt.add(ST_NODES);
-        if (slabRoot(sr, h.t))
+        if (slabRoot(sr, h.t)) {
+            inBlas = true;
+            push(WALK_SENTINEL);
             cur = root;
-        else
-            cur = pop(); // pops the sentinel
+        } else { // the ray misses the mesh's own box (the instance's world-space box is looser): stay in world space
+            sr = wsr;
+            cur = pop();
+        }
     }
 
     // A walk set aside between two rounds and taken up again later, by any lane of any wavefront of the workgroup
@@ -1281,10 +1283,15 @@ struct Walker {
         if (inBlas || enter) {
             const uint32_t root = instanceFrame();
             if (enter) { // what enterInstance does after the frames
-                inBlas = true;
-                push(WALK_SENTINEL);
                 L.cnt.add(ST_NODES);
-                cur = slabRoot(sr, h.t) ? root : pop();
+                if (slabRoot(sr, h.t)) {
+                    inBlas = true;
+                    push(WALK_SENTINEL);
+                    cur = root;
+                } else {
+                    sr = wsr;
+                    cur = pop();
+                }
             }
         }
         for (uint32_t e = 0; e < n; ++e) push(a[8 + e]);
@@ -1380,7 +1387,7 @@ struct Walker {
         if (cur == WALK_DONE || (cur & 7u) == 0u) return; // finished, or still at an inner node (early exit above)
         if (cur == WALK_SENTINEL) { // back to world space
             inBlas = false;
-            ao = org; sr = wsr;
+            sr = wsr;
             cur = pop();
             return;
         }
@@ -1407,6 +1414,14 @@ struct Walker {
                 }
             }
             cur = pop();
+#ifndef THX_NO_LEAF_EXIT
+            // the last leaf of an instance visit: leave the instance here instead of spending the next round on it
+            if (cur == WALK_SENTINEL) {
+                inBlas = false;
+                sr = wsr;
+                cur = pop();
+            }
+#endif
         }
     }
 };
