@@ -163,15 +163,16 @@ THX_DEV Ray loadRay(const Pool<V>& p, uint32_t s) {
     }
     return r;
 }
+// `cold`: which cold chunks the caller may have changed (bit k = chunk k); the others are not written again
 template <class V>
-THX_DEV void storeRay(const Pool<V>& p, uint32_t s, const Ray& r) {
+THX_DEV void storeRay(const Pool<V>& p, uint32_t s, const Ray& r, uint32_t cold = 0xFu) {
     p.st[0 * p.P + s] = make_float4(r.position.x, r.position.y, r.position.z, r.time);
     p.st[1 * p.P + s] = make_float4(r.direction.x, r.direction.y, r.direction.z, r.wavelength);
-    p.stCold(0, s, make_float4(r.lin_contrib, r.log_contrib, __uint_as_float((uint32_t)r.medium), __uint_as_float((uint32_t)(r.medium >> 32))));
-    p.stCold(1, s, make_float4(r.constants.n, r.constants.vg, r.constants.mu_s, r.constants.mu_e));
+    if (cold & 1u) p.stCold(0, s, make_float4(r.lin_contrib, r.log_contrib, __uint_as_float((uint32_t)r.medium), __uint_as_float((uint32_t)(r.medium >> 32))));
+    if (cold & 2u) p.stCold(1, s, make_float4(r.constants.n, r.constants.vg, r.constants.mu_s, r.constants.mu_e));
     if constexpr (V::POL) {
-        p.stCold(2, s, make_float4(r.stokes.x, r.stokes.y, r.stokes.z, r.stokes.w));
-        p.stCold(3, s, make_float4(r.polRef.x, r.polRef.y, r.polRef.z, 0.0f));
+        if (cold & 4u) p.stCold(2, s, make_float4(r.stokes.x, r.stokes.y, r.stokes.z, r.stokes.w));
+        if (cold & 8u) p.stCold(3, s, make_float4(r.polRef.x, r.polRef.y, r.polRef.z, 0.0f));
     }
 }
 
@@ -277,7 +278,8 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
     int dest;
     if (scatterNeeded) dest = 1;
     else dest = endStep(L, ray, m, result) ? 2 : 3;
-    storeRay(pool, slot, ray);
+    // without a surface interaction only the contributions changed (and what the photon roulette of endStep rescales)
+    storeRay(pool, slot, ray, hit.valid ? 0xFu : ((args.flags & THX_FLAG_PHOTON) ? 0x5u : 0x1u));
     m.dim = L.dim;
     storeMeta(pool, slot, m);
     return dest;
@@ -692,7 +694,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 draw2(L, u0, u1); // random2D
                 scatterRay(L, rayA, rayA.medium, u0, u1);
                 doA = endStep(L, rayA, mA, RESULT_CODE_RAY_SCATTERED);
-                storeRay(pool, slotA, rayA);
+                storeRay(pool, slotA, rayA, 0xDu); // a scatter leaves the medium constants alone
                 mA.dim = L.dim;
                 if (!doA) {
                     storeMeta(pool, slotA, mA);
