@@ -110,13 +110,13 @@ struct Pool {
     uint16_t* q;      // rings
     uint32_t* ctr;    // counters
     typedef float vec4 __attribute__((ext_vector_type(4))); // (HIP's float4 has no constructors for address-space qualified objects)
-    THX_GLOBAL vec4* cold; // global [NCOLD][P] of this workgroup
+    THX_GLOBAL vec4* cold; // global [P][NCOLD] of this workgroup: the chunks of a photon share a 32- / 64-B line
     // cold chunk k: 0 {lin, log, medium}, 1 {n, vg, mu_s, mu_e}, 2 {stokes}, 3 {polRef}
     THX_DEV float4 ldCold(uint32_t k, uint32_t slot) const {
-        const vec4 v = cold[k * P + slot];
+        const vec4 v = cold[slot * Lay::NCOLD + k];
         return make_float4(v.x, v.y, v.z, v.w);
     }
-    THX_DEV void stCold(uint32_t k, uint32_t slot, float4 v) const { cold[k * P + slot] = vec4{v.x, v.y, v.z, v.w}; }
+    THX_DEV void stCold(uint32_t k, uint32_t slot, float4 v) const { cold[slot * Lay::NCOLD + k] = vec4{v.x, v.y, v.z, v.w}; }
     uint32_t P, cap, capShift; // pool size, ring capacity (power of two >= P) and its log2
     // ring s holds slot ids; the TS ring (last) has room for 2 cap entries (two shadow rays per photon)
     uint32_t qHalf, ctrWord; // LDS half-word index of ring 0, LDS word index of the counters
