@@ -1220,14 +1220,17 @@ struct Walker {
         L.cnt.add(ST_INSTANCES);
         const uint32_t root = instanceFrame();
         L.cnt.add(ST_NODES);
-        if (slabRoot(sr, h.t)) {
-            inBlas = true;
-            push(WALK_SENTINEL);
+        // (a ray that misses the mesh's own box -- the instance's world-space box is looser -- takes the sentinel
+        // straight off again and leaves through the ordinary exit in the next round. Staying in world space right
+        // here is equivalent on paper and was measured no faster; with hipcc 7.2 the production variant of that
+        // form traced ~1 % of the photons of the two-shell scene differently from run to run, the instrumented
+        // variant did not: tests/test_gpu_parity.py::test_production_kernel_equals_instrumented keeps watch.)
+        inBlas = true;
+        push(WALK_SENTINEL);
+        if (slabRoot(sr, h.t))
             cur = root;
-        } else { // the ray misses the mesh's own box (the instance's world-space box is looser): stay in world space
-            sr = wsr;
-            cur = pop();
-        }
+        else
+            cur = pop(); // pops the sentinel
     }
 
     // A walk set aside between two rounds and taken up again later, by any lane of any wavefront of the workgroup
@@ -1283,15 +1286,10 @@ struct Walker {
         if (inBlas || enter) {
             const uint32_t root = instanceFrame();
             if (enter) { // what enterInstance does after the frames
+                inBlas = true;
+                push(WALK_SENTINEL);
                 L.cnt.add(ST_NODES);
-                if (slabRoot(sr, h.t)) {
-                    inBlas = true;
-                    push(WALK_SENTINEL);
-                    cur = root;
-                } else {
-                    sr = wsr;
-                    cur = pop();
-                }
+                cur = slabRoot(sr, h.t) ? root : pop();
             }
         }
         for (uint32_t e = 0; e < n; ++e) push(a[8 + e]);
