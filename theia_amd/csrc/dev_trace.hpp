@@ -1220,17 +1220,28 @@ struct Walker {
         L.cnt.add(ST_INSTANCES);
         const uint32_t root = instanceFrame();
         L.cnt.add(ST_NODES);
-        // (a ray that misses the mesh's own box -- the instance's world-space box is looser -- takes the sentinel
-        // straight off again and leaves through the ordinary exit in the next round. Staying in world space right
-        // here is equivalent on paper and was measured no faster; with hipcc 7.2 the production variant of that
-        // form traced ~1 % of the photons of the two-shell scene differently from run to run, the instrumented
-        // variant did not: tests/test_gpu_parity.py::test_production_kernel_equals_instrumented keeps watch.)
+        // (A ray that misses the mesh's own box -- the instance's world-space box is looser -- takes the sentinel straight
+        // off again and leaves through the ordinary exit in the next round. Staying in world space right here
+        // (-DTHX_EXP_NEW_MISS) is equivalent and was measured no faster; compiled with the SDWA peephole of hipcc 7.2
+        // the production variant of that form traced ~1 % of the photons of the two-shell scene differently from launch to
+        // launch -- the Makefile turns the peephole off, test_production_kernel_equals_instrumented keeps watch.)
+#ifdef THX_EXP_NEW_MISS
+        if (slabRoot(sr, h.t)) {
+            inBlas = true;
+            push(WALK_SENTINEL);
+            cur = root;
+        } else {
+            sr = wsr;
+            cur = pop();
+        }
+#else
         inBlas = true;
         push(WALK_SENTINEL);
         if (slabRoot(sr, h.t))
             cur = root;
         else
             cur = pop(); // pops the sentinel
+#endif
     }
 
     // A walk set aside between two rounds and taken up again later, by any lane of any wavefront of the workgroup
