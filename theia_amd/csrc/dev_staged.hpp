@@ -411,11 +411,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         const bool pushA = dstA >= 0;
         uint32_t posA = 0, posB = 0;
         if (__ballot(pushA) != 0ull) {
-#ifdef THX_EXP_AGENT_RELEASE
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "agent");
-#else
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // stage data before the entries
-#endif
             if (pushA) posA = atomicAdd(&pool.ctr[cTail(dstA)], 1u);
             if (__ballot(hasB) != 0ull)
                 if (hasB) posB = atomicAdd(&pool.ctr[cTail(S_TS)], 1u);
@@ -545,11 +541,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             if (lane == 0) birthFirst = atomicAdd(&pool.ctr[C_CURSOR], n0);
             birthFirst = __builtin_amdgcn_readfirstlane(birthFirst);
         }
-#ifdef THX_EXP_AGENT_ACQUIRE
-        __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-#else
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
-#endif
 #ifdef THX_STAGE_PROFILE
         const unsigned long long profT0 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
