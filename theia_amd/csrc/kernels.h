@@ -7,7 +7,7 @@
 namespace thx {
 
 constexpr uint32_t kTraceBlock = 256;  // threads per tracing workgroup (4 wavefronts)
-constexpr uint32_t kTreeDepth = 32;    // depth bound of the binary trees the builder makes (TLAS + deepest BLAS + 2)
+constexpr uint32_t kTreeDepth = 48;    // depth bound of the binary trees the builder makes (TLAS + deepest BLAS + 2)
 #ifdef THX_BVH4
 constexpr uint32_t kStackDepth = 2 * kTreeDepth; // a 4-wide visit pushes up to three entries per level
 constexpr uint32_t kRecordSlots = 2;             // NodePair slots per record of the walk
