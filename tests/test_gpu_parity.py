@@ -345,6 +345,36 @@ def test_production_kernel_equals_instrumented(hip_backend, scene):
         assert np.abs(got - want).max() <= 2e-6 * want.sum(), (launch, np.abs(got - want).max() / want.sum())
 
 
+@pytest.mark.parametrize("config", ["config2", "config3", "config5"])
+def test_full_size_properties(hip_backend, config):
+    """BASELINE.json's scene configurations at their full 10^7 photons per launch, where the oracle cannot follow: properties
+    that do not depend on the size. (1) a launch repeated gives the same light curve (sums of the same hits in another
+    order: 1e-6 of the curve); (2) the curve is the sum of its shards: two half launches with `photonOffset`, normalised to
+    the full batch, add up to it -- the multi-GPU contract; (3) it agrees with a 50 times smaller launch of other photons
+    within that launch's statistical error; (4) no launch trips the device error word."""
+    n = 10_000_000
+    make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid}[config]
+    full = make(batch=n)
+    full.rng.autoAdvance = 0  # consecutive batches use the same photons then: the Philox offset stays where it is
+    first, again = [h.astype(np.float64) for h in S.run_batches(full, 2)]
+    assert first.sum() > 0 and np.isfinite(first).all()
+    assert np.abs(again - first).max() <= 1e-6 * first.sum()
+    halves = []
+    for k in range(2):
+        sc = make(batch=n // 2)
+        sc.rng.autoAdvance = 0
+        sc.response.normalization = 1.0 / n
+        sc.tracer.photonOffset = k * (n // 2)
+        halves.append(S.run_batches(sc, 1)[0].astype(np.float64))
+        hip_backend.tracer_check(sc.tracer.program.handle)
+    assert np.abs(halves[0] + halves[1] - first).max() <= 1e-5 * first.sum()
+    small = make(batch=n // 50, key=7)
+    probe = S.run_batches(small, 1)[0].astype(np.float64)
+    # the total of n / 50 photons scatters by a few per cent of itself (contributions are heavy tailed): 15 % is > 5 sigma
+    assert abs(probe.sum() - first.sum()) <= 0.15 * first.sum()
+    hip_backend.tracer_check(full.tracer.program.handle)
+
+
 def test_sharding_is_seed_identical(hip_backend):
     """two half batches with photonOffset reproduce the full batch (multi-GPU contract)"""
     n = 40000
