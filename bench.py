@@ -56,8 +56,8 @@ WORKLOADS = {
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=5)
-    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=5)  # a fresh GPU needs a few launches before its clocks settle
     ap.add_argument("--batch", type=int, default=10_000_000, help="photons per GPU per step")
     ap.add_argument("--workload", default="config2", choices=list(WORKLOADS))
     ap.add_argument("--polarized", type=int, default=-1, help="override the workload's polarization (0/1)")
