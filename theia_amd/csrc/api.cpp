@@ -255,6 +255,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     UP(built.pairs, nodes, NodePair)
     UP(built.frames, frames, TreeFrame)
     UP(built.tris, tris, TriRecord)
+    UP(built.normals, normals, NormalRecord)
     UP(built.instances, instances, InstanceRecord)
     UP(built.walkInstances, walkInstances, WalkInstance)
 #undef UP
@@ -287,7 +288,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     s->info.max_depth = built.maxDepth;
     s->info.bytes_nodes = built.pairs.size() * sizeof(NodePair) + built.frames.size() * sizeof(TreeFrame);
     s->nPairs = (uint32_t)built.pairs.size();
-    s->info.bytes_triangles = built.tris.size() * sizeof(TriRecord);
+    s->info.bytes_triangles = built.tris.size() * (sizeof(TriRecord) + sizeof(NormalRecord));
     s->info.bytes_instances = built.instances.size() * sizeof(InstanceRecord);
     uint64_t total = s->info.bytes_nodes + s->info.bytes_triangles + s->info.bytes_instances +
                      built.walkInstances.size() * sizeof(WalkInstance) + geo.size() * sizeof(GeometryGLSL);
@@ -295,12 +296,12 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
         total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
     s->info.bytes_total = total;
     // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_trace.hpp: Walker,
-    // processRayQuery): half a NodePair per child box; a TriRecord; a WalkInstance (80) per instance entry; index triple (12) + three vertices (72) + Geometry (24) +
+    // processRayQuery): half a NodePair per child box; a TriRecord; a WalkInstance (80) per instance entry; the triangle's TriRecord (48) + NormalRecord (48) + Geometry (24) +
     // Material (24) + the instance record (112) per reconstructed hit
     s->info.layout_box_bytes = sizeof(NodePair) / 2;
     s->info.layout_triangle_bytes = sizeof(TriRecord);
     s->info.layout_instance_bytes = sizeof(WalkInstance);
-    s->info.layout_hit_bytes = 12 + 72 + sizeof(GeometryGLSL) + sizeof(MaterialGLSL) + sizeof(InstanceRecord);
+    s->info.layout_hit_bytes = sizeof(TriRecord) + sizeof(NormalRecord) + sizeof(GeometryGLSL) + sizeof(MaterialGLSL) + sizeof(InstanceRecord);
     *out = s;
     return THX_OK;
 }

@@ -379,6 +379,12 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
             std::memcpy(tr.v2, md.vertices + 6 * (size_t)ix[2], 12);
             tr.prim = p.id;
             out.tris.push_back(tr);
+            NormalRecord nr;
+            std::memset(&nr, 0, sizeof(nr));
+            std::memcpy(nr.n0, md.vertices + 6 * (size_t)ix[0] + 3, 12);
+            std::memcpy(nr.n1, md.vertices + 6 * (size_t)ix[1] + 3, 12);
+            std::memcpy(nr.n2, md.vertices + 6 * (size_t)ix[2] + 3, 12);
+            out.normals.push_back(nr);
         }
     }
 

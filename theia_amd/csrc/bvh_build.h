@@ -16,6 +16,7 @@ struct BuiltScene {
     std::vector<NodePair> pairs;        // what the device walks: one record per inner node
     std::vector<TreeFrame> frames;      // quantisation frame + root ref per tree: [TLAS, BLAS 0, BLAS 1, ...]
     std::vector<TriRecord> tris;        // leaf order, all meshes
+    std::vector<NormalRecord> normals;  // vertex normals of the same triangles
     std::vector<InstanceRecord> instances;
     std::vector<uint32_t> tlasInstance; // TLAS leaf slot -> instance id (host only: the leaf refs of `pairs` hold the ids)
     std::vector<WalkInstance> walkInstances; // by instance id

@@ -924,7 +924,7 @@ THX_DEV bool volPhotonStep(Lane<V>& L, Ray& ray, uint32_t& step) {
 struct QueryHit {
     bool valid;
     bool aborted = false; // the traversal stack overflowed: the result is not the closest hit (ERROR_CODE_TRACE_ABORT)
-    uint32_t instance, prim;
+    uint32_t instance, prim; // prim = index of the triangle's record (leaf order), not its index in the mesh
     float t, b1, b2; // b1, b2 = barycentric weights of v1, v2
 #ifdef THX_STAGE_PROFILE
     uint32_t trips = 0; // inner-node trips of this lane's own ray
@@ -1416,10 +1416,10 @@ struct Walker {
                 if (two) { a1 = tr[3 * i0 + 3]; b1 = tr[3 * i0 + 4]; c1 = tr[3 * i0 + 5]; }
                 L.cnt.add(ST_TRIS, two ? 2u : 1u);
                 if (woopTri(w, ao, f3{a0.x, a0.y, a0.z}, f3{b0.x, b0.y, b0.z}, f3{c0.x, c0.y, c0.z}, h.t, h.b1, h.b2)) {
-                    h.valid = true; h.instance = curInst; h.prim = __float_as_uint(a0.w);
+                    h.valid = true; h.instance = curInst; h.prim = first + i0;
                 }
                 if (two && woopTri(w, ao, f3{a1.x, a1.y, a1.z}, f3{b1.x, b1.y, b1.z}, f3{c1.x, c1.y, c1.z}, h.t, h.b1, h.b2)) {
-                    h.valid = true; h.instance = curInst; h.prim = __float_as_uint(a1.w);
+                    h.valid = true; h.instance = curInst; h.prim = first + i0 + 1u;
                 }
             }
             cur = pop();
@@ -1488,16 +1488,16 @@ THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const Que
     hit.objPos = f3{0, 0, 0}; hit.objNrm = f3{0, 0, 0};
     hit.worldToObj = m3{f3{0, 0, 0}, f3{0, 0, 0}, f3{0, 0, 0}};
     if (!hit.valid) return RESULT_CODE_RAY_MISSED;
+    // everything is addressed by the hit itself: the instance record, its Geometry (geometry k belongs to instance k),
+    // and the triangle's vertex positions and normals in leaf order (the same floats the vertex buffer holds)
     const InstanceRecord* inst = sc.instances + q.instance;
-    const GeometryGLSL geom = sc.geometries[inst->geometry];
+    const GeometryGLSL geom = sc.geometries[q.instance];
     hit.customId = inst->customIndex;
-    const THX_GLOBAL uint32_t* ix = reinterpret_cast<const THX_GLOBAL uint32_t*>(geom.indices) + 3 * (size_t)q.prim;
-    const THX_GLOBAL float* vb = reinterpret_cast<const THX_GLOBAL float*>(geom.vertices);
-    const THX_GLOBAL float* a = vb + 6 * (size_t)ix[0];
-    const THX_GLOBAL float* b = vb + 6 * (size_t)ix[1];
-    const THX_GLOBAL float* c = vb + 6 * (size_t)ix[2];
-    f3 p0 = ld3(a), p1 = ld3(b), p2 = ld3(c);
-    f3 n0 = ld3(a + 3), n1v = ld3(b + 3), n2v = ld3(c + 3);
+    const float4* tv = reinterpret_cast<const float4*>(sc.tris + q.prim);
+    const float4* tn = reinterpret_cast<const float4*>(sc.normals + q.prim);
+    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2], m0 = tn[0], m1 = tn[1], m2 = tn[2];
+    f3 p0 = f3{v0.x, v0.y, v0.z}, p1 = f3{v1.x, v1.y, v1.z}, p2 = f3{v2.x, v2.y, v2.z};
+    f3 n0 = f3{m0.x, m0.y, m0.z}, n1v = f3{m1.x, m1.y, m1.z}, n2v = f3{m2.x, m2.y, m2.z};
     float bx = q.b1, by = q.b2;
     f3 e1 = p1 - p0, e2 = p2 - p0;
     f3 objPos = f3{p0.x + __fmaf_rn(bx, e1.x, by * e2.x), p0.y + __fmaf_rn(bx, e1.y, by * e2.y),

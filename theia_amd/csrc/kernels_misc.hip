@@ -387,7 +387,7 @@ __global__ void __launch_bounds__(kTraceBlock) queryKernel(LaunchArgs args, cons
     float* o = out6 + 6 * (size_t)i;
     o[0] = h.valid ? 1.0f : 0.0f;
     o[1] = (float)h.instance;
-    o[2] = (float)h.prim;
+    o[2] = (float)(h.valid ? args.scene.tris[h.prim].prim : 0u); // the triangle's index in its mesh
     o[3] = h.t;
     o[4] = h.b1;
     o[5] = h.b2;
@@ -418,7 +418,7 @@ __global__ void __launch_bounds__(kTraceBlock) queryKernelPersistent(LaunchArgs 
             const uint32_t cand = next + rank;
             if (idle && mine != 0xFFFFFFFFu) {
                 float* o = out6 + 6 * (size_t)mine;
-                o[0] = wk.h.valid ? 1.0f : 0.0f; o[1] = (float)wk.h.instance; o[2] = (float)wk.h.prim;
+                o[0] = wk.h.valid ? 1.0f : 0.0f; o[1] = (float)wk.h.instance; o[2] = (float)(wk.h.valid ? args.scene.tris[wk.h.prim].prim : 0u);
                 o[3] = wk.h.t; o[4] = wk.h.b1; o[5] = wk.h.b2;
                 mine = 0xFFFFFFFFu;
             }
@@ -440,7 +440,7 @@ __global__ void __launch_bounds__(kTraceBlock) queryKernelPersistent(LaunchArgs 
     }
     if (mine != 0xFFFFFFFFu) {
         float* o = out6 + 6 * (size_t)mine;
-        o[0] = wk.h.valid ? 1.0f : 0.0f; o[1] = (float)wk.h.instance; o[2] = (float)wk.h.prim;
+        o[0] = wk.h.valid ? 1.0f : 0.0f; o[1] = (float)wk.h.instance; o[2] = (float)(wk.h.valid ? args.scene.tris[wk.h.prim].prim : 0u);
         o[3] = wk.h.t; o[4] = wk.h.b1; o[5] = wk.h.b2;
     }
 }

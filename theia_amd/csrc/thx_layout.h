@@ -52,6 +52,15 @@ struct alignas(16) TriRecord {
 };
 static_assert(sizeof(TriRecord) == 48, "triangle record must be 48 B");
 
+// Vertex normals of a triangle in BVH leaf order, 48 B, next to its TriRecord: with them a hit is reconstructed from
+// two records addressed by the hit itself, not through geometry -> index triple -> three vertices (three dependent loads).
+struct alignas(16) NormalRecord {
+    float n0[3]; uint32_t pad0;
+    float n1[3]; uint32_t pad1;
+    float n2[3]; uint32_t pad2;
+};
+static_assert(sizeof(NormalRecord) == 48, "normal record must be 48 B");
+
 // Instance record, 112 B = seven 16-B loads. Matrices are row-major 3x4.
 struct alignas(16) InstanceRecord {
     float w2o[12];
@@ -100,6 +109,7 @@ static_assert(sizeof(GeometryGLSL) == 24, "Geometry is 24 B");
 struct SceneView {
     const NodePair* nodes; // pair records of all trees
     const TriRecord* tris;
+    const NormalRecord* normals; // by triangle record
     const InstanceRecord* instances;
     const WalkInstance* walkInstances; // by instance id (the TLAS leaves hold instance ids)
     const GeometryGLSL* geometries;
