@@ -455,6 +455,10 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         if (pick == (uint32_t)S_T0) {
             qa = S_T0; ha = rl(hvx, S_T0); n0 = min(cT0, 64u);
             hb = rl(hvx, S_TS); n1 = min(cTS, 64u - n0);
+            // A ring that fills the wavefront by itself gives a batch of one kind of ray: what follows the walk differs for
+            // primary and shadow rays, and a mixed batch runs both (config 2 / 5 -3 %; smaller thresholds than a full
+            // wavefront, or never mixing, are slower: profiles/r02_park.txt).
+            if (cTS >= 64u) { n1 = 64u; n0 = 0u; }
         } else if (pick < (uint32_t)S_NUM) {
             qa = pick; ha = rl(hvx, pick); n0 = min(best, 64u);
         }
