@@ -609,7 +609,8 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stack_wave_words = t->stackLds * (t->stack16 ? 32u : 64u);
     a.spill = t->spill;
     a.park = t->park;
-    a.park_below = t->stackDepth > kParkDeepFrom ? kParkBelowDeep : kParkBelow;
+    a.park_below = t->scene && t->scene->info.n_instances > kParkInstancedFrom ? kParkBelowInstanced
+                   : (t->stackDepth > kParkDeepFrom ? kParkBelowDeep : kParkBelow);
     a.park_rounds = kParkRounds;
     if (const char* env = std::getenv("THX_PARK_BELOW")) a.park_below = (uint32_t)std::min(65, std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("THX_PARK_ROUNDS")) a.park_rounds = (uint32_t)std::max(1, std::atoi(env));

@@ -19,7 +19,9 @@ constexpr uint32_t kStackLds16 = 16;   // staged kernel: entries of them kept in
 // staged kernel: a walk batch sets its last rays aside once fewer lanes than kParkBelow still walk (kParkBelowDeep for
 // hierarchies deeper than kParkDeepFrom, whose walks are long and spread more) after at least kParkRounds rounds
 // (dev_staged.hpp: walkBatch; measured: profiles/r02_park.txt)
+// scenes of many instances spread their walks most (every instance visit is a detour of its own): kParkBelowInstanced
 constexpr uint32_t kParkBelow = 10, kParkBelowDeep = 16, kParkDeepFrom = 16, kParkRounds = 2;
+constexpr uint32_t kParkBelowInstanced = 24, kParkInstancedFrom = 16;
 constexpr uint32_t kStackLds32 = 10;   // measured on MI355X (profiles/r02_stack_spill.txt): 81 920 triangles 7.27 -> 6.06 ms, 5.2 M triangles 13.2 -> 10.9 ms
 
 // dynamic LDS bytes of a tracing workgroup (lane kernel)
