@@ -1047,6 +1047,26 @@ THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origi
 #endif
     return r;
 }
+// a 16-bit half of a word as float: one SDWA conversion (the build runs without the compiler's own SDWA folding, see the
+// Makefile; these two, on values that are nothing but loaded words run through v_perm_b32, are written out)
+THX_DEV float u16lo(uint32_t w) {
+#ifdef THX_NO_SDWA_ASM
+    return (float)(w & 0xFFFFu);
+#else
+    float f;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(w));
+    return f;
+#endif
+}
+THX_DEV float u16hi(uint32_t w) {
+#ifdef THX_NO_SDWA_ASM
+    return (float)(w >> 16);
+#else
+    float f;
+    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(w));
+    return f;
+#endif
+}
 // one child of a pair record: c.x = lo.x | lo.y << 16, c.y = hi.x | hi.y << 16, c.z = lo.z | hi.z << 16
 THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
@@ -1055,9 +1075,9 @@ THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     // both distances and taking min / max: t = q a + b is monotonic in q, so the values are the same ones.
     const uint32_t nxy = __builtin_amdgcn_perm(wh, wl, r.sxy), fxy = __builtin_amdgcn_perm(wl, wh, r.sxy);
     const uint32_t nfz = __builtin_amdgcn_perm(wz, wz, r.sz);
-    const v2f tn_xy = __builtin_elementwise_fma(v2f{(float)(nxy & 0xFFFFu), (float)(nxy >> 16)}, r.a_xy, r.b_xy);
-    const v2f tf_xy = __builtin_elementwise_fma(v2f{(float)(fxy & 0xFFFFu), (float)(fxy >> 16)}, r.a_xy, r.b_xy);
-    const float tn_z = __builtin_fmaf((float)(nfz & 0xFFFFu), r.a_z, r.b_z), tf_z = __builtin_fmaf((float)(nfz >> 16), r.a_z, r.b_z);
+    const v2f tn_xy = __builtin_elementwise_fma(v2f{u16lo(nxy), u16hi(nxy)}, r.a_xy, r.b_xy);
+    const v2f tf_xy = __builtin_elementwise_fma(v2f{u16lo(fxy), u16hi(fxy)}, r.a_xy, r.b_xy);
+    const float tn_z = __builtin_fmaf(u16lo(nfz), r.a_z, r.b_z), tf_z = __builtin_fmaf(u16hi(nfz), r.a_z, r.b_z);
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
     const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
     return tn <= tf * 1.0000004f ? tn : -1.0f;
