@@ -68,7 +68,6 @@ struct thx_tracer {
     uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_trace.hpp: Walker::save)
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
-    uint32_t ldsNodes = 0;        // staged kernel: BVH nodes staged in LDS (0 = walk reads HBM/L2)
     uint32_t block = kTraceBlock;
     size_t lds = 0;
     uint32_t gridMax = 1;
@@ -416,36 +415,26 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
         if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
         const uint32_t stackBytes = t->stackLds * (t->stack16 ? 2u : 4u);
-        // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %,
-        // nodes gathered from LDS instead of the vector cache 4.5 %. So the node array is
-        // staged in LDS only when that costs no pool slot (THX_LDS_NODES=<max nodes> forces it).
+        // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %.
         // Deep scenes (large per-thread stacks) leave a pool much smaller than the workgroup:
         // batches run half empty then. Fewer wavefronts with fuller batches win while the pool
-        // holds less than 3/4 photon per thread (config 5: 1024 -> 768 threads, +9 %).
-        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0);
+        // holds less than 3/4 photon per thread.
+        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block);
         if (!std::getenv("THX_THREADS"))
             while (t->block > 512 && 4u * t->pool < 3u * t->block) {
                 t->block -= 128;
-                t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0);
+                t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block);
             }
-        t->ldsNodes = 0;
-        const uint32_t withNodes = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, scene->nPairs);
-        bool stage = withNodes == t->pool;
-        if (const char* env = std::getenv("THX_LDS_NODES")) stage = scene->nPairs <= (uint32_t)std::max(0, std::atoi(env));
-        if (stage) {
-            t->ldsNodes = scene->nPairs;
-            t->pool = withNodes;
-            t->mode |= 4u;
-        }
+        if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(2048, std::max(64, std::atoi(env)));
-        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodes);
+        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block);
     } else {
         t->stackLds = t->stackDepth;
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
     }
     if (std::getenv("THX_VERBOSE"))
-        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u (LDS %u) stack16=%d ldsNodes=%u\n",
-                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, t->stackLds, (int)t->stack16, t->ldsNodes);
+        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u (LDS %u) stack16=%d\n",
+                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, t->stackLds, (int)t->stack16);
     // replay streams its queue once: a few workgroups per CU hide the load latency
     int perCU = replay ? 8 : t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
@@ -617,8 +606,6 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stack16 = t->stack16 ? 1u : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;
-    a.lds_nodes_count = t->ldsNodes;
-    a.lds_nodes_word = (t->desc.n_bins + 3u) & ~3u;
     a.slabs = t->slabs[cfg];
     a.cold = t->cold;
     a.stats = t->stats;

@@ -86,16 +86,16 @@ struct StagedLayout {
         while (c < pool) c <<= 1;
         return c;
     }
-    // dynamic LDS: [hist][nodes][state+scratch (NCH+NSC)*P float4][stack depth*T]
+    // dynamic LDS: [hist][state+scratch (NCH+NSC)*P float4][stack depth*T]
     //              [rings: 6 x qcap u16, TS ring 2 qcap u16][counters]
-    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, uint32_t ldsNodes = 0) {
+    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads) {
         size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
-        return hist + (size_t)ldsNodes * 32 + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool) * 2 + C_NUM * 4;
+        return hist + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool) * 2 + C_NUM * 4;
     }
     // largest pool (multiple of 16, <= 1024) that fits `budget` bytes of LDS
-    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes = 0) {
+    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads) {
         uint32_t p = THX_POOL_MAX;
-        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, ldsNodes) > budget) p -= 16;
+        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads) > budget) p -= 16;
         return p;
     }
     // bytes of global memory one workgroup needs for its cold chunks
@@ -337,16 +337,10 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const uint32_t histWords = (n_bins + 3u) & ~3u;
     Pool<V> pool;
     pool.P = P;
-    const uint32_t nodeWords = V::LDSBVH ? args.lds_nodes_count * 8u : 0u; // == args.lds_nodes_word - histWords
-    pool.st = reinterpret_cast<float4*>(ldsWords() + histWords + nodeWords);
+    pool.st = reinterpret_cast<float4*>(ldsWords() + histWords);
     pool.sc = pool.st + Lay::NCH * P;
     pool.cold = (THX_GLOBAL typename Pool<V>::vec4*)(args.cold) + (size_t)blockIdx.x * Lay::NCOLD * P;
-    const uint32_t stackWord0 = histWords + nodeWords + (Lay::NCH + Lay::NSC) * P * 4;
-    if constexpr (V::LDSBVH) { // stage the node array (TLAS + every BLAS) into LDS, 16 B per lane
-        const float4* src = reinterpret_cast<const float4*>(args.scene.nodes);
-        float4* dst = reinterpret_cast<float4*>(ldsWords() + args.lds_nodes_word);
-        for (uint32_t i = tid; i < args.lds_nodes_count * 2u; i += T) dst[i] = src[i];
-    }
+    const uint32_t stackWord0 = histWords + (Lay::NCH + Lay::NSC) * P * 4;
     pool.q = reinterpret_cast<uint16_t*>(ldsWords() + stackWord0 + args.stack_wave_words * (T >> 6));
     pool.cap = Lay::qcap(P);
     pool.capShift = 31u - (uint32_t)__builtin_clz(pool.cap);

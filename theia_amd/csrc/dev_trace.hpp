@@ -8,13 +8,14 @@ namespace thx {
 
 // compile-time specialisation of one kernel variant (the reference specialises
 // through GLSL macros, trace.py:660-666 / :1226-1235)
-template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, bool LDSBVH_ = false>
+template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, bool S16_ = false>
 struct Variant {
     static constexpr bool POL = POL_;       // POLARIZATION
     static constexpr bool MIS = MIS_;       // !DISABLE_MIS
     static constexpr bool STATS = STATS_;   // EventStatisticCallback + traversal counters
     static constexpr bool TRACK = TRACK_;   // per-event dump
-    static constexpr bool LDSBVH = LDSBVH_; // BVH nodes staged in LDS (small scenes)
+    static constexpr bool S16 = S16_;       // the traversal stack holds 16-bit entries (scenes below 8 190 nodes / triangles / instances):
+                                            // known at compile time, push / pop lose a wave-uniform branch (-1 %); false: decided at run time
 };
 
 // ray.glsl:22-36 (+163-170 polarized part)
@@ -41,8 +42,6 @@ struct LaunchArgs {
     uint32_t stack16;          // 1: stack entries are 16 bit (scene has < 8190 nodes/triangles)
     uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active
     uint32_t pool;             // staged kernel: photons held in LDS per workgroup
-    uint32_t lds_nodes_word;   // LDSBVH variants: LDS word offset of the staged node array
-    uint32_t lds_nodes_count;  // LDSBVH variants: number of nodes staged
     float* slabs;              // [gridDim.x][n_bins] partial histograms
     uint32_t* spill;           // [waves of the grid][stack_depth - stack_lds][64] deep stack entries, or null
     uint32_t park_below;       // staged kernel: a walk batch sets its last rays aside once fewer than this many lanes walk (0: never)
@@ -1113,13 +1112,12 @@ THX_DEV float4 tlasFrame1(const SceneView& sc) { return make_float4(sc.tlas.step
 constexpr uint32_t WALK_DONE = 0xFFFFFFFFu;     // low bits 7
 constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current instance
 
-// Node array of the walk: HBM/L2 (default) or the copy staged in LDS. A divergent
-// 16-B gather costs the L1 one cycle per lane and instruction (measured: ~250 cycles
-// per wave and node pair), an LDS gather about a tenth of that.
+// Node array of the walk. (Round 1 could stage it in LDS -- a divergent 16-B gather costs the L1 one cycle per lane and
+// instruction, an LDS gather about a tenth of that -- but only where that cost no pool slot, which the BASELINE scenes never
+// offered: measured -1.4 % / +1.8 % on configs 2 / 3 with the pool it takes. Removed in round 2.)
 template <class V>
 THX_DEV const float4* walkNodes(const Lane<V>& L) {
-    if constexpr (V::LDSBVH) return reinterpret_cast<const float4*>(ldsWords() + L.a->lds_nodes_word);
-    else return reinterpret_cast<const float4*>(L.a->scene.nodes);
+    return reinterpret_cast<const float4*>(L.a->scene.nodes);
 }
 
 // Closest-hit query: opaque, no culling, 0 < t < tmax, committed closest triangle
@@ -1167,7 +1165,7 @@ struct Walker {
         // 16-bit entries when the scene is small enough (halves the LDS footprint).
         // (Storing entry distances for pop-time culling was measured slower: -10 % node
         // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
-        s16 = L.a->stack16 != 0u;
+        s16 = V::S16 || L.a->stack16 != 0u;
         stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
 #ifdef THX_STACK16_LINEAR // the first layout: lanes 2k and 2k+1 share an LDS bank (profiles/r02_lds_conflicts.txt)
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);

@@ -31,8 +31,8 @@ inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block, uint
     return hist + stack;
 }
 // dynamic LDS bytes of the staged scene kernel (dev_staged.hpp: StagedLayout)
-size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, uint32_t ldsNodes);
-uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, uint32_t ldsNodes);
+size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads);
+uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads);
 // global memory (bytes) of one workgroup's cold photon state (dev_staged.hpp: StagedLayout::coldBytes)
 size_t stagedColdBytes(bool polarized, uint32_t pool);
 constexpr uint32_t kStagedBlock = 1024;

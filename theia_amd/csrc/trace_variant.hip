@@ -102,8 +102,8 @@ __global__ void __launch_bounds__(kTraceBlock, THX_WAVES_PER_SIMD) traceKernel(c
 
 using Plain = Variant<THX_POL != 0, THX_MIS != 0, false, false>;
 using Debug = Variant<THX_POL != 0, THX_MIS != 0, true, true>;
-using PlainL = Variant<THX_POL != 0, THX_MIS != 0, false, false, true>; // BVH nodes staged in LDS
-using DebugL = Variant<THX_POL != 0, THX_MIS != 0, true, true, true>;
+using PlainS = Variant<THX_POL != 0, THX_MIS != 0, false, false, true>; // 16-bit stack entries known at compile time
+using DebugS = Variant<THX_POL != 0, THX_MIS != 0, true, true, true>;
 
 #if THX_KIND == 1
 // staged (regrouped-in-LDS) form of the scene tracer, see dev_staged.hpp
@@ -118,7 +118,7 @@ __global__ void __launch_bounds__(kSchedThreads) sceneStagedKernel(const LaunchA
 #define THX_FN(prefix) THX_CAT(prefix, THX_KIND, THX_POL, THX_MIS)
 
 // mode: bit 0 = instrumented (statistics + track), bit 1 = staged kernel (scene only),
-// bit 2 = BVH nodes staged in LDS (staged kernel only)
+// bit 2 = 16-bit traversal stack entries (staged kernel only: a variant of its own)
 hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t grid, uint32_t block,
                                 size_t lds, hipStream_t stream) {
     const bool debug = mode & 1u;
@@ -126,7 +126,7 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
     if (mode & 2u) {
         // > 64 KB of dynamic LDS needs an explicit opt-in (once per kernel)
         const void* fn[4] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
-                             reinterpret_cast<const void*>(sceneStagedKernel<PlainL>), reinterpret_cast<const void*>(sceneStagedKernel<DebugL>)};
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainS>), reinterpret_cast<const void*>(sceneStagedKernel<DebugS>)};
         static bool optedIn[4] = {false, false, false, false};
         const uint32_t k = (debug ? 1u : 0u) | ((mode & 4u) ? 2u : 0u);
         if (!optedIn[k]) {
@@ -137,8 +137,8 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
         switch (k) {
         case 0: hipLaunchKernelGGL((sceneStagedKernel<Plain>), dim3(grid), dim3(block), lds, stream, args); break;
         case 1: hipLaunchKernelGGL((sceneStagedKernel<Debug>), dim3(grid), dim3(block), lds, stream, args); break;
-        case 2: hipLaunchKernelGGL((sceneStagedKernel<PlainL>), dim3(grid), dim3(block), lds, stream, args); break;
-        default: hipLaunchKernelGGL((sceneStagedKernel<DebugL>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 2: hipLaunchKernelGGL((sceneStagedKernel<PlainS>), dim3(grid), dim3(block), lds, stream, args); break;
+        default: hipLaunchKernelGGL((sceneStagedKernel<DebugS>), dim3(grid), dim3(block), lds, stream, args); break;
         }
         return hipGetLastError();
     }
@@ -160,8 +160,8 @@ int THX_FN(traceOccupancy_)(uint32_t mode, uint32_t block, size_t lds) {
         switch (k) {
         case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<Plain>, (int)block, lds); break;
         case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<Debug>, (int)block, lds); break;
-        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainL>, (int)block, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugL>, (int)block, lds); break;
+        case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainS>, (int)block, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugS>, (int)block, lds); break;
         }
         return e == hipSuccess ? n : -1;
     }
