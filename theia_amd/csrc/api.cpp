@@ -425,7 +425,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
                 t->block -= 128;
                 t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block);
             }
-        if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in
+        if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in ...
+        if (t->stack16 && t->stackLds == t->stackDepth) t->mode |= 8u; // ... and with the whole stack in LDS
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(2048, std::max(64, std::atoi(env)));
         t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block);
     } else {

@@ -8,14 +8,18 @@ namespace thx {
 
 // compile-time specialisation of one kernel variant (the reference specialises
 // through GLSL macros, trace.py:660-666 / :1226-1235)
-template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, bool S16_ = false>
+template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, int STACK_ = 0>
 struct Variant {
     static constexpr bool POL = POL_;       // POLARIZATION
     static constexpr bool MIS = MIS_;       // !DISABLE_MIS
     static constexpr bool STATS = STATS_;   // EventStatisticCallback + traversal counters
     static constexpr bool TRACK = TRACK_;   // per-event dump
-    static constexpr bool S16 = S16_;       // the traversal stack holds 16-bit entries (scenes below 8 190 nodes / triangles / instances):
-                                            // known at compile time, push / pop lose a wave-uniform branch (-1 %); false: decided at run time
+    // What is known about the traversal stack at compile time. 0: nothing (entry width and the split between LDS and global
+    // memory are decided at run time); 1: 16-bit entries (scenes below 8 190 nodes / triangles / instances); 2: 16-bit
+    // entries and the whole stack in LDS (such scenes no deeper than the LDS share). Every push and pop loses a
+    // wave-uniform branch with 1 and a lane-divergent one with 2: -1 % and -2 %.
+    static constexpr bool S16 = STACK_ != 0;
+    static constexpr bool SPILL = STACK_ != 2;
 };
 
 // ray.glsl:22-36 (+163-170 polarized part)
@@ -1183,7 +1187,7 @@ struct Walker {
     // ERROR_CODE_TRACE_ABORT, counted like every other device error (callback.stat.glsl:66-69).
     THX_DEV void push(uint32_t v) {
         if (sp >= depth) { overflow = true; return; }
-        if (sp >= ldsN) spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)] = v;
+        if (V::SPILL && sp >= ldsN) spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)] = v;
         else if (s16) stack16[sp * 64] = (uint16_t)v;
         else stack32[sp * 64] = v;
         ++sp;
@@ -1191,7 +1195,7 @@ struct Walker {
     THX_DEV uint32_t pop() {
         if (sp == 0) return WALK_DONE;
         --sp;
-        if (sp >= ldsN) return spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)];
+        if (V::SPILL && sp >= ldsN) return spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)];
         if (s16) {
             uint32_t v = stack16[sp * 64];
             return v == 0xFFFEu ? WALK_SENTINEL : v;
