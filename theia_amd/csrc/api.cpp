@@ -68,6 +68,8 @@ struct thx_tracer {
     uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_trace.hpp: Walker::save)
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
+    size_t ldsNodeBytes = 0;      // staged kernel: LDS copy of the scene's pair records (0: the walk reads them through the vector cache)
+    size_t ldsNodeOffset = 0;     // ... and its byte offset in the workgroup's LDS
     uint32_t block = kTraceBlock;
     size_t lds = 0;
     uint32_t gridMax = 1;
@@ -425,17 +427,33 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
                 t->block -= 128;
                 t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block);
             }
+        t->pool = std::min(t->pool, kPoolBest);
         if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in ...
         if (t->stack16 && t->stackLds == t->stackDepth) t->mode |= 8u; // ... and with the whole stack in LDS
+        // Small scenes: the walk reads its pair records from a copy in LDS if that leaves a pool of kLdsNodeMinPool photons
+        // (THX_LDS_NODES=0 / 1: never / whenever it fits at all)
+        if ((t->mode & 8u) && t->block == kStagedBlock) {
+            const size_t nodeBytes = (size_t)scene->nPairs * sizeof(NodePair);
+            const uint32_t poolN = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, nodeBytes);
+            bool use = nodeBytes <= kLdsNodeMaxBytes && poolN >= kLdsNodeMinPool;
+            if (const char* env = std::getenv("THX_LDS_NODES")) use = std::atoi(env) != 0 && nodeBytes + 32 * 1024 <= budget && poolN >= 128;
+            if (use) {
+                t->mode |= 16u;
+                t->pool = poolN;
+                t->ldsNodeBytes = nodeBytes;
+            }
+        }
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(2048, std::max(64, std::atoi(env)));
-        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block);
+        t->ldsNodeOffset = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block);
+        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodeBytes);
+        if (t->lds > budget + 2048) { delete t; return fail(THX_ERR_INVALID, "THX_POOL does not fit the LDS of a compute unit"); }
     } else {
         t->stackLds = t->stackDepth;
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
     }
     if (std::getenv("THX_VERBOSE"))
-        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u (LDS %u) stack16=%d\n",
-                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, t->stackLds, (int)t->stack16);
+        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u (LDS %u) stack16=%d ldsNodes=%zu B\n",
+                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, t->stackLds, (int)t->stack16, t->ldsNodeBytes);
     // replay streams its queue once: a few workgroups per CU hide the load latency
     int perCU = replay ? 8 : t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
@@ -605,6 +623,8 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     if (const char* env = std::getenv("THX_PARK_BELOW")) a.park_below = (uint32_t)std::min(65, std::max(0, std::atoi(env)));
     if (const char* env = std::getenv("THX_PARK_ROUNDS")) a.park_rounds = (uint32_t)std::max(1, std::atoi(env));
     a.stack16 = t->stack16 ? 1u : 0u;
+    a.lds_node_word = (uint32_t)(t->ldsNodeOffset / 4);
+    a.lds_node_pairs = t->ldsNodeBytes ? t->scene->nPairs : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;
     a.slabs = t->slabs[cfg];

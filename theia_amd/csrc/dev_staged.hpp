@@ -76,10 +76,20 @@ struct StagedLayout {
     // workgroup, 32 / 64 B per photon: L2 resident): 112 / 144 -> 80 B of LDS per photon. Photons in flight per CU are
     // what the throughput follows: pool 800 -> 1232 on config 3, 704 -> 1024 (and 12 -> 16 wavefronts) on
     // config 5, 1024 -> 1264 on config 2; measured -12 % / -15 % / -3 % kernel time.
+    // Round 3: of the two scratch chunks (sampled distances of a primary ray / direction + weight of the two MIS shadow
+    // rays) the second shadow ray's went the same way: the MIS stage writes it, the one walk batch that takes the ray up
+    // reads it once before it starts. 64 B of LDS per photon; what that frees holds the walk's pair records on small
+    // scenes (Variant::LDSN) and a larger pool on the others (profiles/r03_lds_nodes.txt).
     static constexpr uint32_t NHOT = 3u;
+#ifdef THX_SHADOW2_LDS // the round-2 layout (A/B builds)
     static constexpr uint32_t NCOLD = POL ? 4u : 2u;
-    static constexpr uint32_t NCH = NHOT; // state chunks per photon in LDS
     static constexpr uint32_t NSC = 2u;                                 // scratch chunks per photon
+#else
+    static constexpr uint32_t NCOLD = POL ? 5u : 3u;                    // the last one: direction + weight of the second shadow ray
+    static constexpr uint32_t NSC = 1u;                                 // scratch chunks per photon in LDS
+#endif
+    static constexpr uint32_t C_SHADOW2 = NCOLD - 1u;
+    static constexpr uint32_t NCH = NHOT; // state chunks per photon in LDS
     // ring capacity of a queue: power of two >= pool (the TS ring takes two of them)
     static constexpr uint32_t qcap(uint32_t pool) {
         uint32_t c = 64;
@@ -88,14 +98,19 @@ struct StagedLayout {
     }
     // dynamic LDS: [hist][state+scratch (NCH+NSC)*P float4][stack depth*T]
     //              [rings: 6 x qcap u16, TS ring 2 qcap u16][counters]
-    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads) {
+    //              [Variant::LDSN: copy of the scene's pair records]
+    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes = 0) {
+        return nodeOffset(n_bins, stackBytesPerThread, pool, threads) + nodeBytes;
+    }
+    // byte offset of the node copy = everything in front of it (a multiple of 16: pools are multiples of 16 photons)
+    static size_t nodeOffset(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads) {
         size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
         return hist + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool) * 2 + C_NUM * 4;
     }
-    // largest pool (multiple of 16, <= 1024) that fits `budget` bytes of LDS
-    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads) {
+    // largest pool (multiple of 16, <= THX_POOL_MAX) that fits `budget` bytes of LDS
+    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes = 0) {
         uint32_t p = THX_POOL_MAX;
-        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads) > budget) p -= 16;
+        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, nodeBytes) > budget) p -= 16;
         return p;
     }
     // bytes of global memory one workgroup needs for its cold chunks
@@ -110,7 +125,7 @@ struct Pool {
     uint16_t* q;      // rings
     uint32_t* ctr;    // counters
     typedef float vec4 __attribute__((ext_vector_type(4))); // (HIP's float4 has no constructors for address-space qualified objects)
-    THX_GLOBAL vec4* cold; // global [P][NCOLD] of this workgroup: the chunks of a photon share a 32- / 64-B line
+    THX_GLOBAL vec4* cold; // global [P][NCOLD] of this workgroup: the chunks of a photon lie side by side (48 / 80 B)
     // cold chunk k: 0 {lin, log, medium}, 1 {n, vg, mu_s, mu_e}, 2 {stokes}, 3 {polRef}
     THX_DEV float4 ldCold(uint32_t k, uint32_t slot) const {
         const vec4 v = cold[slot * Lay::NCOLD + k];
@@ -351,6 +366,12 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     // response.histogram.glsl:20-29 initResponse; every slot starts free
     for (uint32_t i = tid; i < n_bins; i += T) hist[i] = 0.0f;
     for (uint32_t i = tid; i < 8 * pool.cap; i += T) pool.q[i] = (uint16_t)(i < P ? i : Q_EMPTY);
+    if constexpr (V::LDSN) { // the walk's copy of the pair records (two 16-B halves each)
+        typedef uint32_t u4 __attribute__((ext_vector_type(4)));
+        const THX_GLOBAL u4* src = (const THX_GLOBAL u4*)(args.scene.nodes);
+        u4* dst = reinterpret_cast<u4*>(ldsWords() + args.lds_node_word);
+        for (uint32_t i = tid; i < 2u * args.lds_node_pairs; i += T) dst[i] = src[i];
+    }
 
     Lane<V> L;
     L.a = &args;
@@ -601,7 +622,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     dir = normalize(f3{c1.x, c1.y, c1.z});
                     tmax = pool.sc[0 * P + slot].x;
                 } else {
+#ifdef THX_SHADOW2_LDS
                     float4 d = pool.sc[(which - 1u) * P + slot];
+#else
+                    float4 d = which == 1u ? pool.sc[slot] : pool.ldCold(Lay::C_SHADOW2, slot);
+#endif
                     dir = f3{d.x, d.y, d.z};
                     weight = d.w;
                     tmax = pool.st[2 * P + slot].w;
@@ -777,7 +802,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
                 float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
                 pool.sc[0 * P + slot] = make_float4(dirPhase.x, dirPhase.y, dirPhase.z, wPhase);
+#ifdef THX_SHADOW2_LDS
                 pool.sc[1 * P + slot] = make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget);
+#else
+                pool.stCold(Lay::C_SHADOW2, slot, make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget));
+#endif
                 t1 = rootHit(L, ray.position, dirPhase, ps.dist);
                 t2 = rootHit(L, ray.position, ts.dir, ts.dist);
                 m.distShadow = ps.dist; // == ts.dist: both are |center - observer| + radius

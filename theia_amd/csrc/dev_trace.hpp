@@ -17,9 +17,13 @@ struct Variant {
     // What is known about the traversal stack at compile time. 0: nothing (entry width and the split between LDS and global
     // memory are decided at run time); 1: 16-bit entries (scenes below 8 190 nodes / triangles / instances); 2: 16-bit
     // entries and the whole stack in LDS (such scenes no deeper than the LDS share). Every push and pop loses a
-    // wave-uniform branch with 1 and a lane-divergent one with 2: -1 % and -2 %.
+    // wave-uniform branch with 1 and a lane-divergent one with 2: -1 % and -2 %. 3: as 2, and the walk reads the pair
+    // records from a copy in LDS (scenes whose whole node array fits next to the photon pool): an LDS read returns in
+    // 64 cycles whatever the other wavefronts do, a 16-B gather through the vector cache in 150 (alone) to 600 (sixteen
+    // wavefronts gathering) when it hits and the L2's 500+ when it does not (profiles/r03_mem_latency.txt).
     static constexpr bool S16 = STACK_ != 0;
-    static constexpr bool SPILL = STACK_ != 2;
+    static constexpr bool SPILL = STACK_ != 2 && STACK_ != 3;
+    static constexpr bool LDSN = STACK_ == 3;
 };
 
 // ray.glsl:22-36 (+163-170 polarized part)
@@ -44,6 +48,8 @@ struct LaunchArgs {
     uint32_t stack_lds;        // the first stack_lds of them live in LDS, deeper ones in `spill` (== stack_depth: all in LDS)
     uint32_t stack_wave_words; // LDS words of one wavefront's stack block (stack_lds*64, or stack_lds*32 for 16-bit entries)
     uint32_t stack16;          // 1: stack entries are 16 bit (scene has < 8190 nodes/triangles)
+    uint32_t lds_node_word;    // staged kernel, Variant::LDSN: LDS word index of the copy of the pair records ...
+    uint32_t lds_node_pairs;   // ... and how many records it holds (all of the scene's)
     uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active
     uint32_t pool;             // staged kernel: photons held in LDS per workgroup
     float* slabs;              // [gridDim.x][n_bins] partial histograms
@@ -1121,7 +1127,8 @@ constexpr uint32_t WALK_SENTINEL = 0xFFFFFFFEu; // low bits 6: leave the current
 // offered: measured -1.4 % / +1.8 % on configs 2 / 3 with the pool it takes. Removed in round 2.)
 template <class V>
 THX_DEV const float4* walkNodes(const Lane<V>& L) {
-    return reinterpret_cast<const float4*>(L.a->scene.nodes);
+    if constexpr (V::LDSN) return reinterpret_cast<const float4*>(ldsWords() + L.a->lds_node_word);
+    else return reinterpret_cast<const float4*>(L.a->scene.nodes);
 }
 
 // Closest-hit query: opaque, no culling, 0 < t < tmax, committed closest triangle

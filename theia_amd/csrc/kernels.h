@@ -31,11 +31,19 @@ inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block, uint
     return hist + stack;
 }
 // dynamic LDS bytes of the staged scene kernel (dev_staged.hpp: StagedLayout)
-size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads);
-uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads);
+// (nodeBytes: the copy of the scene's pair records the Variant::LDSN kernels keep behind everything else)
+size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes = 0);
+uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes = 0);
 // global memory (bytes) of one workgroup's cold photon state (dev_staged.hpp: StagedLayout::coldBytes)
 size_t stagedColdBytes(bool polarized, uint32_t pool);
 constexpr uint32_t kStagedBlock = 1024;
+// staged kernel: the pair records of a scene go into LDS when they are at most kLdsNodeMaxBytes and still leave a pool of
+// kLdsNodeMinPool photons (measured: profiles/r03_lds_nodes.txt)
+constexpr size_t kLdsNodeMaxBytes = 48 * 1024;
+constexpr uint32_t kLdsNodeMinPool = 1056;
+// staged kernel: photons per workgroup beyond which a larger pool no longer pays (config 2: 1264 -> 2.82 ms, 1552 -> 2.88;
+// configs 3 / 5 and the large meshes are flat between 1264 and 1440: profiles/r03_lds_nodes.txt)
+constexpr uint32_t kPoolBest = 1344;
 
 // one function pair per compiled variant (trace_variant.hip, built once per
 // KIND x POL x MIS); mode bit 0 selects the instrumented (statistics + track) kernel,

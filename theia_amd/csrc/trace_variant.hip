@@ -106,6 +106,8 @@ using PlainS = Variant<THX_POL != 0, THX_MIS != 0, false, false, 1>; // 16-bit s
 using DebugS = Variant<THX_POL != 0, THX_MIS != 0, true, true, 1>;
 using PlainT = Variant<THX_POL != 0, THX_MIS != 0, false, false, 2>; // ... and the whole stack in LDS
 using DebugT = Variant<THX_POL != 0, THX_MIS != 0, true, true, 2>;
+using PlainN = Variant<THX_POL != 0, THX_MIS != 0, false, false, 3>; // ... and the pair records in LDS
+using DebugN = Variant<THX_POL != 0, THX_MIS != 0, true, true, 3>;
 
 #if THX_KIND == 1
 // staged (regrouped-in-LDS) form of the scene tracer, see dev_staged.hpp
@@ -115,23 +117,31 @@ __global__ void __launch_bounds__(kSchedThreads) sceneStagedKernel(const LaunchA
 }
 #endif
 
+// staged kernel variants: 0/1 nothing known about the stack, 2/3 16-bit entries, 4/5 ... all in LDS, 6/7 ... and the
+// pair records too; odd = instrumented
+static inline uint32_t stagedVariantIndex(uint32_t mode) {
+    return ((mode & 1u) ? 1u : 0u) | ((mode & 4u) ? ((mode & 8u) ? ((mode & 16u) ? 6u : 4u) : 2u) : 0u);
+}
+
 #define THX_CAT_(a, b, c, d) a##b##_##c##_##d
 #define THX_CAT(a, b, c, d) THX_CAT_(a, b, c, d)
 #define THX_FN(prefix) THX_CAT(prefix, THX_KIND, THX_POL, THX_MIS)
 
 // mode: bit 0 = instrumented (statistics + track), bit 1 = staged kernel (scene only),
-// bit 2 = 16-bit traversal stack entries, bit 3 = the whole stack in LDS (staged kernel only: variants of their own)
+// bit 2 = 16-bit traversal stack entries, bit 3 = the whole stack in LDS, bit 4 = the pair records in LDS
+// (staged kernel only: variants of their own)
 hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t grid, uint32_t block,
                                 size_t lds, hipStream_t stream) {
     const bool debug = mode & 1u;
 #if THX_KIND == 1
     if (mode & 2u) {
         // > 64 KB of dynamic LDS needs an explicit opt-in (once per kernel)
-        const void* fn[6] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
+        const void* fn[8] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
                              reinterpret_cast<const void*>(sceneStagedKernel<PlainS>), reinterpret_cast<const void*>(sceneStagedKernel<DebugS>),
-                             reinterpret_cast<const void*>(sceneStagedKernel<PlainT>), reinterpret_cast<const void*>(sceneStagedKernel<DebugT>)};
-        static bool optedIn[6] = {false, false, false, false, false, false};
-        const uint32_t k = (debug ? 1u : 0u) | ((mode & 4u) ? ((mode & 8u) ? 4u : 2u) : 0u);
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainT>), reinterpret_cast<const void*>(sceneStagedKernel<DebugT>),
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainN>), reinterpret_cast<const void*>(sceneStagedKernel<DebugN>)};
+        static bool optedIn[8] = {false, false, false, false, false, false, false, false};
+        const uint32_t k = stagedVariantIndex(mode);
         if (!optedIn[k]) {
             hipError_t e = hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
             if (e != hipSuccess) return e;
@@ -143,7 +153,9 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
         case 2: hipLaunchKernelGGL((sceneStagedKernel<PlainS>), dim3(grid), dim3(block), lds, stream, args); break;
         case 3: hipLaunchKernelGGL((sceneStagedKernel<DebugS>), dim3(grid), dim3(block), lds, stream, args); break;
         case 4: hipLaunchKernelGGL((sceneStagedKernel<PlainT>), dim3(grid), dim3(block), lds, stream, args); break;
-        default: hipLaunchKernelGGL((sceneStagedKernel<DebugT>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 5: hipLaunchKernelGGL((sceneStagedKernel<DebugT>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 6: hipLaunchKernelGGL((sceneStagedKernel<PlainN>), dim3(grid), dim3(block), lds, stream, args); break;
+        default: hipLaunchKernelGGL((sceneStagedKernel<DebugN>), dim3(grid), dim3(block), lds, stream, args); break;
         }
         return hipGetLastError();
     }
@@ -161,14 +173,16 @@ int THX_FN(traceOccupancy_)(uint32_t mode, uint32_t block, size_t lds) {
     hipError_t e;
 #if THX_KIND == 1
     if (mode & 2u) {
-        const uint32_t k = (debug ? 1u : 0u) | ((mode & 4u) ? ((mode & 8u) ? 4u : 2u) : 0u);
+        const uint32_t k = stagedVariantIndex(mode);
         switch (k) {
         case 0: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<Plain>, (int)block, lds); break;
         case 1: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<Debug>, (int)block, lds); break;
         case 2: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainS>, (int)block, lds); break;
         case 3: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugS>, (int)block, lds); break;
         case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainT>, (int)block, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugT>, (int)block, lds); break;
+        case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugT>, (int)block, lds); break;
+        case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainN>, (int)block, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugN>, (int)block, lds); break;
         }
         return e == hipSuccess ? n : -1;
     }

@@ -21,13 +21,17 @@ for name in names:
                 os.environ.pop(k, None)
             else:
                 os.environ[k] = v
-        sc = MAKE[name](batch=n)
-        pipe = Pipeline(sc.stages())
-        ms = []
-        for k in range(WARM + 5):  # the clocks of a fresh GPU take a second of work to settle
-            pipe.run(k % 2)
-            ms.append(sc.tracer.program.last_kernel_ms(k % 2))
-        info = sc.tracer.program.launch_info(n)
         tag = " ".join(f"{k}={v}" for (k, _), v in zip(axes, combo))
+        try:
+            sc = MAKE[name](batch=n)
+            pipe = Pipeline(sc.stages())
+            ms = []
+            for k in range(WARM + 5):  # the clocks of a fresh GPU take a second of work to settle
+                pipe.run(k % 2)
+                ms.append(sc.tracer.program.last_kernel_ms(k % 2))
+            info = sc.tracer.program.launch_info(n)
+        except Exception as exc:  # a combination the library refuses (e.g. a pool that does not fit)
+            print(f"{name:8s} {tag:40s} refused: {exc}", flush=True)
+            continue
         print(f"{name:8s} {tag:40s} kernel ms = {np.median(ms[-5:]):8.3f}   block={info['block']} lds={info['lds_bytes']}", flush=True)
         del sc, pipe
