@@ -64,6 +64,7 @@ struct thx_tracer {
     uint32_t mode = 0;            // bit 0 instrumented, bit 1 staged
     uint32_t stackDepth = kStackDepth;
     uint32_t stackLds = kStackDepth; // entries of the traversal stack kept in LDS; the rest of stackDepth spills to `spill`
+    uint32_t stackSlots = kStackDepth; // staged kernel: LDS slots per lane (stackLds, + 1 for the variants with the whole stack in LDS)
     uint32_t* spill = nullptr;
     uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_trace.hpp: Walker::save)
     bool stack16 = false;         // 16-bit stack entries (small scenes)
@@ -416,7 +417,12 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // come out of LDS and the rest lives in global memory (dev_trace.hpp: Walker::push)
         t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
         if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
-        const uint32_t stackBytes = t->stackLds * (t->stack16 ? 2u : 4u);
+        // the kernel variants with the whole stack in LDS (16-bit entries read sign-extended: every ref below 0x8000) keep
+        // one more slot per lane, below entry 0 (dev_trace.hpp: Walker)
+        const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth && scene->nPairs < 4096 * kRecordSlots &&
+                                 scene->info.n_triangles < 4096 && scene->info.n_instances < 4096;
+        t->stackSlots = t->stackLds + (stackAllLds ? 1u : 0u);
+        const uint32_t stackBytes = t->stackSlots * (t->stack16 ? 2u : 4u);
         // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %.
         // Deep scenes (large per-thread stacks) leave a pool much smaller than the workgroup:
         // batches run half empty then. Fewer wavefronts with fuller batches win while the pool
@@ -429,7 +435,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
             }
         t->pool = std::min(t->pool, kPoolBest);
         if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in ...
-        if (t->stack16 && t->stackLds == t->stackDepth) t->mode |= 8u; // ... and with the whole stack in LDS
+        if (stackAllLds) t->mode |= 8u; // ... and with the whole stack in LDS
         // Small scenes: the walk reads its pair records from a copy in LDS if that leaves a pool of kLdsNodeMinPool photons
         // (THX_LDS_NODES=0 / 1: never / whenever it fits at all)
         if ((t->mode & 8u) && t->block == kStagedBlock) {
@@ -614,7 +620,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.track_events = t->trackEvents;
     a.stack_depth = t->stackDepth;
     a.stack_lds = t->stackLds;
-    a.stack_wave_words = t->stackLds * (t->stack16 ? 32u : 64u);
+    a.stack_wave_words = (t->staged ? t->stackSlots : t->stackLds) * (t->stack16 ? 32u : 64u);
     a.spill = t->spill;
     a.park = t->park;
     a.park_below = t->scene && t->scene->info.n_instances > kParkInstancedFrom ? kParkBelowInstanced

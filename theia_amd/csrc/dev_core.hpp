@@ -196,6 +196,9 @@ THX_DEV void philox4x32(const thx_philox_params& p, uint32_t stream, uint32_t i,
     t = kx + stream; carry = t < kx ? 1u : 0u; kx = t;
     t = ky + carry; carry = t < ky ? 1u : 0u; ky = t;
     kx += carry;
+    // (the key words are final here: without this the compiler carries the carry flag through all ten rounds and
+    // spends an add-with-carry and a move on every key bump instead of one add)
+    asm volatile("" : "+v"(kx), "+v"(ky));
     constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
 #pragma unroll
     for (int r = 0; r < 10; ++r) {

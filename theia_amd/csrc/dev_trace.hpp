@@ -1008,7 +1008,17 @@ struct SlabRay {
     v2f inv_xy, noi_xy; // 1/d and -(o/d), x and y
     float inv_z, noi_z;
 };
+// Round 3: the reciprocal is the hardware's (v_rcp_f32, 1 ulp) instead of a correctly rounded division (~10 instructions
+// each, six per ray and frame: profiles/r03_inner_loop.txt). The box tests only have to be conservative: an error of the
+// reciprocal scales all plane distances of an axis by the same 1 +- 1.2e-7, which the relative slack of the interval test
+// (kSlabSlack, raised from 4e-7 to 1e-6 with this) covers whatever the distance; the ray/triangle test -- what decides a
+// hit and its coordinates -- keeps its exact divisions (woopSetup), so hits stay bitwise those of the oracle's brute force.
+#ifdef THX_SLAB_EXACT_DIV
 THX_DEV float slabInv(float d) { return fminf(fmaxf(1.0f / d, -1.0e30f), 1.0e30f); }
+#else
+THX_DEV float slabInv(float d) { return fminf(fmaxf(__builtin_amdgcn_rcpf(d), -1.0e30f), 1.0e30f); }
+#endif
+constexpr float kSlabSlack = 1.000001f;
 THX_DEV SlabRay slabRay(f3 o, f3 d) {
     SlabRay r;
     const float ix = slabInv(d.x), iy = slabInv(d.y), iz = slabInv(d.z);
@@ -1024,7 +1034,7 @@ THX_DEV float slabNode(const float4 a, const float4 b, const SlabRay& r, float t
     const float tz0 = __builtin_fmaf(a.z, r.inv_z, r.noi_z), tz1 = __builtin_fmaf(b.z, r.inv_z, r.noi_z);
     float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
-    return tn <= tf * 1.0000004f ? tn : -1.0f;
+    return tn <= tf * kSlabSlack ? tn : -1.0f;
 }
 
 // The walk reads 16-bit quantised child boxes (thx_layout.h: NodePair): plane = origin + q * step in
@@ -1089,20 +1099,33 @@ THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     const float tn_z = __builtin_fmaf(u16lo(nfz), r.a_z, r.b_z), tf_z = __builtin_fmaf(u16hi(nfz), r.a_z, r.b_z);
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
     const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
-    return tn <= tf * 1.0000004f ? tn : -1.0f;
+    return tn <= tf * kSlabSlack ? tn : -1.0f;
 #else
     const v2f t0 = __builtin_elementwise_fma(v2f{(float)(wl & 0xFFFFu), (float)(wl >> 16)}, r.a_xy, r.b_xy);
     const v2f t1 = __builtin_elementwise_fma(v2f{(float)(wh & 0xFFFFu), (float)(wh >> 16)}, r.a_xy, r.b_xy);
     const float tz0 = __builtin_fmaf((float)(wz & 0xFFFFu), r.a_z, r.b_z), tz1 = __builtin_fmaf((float)(wz >> 16), r.a_z, r.b_z);
     float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
-    return tn <= tf * 1.0000004f ? tn : -1.0f;
+    return tn <= tf * kSlabSlack ? tn : -1.0f;
 #endif
 }
 // the same with a miss at infinity (what the 4-wide visit sorts by)
 THX_DEV float slabChildFar(const float4 c, const QRay& r, float tmax) {
     const float t = slabChild(c, r, tmax);
     return t >= 0.0f ? t : INFINITY;
+}
+// ... in one select: entry distance, or +inf for a miss (a hit's distance is finite: the reciprocals are clamped). What
+// the branch-free inner-node loop orders the children by: min / max / <= on these do the work of the four-way branch.
+THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax) {
+    const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
+    const uint32_t nxy = __builtin_amdgcn_perm(wh, wl, r.sxy), fxy = __builtin_amdgcn_perm(wl, wh, r.sxy);
+    const uint32_t nfz = __builtin_amdgcn_perm(wz, wz, r.sz);
+    const v2f tn_xy = __builtin_elementwise_fma(v2f{u16lo(nxy), u16hi(nxy)}, r.a_xy, r.b_xy);
+    const v2f tf_xy = __builtin_elementwise_fma(v2f{u16lo(fxy), u16hi(fxy)}, r.a_xy, r.b_xy);
+    const float tn_z = __builtin_fmaf(u16lo(nfz), r.a_z, r.b_z), tf_z = __builtin_fmaf(u16hi(nfz), r.a_z, r.b_z);
+    const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
+    const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
+    return tn <= tf * kSlabSlack ? tn : INFINITY;
 }
 // the root box of a tree = its whole frame, q = 0 .. 65535
 THX_DEV bool slabRoot(const QRay& r, float tmax) {
@@ -1111,7 +1134,7 @@ THX_DEV bool slabRoot(const QRay& r, float tmax) {
     const float tz0 = r.b_z, tz1 = __builtin_fmaf(65535.0f, r.a_z, r.b_z);
     float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
-    return tn <= tf * 1.0000004f;
+    return tn <= tf * kSlabSlack;
 }
 THX_DEV float4 tlasFrame0(const SceneView& sc) { return make_float4(sc.tlas.origin[0], sc.tlas.origin[1], sc.tlas.origin[2], __uint_as_float(sc.tlas.rootRef)); }
 THX_DEV float4 tlasFrame1(const SceneView& sc) { return make_float4(sc.tlas.step[0], sc.tlas.step[1], sc.tlas.step[2], 0.0f); }
@@ -1185,6 +1208,13 @@ struct Walker {
         // touch 32 different banks whatever their stack pointers are
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (((threadIdx.x & 31u) << 1) | ((threadIdx.x >> 5) & 1u));
 #endif
+        // Whole stack in LDS (variants T / N): one more slot BELOW entry 0 holds WALK_DONE for good, so the inner-node loop
+        // can read "what a pop would return" before it knows whether it pops, without asking whether the stack is empty
+        // (the host adds the slot to the wavefront's block; entries are read sign-extended: refs stay below 0x8000 there).
+        if constexpr (!V::SPILL) {
+            stack16 += 64;
+            stack16[-64] = (uint16_t)0xFFFFu;
+        }
         sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false; overflow = false;
         w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
         h.valid = false; h.instance = 0; h.prim = 0; h.t = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
@@ -1193,7 +1223,8 @@ struct Walker {
     // invariant; it is not silent: the walk goes on without the entry and its photon is ended with
     // ERROR_CODE_TRACE_ABORT, counted like every other device error (callback.stat.glsl:66-69).
     THX_DEV void push(uint32_t v) {
-        if (sp >= depth) { overflow = true; return; }
+        // (whole stack in LDS: the inner-node loop writes the slot above the top unconditionally, so the last one stays free)
+        if (sp >= (V::SPILL ? depth : depth - 1u)) { overflow = true; return; }
         if (V::SPILL && sp >= ldsN) spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)] = v;
         else if (s16) stack16[sp * 64] = (uint16_t)v;
         else stack32[sp * 64] = v;
@@ -1203,6 +1234,7 @@ struct Walker {
         if (sp == 0) return WALK_DONE;
         --sp;
         if (V::SPILL && sp >= ldsN) return spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)];
+        if constexpr (!V::SPILL) return (uint32_t)(int32_t)(int16_t)stack16[sp * 64]; // 0xFFFE -> WALK_SENTINEL
         if (s16) {
             uint32_t v = stack16[sp * 64];
             return v == 0xFFFEu ? WALK_SENTINEL : v;
@@ -1325,11 +1357,12 @@ struct Walker {
         sp = 0;
         if (inBlas || enter) {
             const uint32_t root = instanceFrame();
-            if (enter) { // what enterInstance does after the frames
+            if (enter) { // what enterInstance does after the frames -- without the sentinel entry: the TLAS of a
+                         // one-instance scene is this one leaf, so when the stack runs empty inside the instance the
+                         // walk is over (enterInstance's way costs every ray one more pop and the way back to world space)
                 inBlas = true;
-                push(WALK_SENTINEL);
                 L.cnt.add(ST_NODES);
-                cur = slabRoot(sr, h.t) ? root : pop();
+                cur = slabRoot(sr, h.t) ? root : WALK_DONE;
             }
         }
         for (uint32_t e = 0; e < n; ++e) push(a[8 + e]);
@@ -1345,6 +1378,50 @@ struct Walker {
         // nodes (fewer than THX_INNER_KEEP / 8 of those that started the loop) that the others should not wait any
         // longer: everybody leaves then, lanes holding a leaf process it, the rest go on in the next round
         const uint32_t innerKeep = ((uint32_t)__popcll(__ballot((cur & 7u) == 0u)) * (uint32_t)THX_INNER_KEEP) >> 3;
+#if !defined(THX_BVH4) && !defined(THX_BRANCHY_INNER)
+        // Whole stack in LDS, 16-bit entries (variants T / N): the visit of an inner node as straight-line code. With the
+        // pair records in LDS a trip is bound by its own chain of dependent instructions -- 64 idle cycles per trip cost
+        // configs 2 / 3 +3.7 %, 16 more vector instructions +3.6 % (profiles/r03_inner_loop.txt) -- and the four-way branch
+        // on (left hit, right hit) was five hand-overs from the vector unit to the scalar unit and back (~30 cycles each)
+        // plus the LDS round trip of a pop behind them. Here: misses are at +inf, so near / far child, "both" and "none"
+        // come out of min / max / compare on the two distances; the far child is written to the slot above the stack top
+        // whether or not it is pushed (harmless: the slot is free), and what a pop would return is read together with the
+        // node (harmless if it does not pop). Same visits in the same order as the branchy form below.
+        if constexpr (!V::SPILL) {
+            const uint32_t top = depth - 1u; // the last slot stays free for the unconditional write
+            uint32_t spHi = sp;
+            while ((cur & 7u) == 0u) {
+#ifdef THX_STAGE_PROFILE
+                pLane += 1;
+                pTrips += 1;
+                {
+                    const unsigned long long m = __ballot(1);
+                    if (L.prof != nullptr && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
+                        atomicAdd(&L.prof[31], (unsigned long long)__popcll(m));
+                        atomicAdd(&L.prof[39], 1ull);
+                    }
+                }
+#endif
+                const float4* rec = nodes + (cur >> 2); // record (cur >> 3) = two float4
+                const float4 lc = rec[0], rc = rec[1];
+                const uint32_t below = (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64];
+                L.cnt.add(ST_NODES, 2);
+                const float tl = slabChildInf(lc, sr, h.t), tr = slabChildInf(rc, sr, h.t);
+                const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
+                const bool leftFirst = tl <= tr;
+                const uint32_t nearRef = leftFirst ? ml : mr, farRef = leftFirst ? mr : ml;
+                const bool both = fmaxf(tl, tr) < INFINITY, none = fminf(tl, tr) == INFINITY;
+                stack16[(sp < top ? sp : top) << 6] = (uint16_t)farRef;
+                const uint32_t pushed = sp + (both ? 1u : 0u);
+                spHi = pushed > spHi ? pushed : spHi;
+                sp = (pushed < top ? pushed : top) - (none ? 1u : 0u);
+                cur = none ? below : nearRef;
+                if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
+            }
+            if (spHi > top) overflow = true; // an entry did not fit (the host sizes the stack two above the scene's depth)
+            if (cur == WALK_DONE) sp = 0;
+        } else
+#endif
         while ((cur & 7u) == 0u) {
 #ifdef THX_STAGE_PROFILE
             pLane += 1;
@@ -1391,6 +1468,17 @@ struct Walker {
 #endif
             float tl = slabChild(lc, sr, h.t);
             float tr = slabChild(rc, sr, h.t);
+#ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
+            {
+                float sink;
+#pragma unroll
+                for (int e = 0; e < THX_EXTRA_ISSUE; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(tl));
+            }
+#endif
+#ifdef THX_EXTRA_NOP // experiment: N x 16 cycles in which this wavefront issues nothing (latency, no issue slots)
+#pragma unroll
+            for (int e = 0; e < THX_EXTRA_NOP; ++e) asm volatile("s_nop 15");
+#endif
 #ifdef THX_EXTRA_VALU // experiment: is the walk bound by VALU issue? N dependent FMAs per visit that cannot be removed
             {
                 float acc = tl;
