@@ -62,6 +62,20 @@ constexpr uint32_t kCellSpinLimit = 1u << 22;
 #define THX_IDLE_SLEEP 4 // x64 cycles between two looks of a wavefront that found no work (VALU is ~97 % busy: polling costs)
 #endif
 
+// Wavefront priorities (s_setprio; the SIMD's arbiter serves the higher one first): a walking wavefront is bound by its own
+// chain of dependent instructions and issues one every ~10 cycles, a shading stage is a dense stream of vector instructions
+// that takes every slot it gets -- so walks go first and the shading stages fill the gaps; the scheduling code between two
+// stages is short and other wavefronts wait for what it publishes. Measured (profiles/r03_inner_loop.txt): walk 1 / scheduler 3
+// over shading 0: config 2 / 3 / 5 -1.8 / -2.7 / -0.9 %; shading above the walks: +2 %. -DTHX_NO_PRIO builds without.
+#ifndef THX_NO_PRIO
+#ifndef THX_SCHED_PRIO
+#define THX_SCHED_PRIO 3
+#endif
+#ifndef THX_WALK_PRIO
+#define THX_WALK_PRIO 1
+#endif
+#endif
+
 // photon flags (meta.z)
 constexpr uint32_t F_ALIVE = 1u, F_ALLOW = 2u, F_MIS_TARGET = 4u;
 constexpr uint32_t F_STEP_SHIFT = 8, F_STEP_MASK = 0xFFFFu << 8; // step index
@@ -423,6 +437,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     while (true) {
         // ===== LDS round trip 1: reserve a ring cell per entry of the finished stage and
         // fetch the counter block (issued behind the atomics, so it sees them).
+#ifdef THX_SCHED_PRIO
+        __builtin_amdgcn_s_setprio(THX_SCHED_PRIO);
+#endif
         const bool pushA = dstA >= 0;
         uint32_t posA = 0, posB = 0;
         if (__ballot(pushA) != 0ull) {
@@ -561,6 +578,13 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             birthFirst = __builtin_amdgcn_readfirstlane(birthFirst);
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
+#ifdef THX_SCHED_PRIO
+#ifdef THX_SHADE_PRIO
+        __builtin_amdgcn_s_setprio(THX_SHADE_PRIO);
+#else
+        __builtin_amdgcn_s_setprio(0);
+#endif
+#endif
 #ifdef THX_STAGE_PROFILE
         const unsigned long long profT0 = __builtin_amdgcn_s_memtime();
         if (lane == 0) {
@@ -608,6 +632,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
         case S_T0: { // closest-hit walks: primary rays (which 0; a surface hit is finished here,
                      // scene.traverse.glsl:312-351) and shadow rays (which 1, 2; :185-214)
+#ifdef THX_WALK_PRIO
+            __builtin_amdgcn_s_setprio(THX_WALK_PRIO);
+#endif
             const uint32_t slot = entry & 0x7FFu, which = entry >> 12;
             const bool resumed = (entry & E_RESUME) != 0u;
             bool parked = false;
@@ -690,6 +717,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 if ((tid & 63u) == 0u) atomicAdd(&profLds[9], __builtin_amdgcn_s_memtime() - wt1);
 #endif
             }
+#if defined(THX_WALK_PRIO) && defined(THX_SHADE_PRIO)
+            __builtin_amdgcn_s_setprio(THX_SHADE_PRIO);
+#elif defined(THX_WALK_PRIO)
+            __builtin_amdgcn_s_setprio(0);
+#endif
             entA = slot;
             dstA = dest == 4 ? S_BM : (dest == 1 ? (V::MIS ? S_M : S_C) : (dest == 2 ? S_A : (dest == 3 ? S_BIRTH : (lastShadow ? S_C : -1))));
             if (parked) {

@@ -6,7 +6,7 @@ ROOT=$(cd "$(dirname "$0")/.." && pwd)
 POL=$1; MIS=$2; VAR=$3; DBG=${4:-0}; shift 4 || shift $#
 SUF=""; if [ "$DBG" = 1 ]; then SUF=d; fi
 OUT=/tmp/thx_${POL}${MIS}_v${VAR}${SUF}.s
-/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -mllvm -amdgpu-sdwa-peephole=0 \
+/opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -ffp-contract=off -fno-fast-math -fno-slp-vectorize -mllvm -disable-vector-combine -mllvm -amdgpu-sdwa-peephole=0 \
   -DTHX_KIND=1 -DTHX_POL=$POL -DTHX_MIS=$MIS "$@" --cuda-device-only -S $ROOT/theia_amd/csrc/trace_variant.hip -o /tmp/thx_all.s 2>&1 | grep -E "error" || true
 B=Lb0ELb0E; if [ "$DBG" = 1 ]; then B=Lb1ELb1E; fi
 NAME="_ZN3thx17sceneStagedKernelINS_7VariantILb${POL}ELb${MIS}E${B}Li${VAR}EEEEEvNS_10LaunchArgsE"
