@@ -396,7 +396,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     t->block = replay ? kReplayBlock : kTraceBlock;
     if (scene) {
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
-        t->stack16 = scene->nPairs < 8190 * kRecordSlots && scene->info.n_triangles < 8190 && scene->info.n_instances < 8190;
+        // 16-bit stack entries are read sign-extended (0xFFFE / 0xFFFF = leave the instance / done): every ref = index << 3 | count
+        // of the scene has to stay below 0x8000
+        t->stack16 = scene->nPairs < 4096 * kRecordSlots && scene->info.n_triangles < 4096 && scene->info.n_instances < 4096;
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
         // test hook: a stack shallower than the scene needs (the walk then flags ERROR_CODE_TRACE_ABORT)
         if (const char* env = std::getenv("THX_STACK_DEPTH")) t->stackDepth = (uint32_t)std::min<int>(kStackDepth, std::max(1, std::atoi(env)));
@@ -417,11 +419,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // come out of LDS and the rest lives in global memory (dev_trace.hpp: Walker::push)
         t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
         if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
-        // the kernel variants with the whole stack in LDS (16-bit entries read sign-extended: every ref below 0x8000) keep
-        // one more slot per lane, below entry 0 (dev_trace.hpp: Walker)
-        const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth && scene->nPairs < 4096 * kRecordSlots &&
-                                 scene->info.n_triangles < 4096 && scene->info.n_instances < 4096;
-        t->stackSlots = t->stackLds + (stackAllLds ? 1u : 0u);
+        // one more slot per lane below entry 0 (dev_trace.hpp: Walker<V, FAST>)
+        const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth;
+        t->stackSlots = t->stackLds + 1u;
         const uint32_t stackBytes = t->stackSlots * (t->stack16 ? 2u : 4u);
         // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %.
         // Deep scenes (large per-thread stacks) leave a pool much smaller than the workgroup:

@@ -318,7 +318,7 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
 // lane is through -- or until so few are left that they are set aside (`parked`, see LaunchArgs::park_below).
 template <class V>
 THX_DEV QueryHit walkBatch(Lane<V>& L, f3 org, f3 dir, float tmax, bool resumed, THX_GLOBAL uint32_t* area, bool& parked) {
-    Walker<V> wk(L);
+    Walker<V, true> wk(L);
     wk.start(org, dir, tmax, resumed, area);
     uint32_t rounds = 0;
     while (true) {

@@ -1166,7 +1166,11 @@ THX_DEV const float4* walkNodes(const Lane<V>& L) {
 // leaf (triangles, instance entry or instance exit). rayQuery() runs one ray per
 // lane to completion; walkQueue() (dev_staged.hpp) keeps the lanes of a wave fed
 // from a queue of rays.
-template <class V>
+// FAST (the staged kernel's walks): the LDS part of the stack has one more slot BELOW entry 0 that holds WALK_DONE for
+// good (the host adds it to the wavefront's block), 16-bit entries are read sign-extended (the host picks them only for
+// scenes whose refs stay below 0x8000), and advance() visits inner nodes in straight-line code while a lane's stack
+// top is inside the LDS part.
+template <class V, bool FAST = false>
 struct Walker {
     Lane<V>& L;
     const float4* nodes;
@@ -1199,7 +1203,7 @@ struct Walker {
         // 16-bit entries when the scene is small enough (halves the LDS footprint).
         // (Storing entry distances for pop-time culling was measured slower: -10 % node
         // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
-        s16 = V::S16 || L.a->stack16 != 0u;
+        s16 = FAST ? V::S16 : (V::S16 || L.a->stack16 != 0u);
         stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
 #ifdef THX_STACK16_LINEAR // the first layout: lanes 2k and 2k+1 share an LDS bank (profiles/r02_lds_conflicts.txt)
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
@@ -1208,12 +1212,14 @@ struct Walker {
         // touch 32 different banks whatever their stack pointers are
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (((threadIdx.x & 31u) << 1) | ((threadIdx.x >> 5) & 1u));
 #endif
-        // Whole stack in LDS (variants T / N): one more slot BELOW entry 0 holds WALK_DONE for good, so the inner-node loop
-        // can read "what a pop would return" before it knows whether it pops, without asking whether the stack is empty
-        // (the host adds the slot to the wavefront's block; entries are read sign-extended: refs stay below 0x8000 there).
-        if constexpr (!V::SPILL) {
-            stack16 += 64;
-            stack16[-64] = (uint16_t)0xFFFFu;
+        if constexpr (FAST) { // the sentinel slot below entry 0: "what a pop would return" can be read without asking for an empty stack
+            if (V::S16) {
+                stack16 += 64;
+                stack16[-64] = (uint16_t)0xFFFFu;
+            } else {
+                stack32 += 64;
+                stack32[-64] = WALK_DONE;
+            }
         }
         sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false; overflow = false;
         w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
@@ -1223,8 +1229,7 @@ struct Walker {
     // invariant; it is not silent: the walk goes on without the entry and its photon is ended with
     // ERROR_CODE_TRACE_ABORT, counted like every other device error (callback.stat.glsl:66-69).
     THX_DEV void push(uint32_t v) {
-        // (whole stack in LDS: the inner-node loop writes the slot above the top unconditionally, so the last one stays free)
-        if (sp >= (V::SPILL ? depth : depth - 1u)) { overflow = true; return; }
+        if (sp >= depth) { overflow = true; return; }
         if (V::SPILL && sp >= ldsN) spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)] = v;
         else if (s16) stack16[sp * 64] = (uint16_t)v;
         else stack32[sp * 64] = v;
@@ -1234,7 +1239,7 @@ struct Walker {
         if (sp == 0) return WALK_DONE;
         --sp;
         if (V::SPILL && sp >= ldsN) return spill[(sp - ldsN) * 64u + (threadIdx.x & 63u)];
-        if constexpr (!V::SPILL) return (uint32_t)(int32_t)(int16_t)stack16[sp * 64]; // 0xFFFE -> WALK_SENTINEL
+        if (FAST && s16) return (uint32_t)(int32_t)(int16_t)stack16[sp * 64]; // 0xFFFE -> WALK_SENTINEL
         if (s16) {
             uint32_t v = stack16[sp * 64];
             return v == 0xFFFEu ? WALK_SENTINEL : v;
@@ -1316,7 +1321,7 @@ struct Walker {
         for (uint32_t e = 0; e < sp; ++e) {
             uint32_t v;
             if (e >= ldsN) v = spill[(e - ldsN) * 64u + (threadIdx.x & 63u)];
-            else if (s16) { v = stack16[e * 64]; v = v == 0xFFFEu ? WALK_SENTINEL : v; }
+            else if (s16) { v = stack16[e * 64]; v = v == 0xFFFEu ? WALK_SENTINEL : v; } // (refs are below 0xFFFE either way)
             else v = stack32[e * 64];
             a[8 + e] = v;
         }
@@ -1368,6 +1373,77 @@ struct Walker {
         for (uint32_t e = 0; e < n; ++e) push(a[8 + e]);
     }
 
+    // One inner-node visit, branchy form: the four cases of (left hit, right hit), a push or a pop through push() / pop()
+    // (LDS or the global part of the stack, overflow check). What lanes deeper than the LDS part of their stack run, and
+    // every walk outside the staged kernel.
+    THX_DEV void visitBranchy() {
+        const uint32_t pair = cur >> 3;
+        const float4 lc = nodes[2 * pair], rc = nodes[2 * pair + 1];
+        L.cnt.add(ST_NODES, 2);
+#ifdef THX_EXTRA_LOADS // experiment: what do two more 16-B gathers per visit cost?
+        {
+            float4 x0 = nodes[2 * pair + 0 + THX_EXTRA_LOADS], x1 = nodes[2 * pair + 1 + THX_EXTRA_LOADS];
+            if (x0.x == 12345.678f || x1.x == 12345.678f) h.t = 0.0f;
+        }
+#endif
+        float tl = slabChild(lc, sr, h.t);
+        float tr = slabChild(rc, sr, h.t);
+#ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
+        {
+            float sink;
+#pragma unroll
+            for (int e = 0; e < THX_EXTRA_ISSUE; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(tl));
+        }
+#endif
+#ifdef THX_EXTRA_NOP // experiment: N x 16 cycles in which this wavefront issues nothing (latency, no issue slots)
+#pragma unroll
+        for (int e = 0; e < THX_EXTRA_NOP; ++e) asm volatile("s_nop 15");
+#endif
+#ifdef THX_EXTRA_VALU // experiment: is the walk bound by VALU issue? N dependent FMAs per visit that cannot be removed
+        {
+            float acc = tl;
+#pragma unroll
+            for (int e = 0; e < THX_EXTRA_VALU; ++e) acc = __builtin_fmaf(acc, 1.0000001f, tr);
+            if (acc == 12345.678f) h.t = 0.0f;
+        }
+#endif
+        const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
+        if (tl >= 0.0f && tr >= 0.0f) {
+            bool leftFirst = tl <= tr;
+            push(leftFirst ? mr : ml);
+            cur = leftFirst ? ml : mr;
+        } else if (tl >= 0.0f) {
+            cur = ml;
+        } else if (tr >= 0.0f) {
+            cur = mr;
+        } else {
+            cur = pop();
+        }
+    }
+    // One inner-node visit as straight-line code, for a lane whose stack top is inside the LDS part (FAST walkers). With the
+    // pair records in LDS a trip is bound by its own chain of dependent instructions -- 64 idle cycles per trip cost configs
+    // 2 / 3 +3.7 %, 16 more vector instructions +3.6 % (profiles/r03_inner_loop.txt) -- and the four-way branch of
+    // visitBranchy() is five hand-overs from the vector unit to the scalar unit and back (~30 cycles each) plus the LDS round
+    // trip of a pop behind them. Here: misses are at +inf, so near / far child, "both" and "none" come out of min / max /
+    // compare on the two distances; the far child is written to the slot above the stack top whether or not it is pushed
+    // (harmless: the slot is free), and what a pop would return is read together with the node (harmless if it does not
+    // pop; the slot below entry 0 holds WALK_DONE). Same visits in the same order as the branchy form.
+    THX_DEV void visitStraight() {
+        const float4* rec = nodes + (cur >> 2); // record (cur >> 3) = two float4
+        const float4 lc = rec[0], rc = rec[1];
+        const uint32_t below = V::S16 ? (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64] : stack32[(int32_t)(sp << 6) - 64];
+        L.cnt.add(ST_NODES, 2);
+        const float tl = slabChildInf(lc, sr, h.t), tr = slabChildInf(rc, sr, h.t);
+        const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
+        const bool leftFirst = tl <= tr;
+        const uint32_t nearRef = leftFirst ? ml : mr, farRef = leftFirst ? mr : ml;
+        const bool both = fmaxf(tl, tr) < INFINITY, none = fminf(tl, tr) == INFINITY;
+        if (V::S16) stack16[sp << 6] = (uint16_t)farRef;
+        else stack32[sp << 6] = farRef;
+        sp = sp + (both ? 1u : 0u) - (none ? 1u : 0u);
+        cur = none ? below : nearRef;
+    }
+
     // one round: inner nodes down to a leaf, then that leaf. No-op for a finished lane.
     THX_DEV void advance() {
 #ifdef THX_STAGE_PROFILE
@@ -1379,18 +1455,12 @@ struct Walker {
         // longer: everybody leaves then, lanes holding a leaf process it, the rest go on in the next round
         const uint32_t innerKeep = ((uint32_t)__popcll(__ballot((cur & 7u) == 0u)) * (uint32_t)THX_INNER_KEEP) >> 3;
 #if !defined(THX_BVH4) && !defined(THX_BRANCHY_INNER)
-        // Whole stack in LDS, 16-bit entries (variants T / N): the visit of an inner node as straight-line code. With the
-        // pair records in LDS a trip is bound by its own chain of dependent instructions -- 64 idle cycles per trip cost
-        // configs 2 / 3 +3.7 %, 16 more vector instructions +3.6 % (profiles/r03_inner_loop.txt) -- and the four-way branch
-        // on (left hit, right hit) was five hand-overs from the vector unit to the scalar unit and back (~30 cycles each)
-        // plus the LDS round trip of a pop behind them. Here: misses are at +inf, so near / far child, "both" and "none"
-        // come out of min / max / compare on the two distances; the far child is written to the slot above the stack top
-        // whether or not it is pushed (harmless: the slot is free), and what a pop would return is read together with the
-        // node (harmless if it does not pop). Same visits in the same order as the branchy form below.
-        if constexpr (!V::SPILL) {
-            const uint32_t top = depth - 1u; // the last slot stays free for the unconditional write
-            uint32_t spHi = sp;
-            while ((cur & 7u) == 0u) {
+        // Staged kernel: straight-line visits (visitStraight) while a lane's stack top is inside the LDS part. Variants with
+        // the whole stack in LDS run nothing else (the loop below is there for a full stack, which the host's sizing rules
+        // out: push() flags it); on deeper scenes a lane beyond its LDS part takes the branchy visit for those trips.
+        if constexpr (FAST) {
+            bool leftEarly = false;
+            while ((cur & 7u) == 0u && (V::SPILL || sp < ldsN)) {
 #ifdef THX_STAGE_PROFILE
                 pLane += 1;
                 pTrips += 1;
@@ -1402,25 +1472,13 @@ struct Walker {
                     }
                 }
 #endif
-                const float4* rec = nodes + (cur >> 2); // record (cur >> 3) = two float4
-                const float4 lc = rec[0], rc = rec[1];
-                const uint32_t below = (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64];
-                L.cnt.add(ST_NODES, 2);
-                const float tl = slabChildInf(lc, sr, h.t), tr = slabChildInf(rc, sr, h.t);
-                const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
-                const bool leftFirst = tl <= tr;
-                const uint32_t nearRef = leftFirst ? ml : mr, farRef = leftFirst ? mr : ml;
-                const bool both = fmaxf(tl, tr) < INFINITY, none = fminf(tl, tr) == INFINITY;
-                stack16[(sp < top ? sp : top) << 6] = (uint16_t)farRef;
-                const uint32_t pushed = sp + (both ? 1u : 0u);
-                spHi = pushed > spHi ? pushed : spHi;
-                sp = (pushed < top ? pushed : top) - (none ? 1u : 0u);
-                cur = none ? below : nearRef;
-                if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
+                if (!V::SPILL || sp < ldsN) visitStraight();
+                else visitBranchy();
+                if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) { leftEarly = true; break; }
             }
-            if (spHi > top) overflow = true; // an entry did not fit (the host sizes the stack two above the scene's depth)
-            if (cur == WALK_DONE) sp = 0;
-        } else
+            if (cur == WALK_DONE) sp = 0; // (popping the sentinel slot took the stack pointer below zero)
+            if (V::SPILL || __ballot(leftEarly) != 0ull) goto innerDone;
+        }
 #endif
         while ((cur & 7u) == 0u) {
 #ifdef THX_STAGE_PROFILE
@@ -1457,51 +1515,13 @@ struct Walker {
             if (t1 < INFINITY) push(r1);
             cur = t0 < INFINITY ? r0 : pop();
 #else
-            const uint32_t pair = cur >> 3;
-            const float4 lc = nodes[2 * pair], rc = nodes[2 * pair + 1];
-            L.cnt.add(ST_NODES, 2);
-#ifdef THX_EXTRA_LOADS // experiment: what do two more 16-B gathers per visit cost?
-            {
-                float4 x0 = nodes[2 * pair + 0 + THX_EXTRA_LOADS], x1 = nodes[2 * pair + 1 + THX_EXTRA_LOADS];
-                if (x0.x == 12345.678f || x1.x == 12345.678f) h.t = 0.0f;
-            }
-#endif
-            float tl = slabChild(lc, sr, h.t);
-            float tr = slabChild(rc, sr, h.t);
-#ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
-            {
-                float sink;
-#pragma unroll
-                for (int e = 0; e < THX_EXTRA_ISSUE; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(tl));
-            }
-#endif
-#ifdef THX_EXTRA_NOP // experiment: N x 16 cycles in which this wavefront issues nothing (latency, no issue slots)
-#pragma unroll
-            for (int e = 0; e < THX_EXTRA_NOP; ++e) asm volatile("s_nop 15");
-#endif
-#ifdef THX_EXTRA_VALU // experiment: is the walk bound by VALU issue? N dependent FMAs per visit that cannot be removed
-            {
-                float acc = tl;
-#pragma unroll
-                for (int e = 0; e < THX_EXTRA_VALU; ++e) acc = __builtin_fmaf(acc, 1.0000001f, tr);
-                if (acc == 12345.678f) h.t = 0.0f;
-            }
-#endif
-            const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
-            if (tl >= 0.0f && tr >= 0.0f) {
-                bool leftFirst = tl <= tr;
-                push(leftFirst ? mr : ml);
-                cur = leftFirst ? ml : mr;
-            } else if (tl >= 0.0f) {
-                cur = ml;
-            } else if (tr >= 0.0f) {
-                cur = mr;
-            } else {
-                cur = pop();
-            }
+            visitBranchy();
 #endif
             if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
         }
+#if !defined(THX_BVH4) && !defined(THX_BRANCHY_INNER)
+    innerDone:
+#endif
 #ifdef THX_STAGE_PROFILE
         const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
         pInner += pt1 - pt0;
