@@ -299,6 +299,33 @@ def test_parked_walks_change_nothing(hip_backend, scene, monkeypatch):
         assert np.abs(h - h0).max() <= 1e-5 * h0.sum(), name               # same hits, summed in another order
 
 
+@pytest.mark.parametrize("scene", ["config2", "config3", "suzanne-grid"])
+def test_walk_variants_change_nothing(hip_backend, scene, monkeypatch):
+    """The walk exists in several compiled forms the host picks by the scene (dev_trace.hpp: Variant, Walker<V, FAST>): pair
+    records read from a copy in LDS or through the vector cache, 16- or 32-bit stack entries, the whole stack in LDS or its
+    deep part in global memory (where a lane takes the branchy visit instead of the straight-line one). All of them walk the
+    same tree in the same order: every photon's events are the same bit for bit, and so are the traversal counters."""
+    make = {"config2": lambda: S.config2_sphere(batch=20000, stats=True, track=True),
+            "config3": lambda: S.config3_cube_torus(batch=20000, polarized=True, stats=True, track=True),
+            "suzanne-grid": lambda: S.config5_suzanne_grid(batch=20000, n_side=4, polarized=True, stats=True, track=True)}[scene]
+    runs = {}
+    for name, env in (("default", {}), ("records through the vector cache", {"THX_LDS_NODES": "0"}), ("records in LDS", {"THX_LDS_NODES": "1"}),
+                      ("32-bit stack entries", {"THX_STACK32": "1"}), ("3 stack entries in LDS", {"THX_STACK_LDS": "3", "THX_LDS_NODES": "0"}),
+                      ("32-bit entries, 2 of them in LDS", {"THX_STACK32": "1", "THX_STACK_LDS": "2"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            sc = make()
+            hist = S.run_batches(sc, 1)[0]
+            runs[name] = (hist, sc.tracer.program.read_stats(), sc.tracer.program.read_track(sc.tracer.batchSize))
+    h0, s0, t0 = runs["default"]
+    assert h0.sum() > 0 and s0[0] == 20000 and s0[10] == s0[11]  # every photon created; no error but media mismatches (suzanne.stl is not closed)
+    for name, (h, s, t) in runs.items():
+        assert np.array_equal(t0.view(np.uint32), t.view(np.uint32)), name
+        assert np.array_equal(s0[:20], s[:20]), name
+        assert np.abs(h - h0).max() <= 1e-5 * h0.sum(), name
+
+
 def _two_shells(batch, stats):
     """the two-media scene of the reference's energy test (tests/test_trace_energy.py: test_SceneForwardTracer_MultiMedia): a
     glass-like shell inside the detector sphere, paths of up to 50 steps that cross the shell again and again"""
