@@ -72,6 +72,15 @@ THX_DEV float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 // keeps the kernels comparable to the CPU oracle at the libm level. -DTHX_NATIVE_MATH
 // switches to the hardware approximations (v_sin/v_cos/v_exp/v_log based, what GLSL
 // drivers typically emit for the reference's shaders).
+// sine and cosine of one angle: the device library's sinf and cosf each compute both (one argument reduction, the pair of
+// polynomials, a selection by quadrant); sincosf does that once and returns the same two values
+#ifdef THX_NATIVE_MATH
+THX_DEV void thx_sincos(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
+#elif defined(THX_SEPARATE_SINCOS)
+THX_DEV void thx_sincos(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
+#else
+THX_DEV void thx_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
+#endif
 #ifdef THX_NATIVE_MATH
 THX_DEV float thx_sin(float x) { return __sinf(x); }
 THX_DEV float thx_cos(float x) { return __cosf(x); }
@@ -419,7 +428,9 @@ THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, 
 THX_DEV f3 scatterDir(f3 prevDir, float cos_theta, float phi) {
     prevDir = normalize(prevDir);
     float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
-    f3 local = f3{sin_theta * thx_cos(phi), sin_theta * thx_sin(phi), cos_theta};
+    float sp, cp;
+    thx_sincos(phi, sp, cp);
+    f3 local = f3{sin_theta * cp, sin_theta * sp, cos_theta};
     local = normalize(local);
     m3 trafo = createLocalCOSY(prevDir);
     return normalize(mul(trafo, local));
@@ -462,7 +473,9 @@ THX_DEV float scatterProb(uint64_t medium, f3 inDir, f3 outDir, Counters<ST>& cn
 // util.sample.glsl:10-17
 THX_DEV f3 sphericalToCartessian(float phi, float cos_theta) {
     float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
-    return f3{sin_theta * thx_sin(phi), sin_theta * thx_cos(phi), cos_theta};
+    float sp, cp;
+    thx_sincos(phi, sp, cp);
+    return f3{sin_theta * sp, sin_theta * cp, cos_theta};
 }
 
 } // namespace thx

@@ -618,7 +618,9 @@ THX_DEV f3 sampleUnitDisk(float u0, float u1) {
         r = ry;
         phi = 1.57079632679489661923f - 0.78539816339744830962f * (rx / ry);
     }
-    return f3{r * thx_cos(phi), r * thx_sin(phi), 0.0f};
+    float sp, cp;
+    thx_sincos(phi, sp, cp);
+    return f3{r * cp, r * sp, 0.0f};
 }
 THX_DEV m3 ldm3(const float* m) { // column major
     return m3{f3{m[0], m[1], m[2]}, f3{m[3], m[4], m[5]}, f3{m[6], m[7], m[8]}};
@@ -1835,7 +1837,9 @@ THX_DEV GuideSample sampleTargetGuide(Lane<V>& L, f3 observer) {
     float cosTheta = 1.0f - cosMin * draw(L);
     float sinTheta = sqrtf(fmaxf(1.0f - cosTheta * cosTheta, 0.0f));
     float phi = TWO_PI * draw(L);
-    f3 local = f3{sinTheta * thx_sin(phi), sinTheta * thx_cos(phi), cosTheta};
+    float sp, cp;
+    thx_sincos(phi, sp, cp);
+    f3 local = f3{sinTheta * sp, sinTheta * cp, cosTheta};
     GuideSample s;
     s.dir = mul(createLocalCOSY(viewDir), local);
     s.dist = d + g.radius;

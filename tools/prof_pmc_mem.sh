@@ -1,7 +1,8 @@
 #!/bin/bash
 # PMC passes over the memory path of the tracing kernel (vector cache, texture addresser, L2, instruction latencies):
 #   tools/prof_pmc_mem.sh <outdir-under-gpurun_out> [bench args...]
-# One counter set per pass, kernel-trace only (MI355X_MICROARCH.md: separate --pmc passes).
+# One counter set per pass, kernel-trace only (MI355X_MICROARCH.md: separate --pmc passes). (A pass over the TA_* counters
+# -- TA_TA_BUSY_sum, TA_ADDR_STALLED_BY_TC_CYCLES_sum ... -- never returned on this pool in round 3: left out.)
 set -u
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; shift
 mkdir -p $OUT
@@ -11,11 +12,10 @@ for set in \
   "SQ_INSTS_VMEM_RD SQ_INSTS_VMEM_WR SQ_INST_LEVEL_VMEM SQ_INSTS_LDS SQ_INST_LEVEL_LDS SQ_INSTS_SMEM SQ_INST_LEVEL_SMEM SQ_WAVE_CYCLES" \
   "TCP_TOTAL_CACHE_ACCESSES_sum TCP_TCC_READ_REQ_sum TCP_TCC_WRITE_REQ_sum TCP_TCC_READ_REQ_LATENCY_sum" \
   "TCP_PENDING_STALL_CYCLES_sum TCP_TA_TCP_STATE_READ_sum TCP_GATE_EN1_sum TCP_GATE_EN2_sum" \
-  "TA_TA_BUSY_sum TA_BUSY_avr TA_ADDR_STALLED_BY_TC_CYCLES_sum TA_DATA_STALLED_BY_TC_CYCLES_sum" \
   "TCC_REQ_sum TCC_HIT_sum TCC_MISS_sum TCC_READ_sum" \
   "TD_TD_BUSY_sum TCP_TCP_TA_DATA_STALL_CYCLES_sum TCP_TD_TCP_STALL_CYCLES_sum TCP_READ_TAGCONFLICT_STALL_CYCLES_sum"; do
   i=$((i+1))
-  rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed: $(tail -2 $OUT/pass$i.log | tr '\n' ' ')"
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $set --output-format csv -d $OUT/pass$i -- python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 "$@" > $OUT/pass$i.log 2>&1 || echo "pass $i failed: $(tail -2 $OUT/pass$i.log | tr '\n' ' ')"
 done
 python3 - "$OUT" <<'PY'
 import csv, glob, sys, collections, re

@@ -4,7 +4,7 @@
 OUT=$GRAFT_REPO_ROOT/gpurun_out/$1; W=$2
 mkdir -p $OUT; export TMPDIR=/tmp
 for c in FETCH_SIZE WRITE_SIZE; do
-  rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 --workload $W > $OUT/$c.log 2>&1 || echo "$c failed"
+  timeout -k 10 120 rocprofv3 --kernel-trace --pmc $c --output-format csv -d $OUT/$c -- python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 --workload $W > $OUT/$c.log 2>&1 || echo "$c failed"
 done
 python3 - "$OUT" "$W" <<'PY'
 import csv, glob, sys, collections, json
