@@ -443,7 +443,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         const bool pushA = dstA >= 0;
         uint32_t posA = 0, posB = 0;
         if (__ballot(pushA) != 0ull) {
+#ifdef THX_EARLY_RELEASE // round 2: the release fence in front of the reservation
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // stage data before the entries
+#endif
             if (pushA) posA = atomicAdd(&pool.ctr[cTail(dstA)], 1u);
             if (__ballot(hasB) != 0ull)
                 if (hasB) posB = atomicAdd(&pool.ctr[cTail(S_TS)], 1u);
@@ -514,7 +516,12 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
         if (claimCell != kNoCell) spec = ldsRead16(claimCell);
 
-        // ---- publish the entries of the finished stage
+        // ---- publish the entries of the finished stage. What the stage stored (cold chunks in global memory, hot chunks in
+        // LDS) has to be visible before an entry is: the release fence waits for those stores -- here, behind the two LDS round
+        // trips above, which need nothing of it (a reserved cell without its entry makes the claimer wait, not read).
+#ifndef THX_EARLY_RELEASE
+        __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
+#endif
         if (cellA != kNoCell) {
             for (uint32_t spin = 0; chkA != Q_EMPTY; ++spin) {
                 if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); break; }

@@ -1336,8 +1336,14 @@ struct Walker {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         const SceneView& sc = L.a->scene;
         org = o; dir = d;
-        wsr = qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir);
-        sr = wsr;
+        // A scene of one instance never walks in world space: its TLAS is one leaf, and the stage that queued the ray has
+        // tested the TLAS root box already (dev_staged.hpp: rootHit, the same test with the same distance) -- no world-space
+        // slab ray then, and no second root test for any scene.
+        const bool oneInstance = FAST && (sc.tlas.rootRef & 7u) != 0u;
+        if (!oneInstance) {
+            wsr = qRay(tlasFrame0(sc), tlasFrame1(sc), org, dir);
+            sr = wsr;
+        }
         ao = org;
         uint32_t n = 0;       // stack entries to refill (a ray taken up again)
         bool enter = false;   // fresh ray of a one-instance scene: goes straight into the instance
@@ -1354,7 +1360,7 @@ struct Walker {
             L.cnt.add(ST_QUERIES);
             inBlas = false; curInst = 0; overflow = false;
             L.cnt.add(ST_NODES);
-            cur = slabRoot(wsr, h.t) ? sc.tlas.rootRef : WALK_DONE;
+            cur = (FAST || slabRoot(wsr, h.t)) ? sc.tlas.rootRef : WALK_DONE;
             enter = cur != WALK_DONE && (cur & 7u) != 0u;
             if (enter) {
                 curInst = cur >> 3;
