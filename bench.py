@@ -294,8 +294,10 @@ def main() -> None:
     roof.update(m.roofline(m.steps_local))
     roof["note"] = ("bound = the north star's algorithmic-HBM contract: `achieved` = SURVEY.md 8(d) per-unit bytes x the counted units "
                     "(units_per_step) / kernel time; `achieved_layout` prices the same counts with the bytes this build's records "
-                    "actually move. The BASELINE scenes are cache resident (`traffic` = HBM bytes from PMC counters), so what limits "
-                    "the kernel is instruction issue of divergent code and gather latency, not HBM (DESIGN.md section 3.1)")
+                    "actually move (16 B per box, read from a copy in LDS on small scenes). The BASELINE scenes are cache resident "
+                    "(`traffic` = HBM bytes from PMC counters), so what limits the kernel is instruction issue of divergent code and "
+                    "its dependency chains, not HBM -- which is also why `frac` can exceed 1: the contract's bytes never have to "
+                    "come out of HBM (DESIGN.md sections 3.1 and 5)")
 
     result = {
         "metric": "Mphoton-steps/sec at 10^7 photons; achieved HBM GB/s vs roofline",
