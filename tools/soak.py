@@ -24,7 +24,12 @@ while time.time() - t0 < seconds:
     if gen.integers(2):
         knobs = {"THX_PARK_BELOW": str(int(gen.integers(0, 66))), "THX_PARK_ROUNDS": str(int(gen.integers(1, 5))),
                  "THX_STACK_LDS": str(int(gen.integers(2, 33)))}
-    for k in ("THX_PARK_BELOW", "THX_PARK_ROUNDS", "THX_STACK_LDS"):
+    # ... and which compiled form of the walk runs: pair records in LDS or not, 16- or 32-bit stack entries
+    if gen.integers(3) == 0:
+        knobs["THX_LDS_NODES"] = str(int(gen.integers(2)))
+    if gen.integers(4) == 0:
+        knobs["THX_STACK32"] = "1"
+    for k in ("THX_PARK_BELOW", "THX_PARK_ROUNDS", "THX_STACK_LDS", "THX_LDS_NODES", "THX_STACK32"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     sc = make(batch=n, stats=True, key=int(gen.integers(1 << 40)), **kw)
