@@ -28,6 +28,17 @@ from theia.target import InnerSphereTarget, SphereTargetGuide
 
 pytestmark = pytest.mark.gpu
 
+
+def CASES(table):
+    """(argument names, rows) of one case table of tests/golden/energy_cases.json: the reference's own cases and tolerances"""
+    import json
+    import os
+
+    with open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "energy_cases.json"), encoding="utf-8") as fh:
+        t = json.load(fh)[table]
+    rows = [tuple(float("nan") if v is None else v for v in row) for row in t["rows"]]
+    return ",".join(t["columns"]), rows
+
 LAMBDA, T_EMIT = 400.0 * u.nm, 10.0 * u.ns
 OFF_CENTRE = (12.0, 15.0, 0.2) * u.m
 Mi = 1024 * 1024
@@ -89,8 +100,7 @@ def assert_stokes_valid(stokes):
     assert np.all(np.square(stokes[:, 1:]).sum(-1) <= 1.0 + 1e-6)
 
 
-@pytest.mark.parametrize("mu_a,mu_s,g,polarized", [(0.0, 0.005, 0.0, False), (0.05, 0.01, 0.0, False), (0.05, 0.01, -0.9, False),
-                                                   (0.05, 0.01, 0.9, False), (0.0, 0.005, 0.0, True), (0.05, 0.01, -0.9, True)])
+@pytest.mark.parametrize(*CASES("scene_ground_truth"))
 def test_scene_ground_truth(mu_a, mu_s, g, polarized):
     """light at the centre of a 100 m detector sphere full of scattering medium: with the absorption
     undone all of the budget arrives (5 %, from below: longer paths are cut), uniformly over the sphere"""
@@ -113,8 +123,7 @@ def test_scene_ground_truth(mu_a, mu_s, g, polarized):
         assert_stokes_valid(column("stokes"))
 
 
-@pytest.mark.parametrize("mu_a,mu_s,g,polarized", [(0.0, 0.01, 0.0, False), (0.05, 0.005, 0.5, False), (0.0, 0.01, 0.0, True),
-                                                   (0.05, 0.005, -0.5, True)])
+@pytest.mark.parametrize(*CASES("scene_crosscheck"))
 def test_scene_crosscheck(mu_a, mu_s, g, polarized):
     """5 m detector sphere at the origin, light 6 m off: paths of length 10 with target-guide MIS
     against plain paths of length 20 (2 % in total, 1 % in the mean relative error of the log curves;
@@ -160,17 +169,7 @@ def test_scene_multi_media(polarized):
     assert abs(mean_curve(tracer, response, tasks).sum() / budget - 1.0) < 0.0061
 
 
-VOLUME_ROWS = [  # mu_a, mu_s, sampling coefficient, g, no direct light, target sampling, polarized, tolerance
-    (0.0, 0.005, 0.05, 0.0, False, True, False, 4.5e-4), (0.0, 0.005, 0.05, 0.0, False, False, False, 0.011),
-    (0.0, 0.005, 0.05, 0.0, True, True, False, 0.011), (0.05, 0.01, 0.05, 0.0, False, True, False, 1.8e-3),
-    (0.05, 0.01, 0.05, 0.0, True, True, False, 2.6e-3), (0.05, 0.01, 0.05, -0.9, False, True, False, 0.012),
-    (0.05, 0.01, 0.05, 0.9, True, True, False, 2.8e-4), (0.05, 0.01, 0.05, 0.9, True, False, False, 2.9e-3),
-    (0.05, 0.01, np.nan, 0.9, False, True, True, 2.9e-3), (0.0, 0.005, 0.05, 0.0, False, True, True, 5e-4),
-    (0.0, 0.005, 0.05, 0.0, True, True, True, 1.2e-3), (0.05, 0.01, 0.05, -0.9, False, True, True, 0.012),
-]
-
-
-@pytest.mark.parametrize("mu_a,mu_s,mu_sample,g,no_direct,sample_target,polarized,tol", VOLUME_ROWS)
+@pytest.mark.parametrize(*CASES("volume"))
 def test_volume_energy(mu_a, mu_s, mu_sample, g, no_direct, sample_target, polarized, tol):
     """light at the centre of a 100 m InnerSphereTarget: the budget (minus the unscattered share when
     direct light is off) arrives once absorption is undone"""
@@ -200,11 +199,6 @@ def test_volume_energy(mu_a, mu_s, mu_sample, g, no_direct, sample_target, polar
         assert_stokes_valid(np.concatenate(acc["stokes"]))
 
 
-# the reference leaves (0.0, 0.05, 0.0, polarized) out: "Polarization seems broken for now"
-PHOTON_ROWS = [(0.0, 0.05, 0.0, False), (0.05, 0.05, 0.0, False), (0.05, 0.01, -0.9, False), (0.05, 0.01, 0.9, False),
-               (0.05, 0.01, -0.9, True)]
-
-
 def assert_photon_count(count, expected, budget, mu_a):
     if mu_a != 0.0:  # a count of random survivors: 5 sigma
         assert abs(count - expected) < 5.0 * np.sqrt(expected)
@@ -212,7 +206,7 @@ def assert_photon_count(count, expected, budget, mu_a):
         assert count == int(budget)
 
 
-@pytest.mark.parametrize("mu_a,mu_s,g,polarized", PHOTON_ROWS)
+@pytest.mark.parametrize(*CASES("photon"))
 def test_scene_photon_tracer(mu_a, mu_s, g, polarized):
     """photons a ScenePhotonTracer detects (one batch of 10^6, 20 runs x 5 steps) against the light
     curve integral of the SceneForwardTracer (20 Mi paths of length 80) in a 60 m detector sphere"""
@@ -233,7 +227,7 @@ def test_scene_photon_tracer(mu_a, mu_s, g, polarized):
     assert_photon_count(stored.result(0).count, expected, budget, mu_a)
 
 
-@pytest.mark.parametrize("mu_a,mu_s,g,polarized", PHOTON_ROWS)
+@pytest.mark.parametrize(*CASES("photon"))
 def test_volume_photon_tracer(mu_a, mu_s, g, polarized):
     """the same for the VolumePhotonTracer (40 runs x 5 steps) inside a 60 m InnerSphereTarget against
     the VolumeForwardTracer with target sampling"""
