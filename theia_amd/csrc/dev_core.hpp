@@ -303,23 +303,64 @@ THX_DEV float lookUp(uint64_t table, float u, float nullValue, Counters<ST>& cnt
     return samples[lo] * (1.0f - l) + samples[hi] * l;
 }
 
+// The same look-up cut into its dependent load levels (round 3). lookUp() above is three round trips to memory in a
+// row -- table pointer, header, samples -- each behind a branch on "no table", and a medium look-up was four of those one
+// after the other (the compiler cannot move a load across the branch that guards it): twelve exposed round trips at the
+// birth of a photon, six per scatter, twelve more per polarized scatter, at 300-600 cycles each. Here a null table reads
+// a dummy region instead of branching (its result is selected away), so the loads of one level of ALL the tables a
+// function needs are independent instructions in straight-line code and go out together: three round trips for a medium
+// look-up, four for a scatter (two tables, the second indexed by the first's result). Same arithmetic on the same values:
+// results are bit for bit those of lookUp().
+static __device__ uint32_t thx_null_region[32]; // what the loads of a "null" table / the vacuum medium read (never used)
+struct TableRef {
+    const THX_GLOBAL float* samples; // samples[0]
+    float nm1;                       // float(n - 1); 0 for a null table (index 0 then)
+    bool null_;
+};
+// level 2: the header of the table at address `table` (0: null)
+THX_DEV TableRef tableRef(uint64_t table) {
+    const bool isNull = table == 0;
+    const THX_GLOBAL int32_t* hdr = reinterpret_cast<const THX_GLOBAL int32_t*>(isNull ? (uint64_t)(uintptr_t)thx_null_region : table);
+    const int32_t n = hdr[0];
+    return TableRef{reinterpret_cast<const THX_GLOBAL float*>(hdr + 1), isNull ? 0.0f : (float)(n - 1), isNull};
+}
+// level 3: lookup.glsl:14-28 on a table whose header is known
+template <bool ST>
+THX_DEV float lookUpRef(const TableRef& t, float u, float nullValue, Counters<ST>& cnt) {
+    cnt.add(ST_LUT, t.null_ ? 0u : 1u);
+    u = clampf(u, 0.0f, 1.0f); // (also turns a NaN from the dummy medium's wavelength range into 0)
+    u *= t.nm1;
+    float fl = floorf(u);
+    int lo = (int)fl;
+    int hi = (int)ceilf(u);
+    float l = u - fl;
+    const float v = t.samples[lo] * (1.0f - l) + t.samples[hi] * l;
+    return t.null_ ? nullValue : v;
+}
+// the medium record a pointer stands for; vacuum (0) reads the dummy region and reports every table as null
+THX_DEV const THX_GLOBAL MediumGLSL* mediumRecord(uint64_t medium) {
+    return reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium == 0 ? (uint64_t)(uintptr_t)thx_null_region : medium);
+}
+
 // material.glsl:37-39
 THX_DEV float normalize_lambda(const THX_GLOBAL MediumGLSL* m, float lambda) {
     return clampf((lambda - m->lambda_min) / (m->lambda_max - m->lambda_min), 0.0f, 1.0f);
 }
 
-// material.glsl:50-74
+// material.glsl:50-74 (vacuum = the null medium: n = 1, vg = c, no scattering, no absorption -- what four null tables give)
 template <bool ST>
 THX_DEV MediumConstants lookUpMedium(uint64_t medium, float lambda, Counters<ST>& cnt) {
-    if (medium == 0) return MediumConstants{1.0f, SPEED_OF_LIGHT, 0.0f, 0.0f};
-    const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
-    float u = normalize_lambda(m, lambda);
-    float mu_a = lookUp(m->mu_a, u, 0.0f, cnt);
-    float mu_s = lookUp(m->mu_s, u, 0.0f, cnt);
+    const bool vac = medium == 0;
+    const THX_GLOBAL MediumGLSL* m = mediumRecord(medium);
+    const float u = normalize_lambda(m, lambda);
+    const uint64_t ta = m->mu_a, ts = m->mu_s, tn = m->n, tv = m->vg;                                     // level 1
+    const TableRef ra = tableRef(vac ? 0 : ta), rs = tableRef(vac ? 0 : ts), rn = tableRef(vac ? 0 : tn), rv = tableRef(vac ? 0 : tv); // level 2
+    const float mu_a = lookUpRef(ra, u, 0.0f, cnt);                                                        // level 3
+    const float mu_s = lookUpRef(rs, u, 0.0f, cnt);
     MediumConstants c;
     c.mu_e = mu_a + mu_s;
-    c.n = lookUp(m->n, u, 1.0f, cnt);
-    c.vg = lookUp(m->vg, u, SPEED_OF_LIGHT, cnt);
+    c.n = lookUpRef(rn, u, 1.0f, cnt);
+    c.vg = lookUpRef(rv, u, SPEED_OF_LIGHT, cnt);
     c.mu_s = mu_s;
     return c;
 }
@@ -386,15 +427,16 @@ THX_DEV float mfmaDiag(v4f acc) {
 template <bool ST>
 THX_DEV f4 phaseRotateApply(uint64_t medium, float cos_theta, float c, float s, f4 v,
                             Counters<ST>& cnt) {
-    float m12 = 0.0f, m22 = 1.0f, m33 = 1.0f, m34 = 0.0f;
-    if (medium != 0) {
-        const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
-        float t = 0.5f * (cos_theta + 1.0f);
-        m12 = lookUp(m->phase_m12, t, 0.0f, cnt);
-        m22 = lookUp(m->phase_m22, t, 0.0f, cnt);
-        m33 = lookUp(m->phase_m33, t, 0.0f, cnt);
-        m34 = lookUp(m->phase_m34, t, 0.0f, cnt);
-    }
+    // (vacuum: the identity; a medium without one of the tables: 0 for that element, as lookUp() gives)
+    const bool vac = medium == 0;
+    const THX_GLOBAL MediumGLSL* m = mediumRecord(medium);
+    const uint64_t t12 = m->phase_m12, t22 = m->phase_m22, t33 = m->phase_m33, t34 = m->phase_m34;                                  // level 1
+    const TableRef r12 = tableRef(vac ? 0 : t12), r22 = tableRef(vac ? 0 : t22), r33 = tableRef(vac ? 0 : t33), r34 = tableRef(vac ? 0 : t34); // level 2
+    const float t = 0.5f * (cos_theta + 1.0f);
+    const float m12 = lookUpRef(r12, t, 0.0f, cnt);                                                                                   // level 3
+    const float m22 = vac ? 1.0f : lookUpRef(r22, t, 0.0f, cnt);
+    const float m33 = vac ? 1.0f : lookUpRef(r33, t, 0.0f, cnt);
+    const float m34 = lookUpRef(r34, t, 0.0f, cnt);
     f4 o;
 #ifdef THX_MUELLER_MFMA
     // M = phase * rotate, row by row (zero entries skipped: rows 0, 1 have no column 3, rows 2, 3 no column 0);
@@ -436,38 +478,65 @@ THX_DEV f3 scatterDir(f3 prevDir, float cos_theta, float phi) {
     return normalize(mul(trafo, local));
 }
 
+// The two tables a scatter reads (inverse CDF of cos theta, log phase function), pointers and headers loaded once per stage
+// and shared by sampleScatterDir() and scatterProb() (the MIS stage evaluates the phase function twice).
+struct ScatterTabs {
+    TableRef sampling, logPhase;
+    bool canSample, hasPhase; // medium != 0 && phase_sampling != 0; medium != 0 && log_phase != 0
+};
+THX_DEV ScatterTabs scatterTabs(uint64_t medium) {
+    const bool vac = medium == 0;
+    const THX_GLOBAL MediumGLSL* m = mediumRecord(medium);
+    const uint64_t ts = m->phase_sampling, tl = m->log_phase; // level 1
+    ScatterTabs t;
+    t.canSample = !vac && ts != 0;
+    t.hasPhase = !vac && tl != 0;
+    t.sampling = tableRef(t.canSample ? ts : 0);             // level 2
+    t.logPhase = tableRef(t.hasPhase ? tl : 0);
+    return t;
+}
+
 // scatter.volume.glsl:28-45
 template <bool ST>
-THX_DEV float sampleScatterDir(uint64_t medium, float u0, float u1, float& cos_theta, float& phi,
-                               Counters<ST>& cnt) {
+THX_DEV float sampleScatterDir(const ScatterTabs& t, float u0, float u1, float& cos_theta, float& phi, Counters<ST>& cnt) {
     phi = u0 * TWO_PI;
-    const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
-    if (medium != 0 && m->phase_sampling != 0) {
-        float ct = lookUp(m->phase_sampling, u1, 0.0f, cnt);
-        ct = clampf(ct, -1.0f, 1.0f);
-        cos_theta = ct;
-        return thx_exp(lookUp(m->log_phase, 0.5f * (ct + 1.0f), 0.0f, cnt));
-    }
-    cos_theta = 2.0f * u1 - 1.0f;
-    return INV_4PI;
+    float ct = lookUpRef(t.sampling, u1, 0.0f, cnt);
+    ct = clampf(ct, -1.0f, 1.0f);
+    // (a medium with a sampling table but no phase table: lookUp() of the null table gives 0, exp(0) = 1; without a sampling
+    // table the phase table is not read)
+    TableRef lp = t.logPhase;
+    lp.null_ = lp.null_ || !t.canSample;
+    const float p = thx_exp(lookUpRef(lp, 0.5f * (ct + 1.0f), 0.0f, cnt));
+    cos_theta = t.canSample ? ct : 2.0f * u1 - 1.0f;
+    return t.canSample ? p : INV_4PI;
+}
+template <bool ST>
+THX_DEV float sampleScatterDir(uint64_t medium, float u0, float u1, float& cos_theta, float& phi, Counters<ST>& cnt) {
+    return sampleScatterDir(scatterTabs(medium), u0, u1, cos_theta, phi, cnt);
 }
 
 // scatter.volume.glsl:47-52
 template <bool ST>
-THX_DEV f3 scatter(uint64_t medium, f3 inDir, float u0, float u1, float& p, Counters<ST>& cnt) {
+THX_DEV f3 scatter(const ScatterTabs& t, f3 inDir, float u0, float u1, float& p, Counters<ST>& cnt) {
     float cos_theta, phi;
-    p = sampleScatterDir(medium, u0, u1, cos_theta, phi, cnt);
+    p = sampleScatterDir(t, u0, u1, cos_theta, phi, cnt);
     return scatterDir(inDir, cos_theta, phi);
+}
+template <bool ST>
+THX_DEV f3 scatter(uint64_t medium, f3 inDir, float u0, float u1, float& p, Counters<ST>& cnt) {
+    return scatter(scatterTabs(medium), inDir, u0, u1, p, cnt);
 }
 
 // scatter.volume.glsl:54-65
 template <bool ST>
-THX_DEV float scatterProb(uint64_t medium, f3 inDir, f3 outDir, Counters<ST>& cnt) {
-    const THX_GLOBAL MediumGLSL* m = reinterpret_cast<const THX_GLOBAL MediumGLSL*>(medium);
-    if (medium == 0 || m->log_phase == 0) return INV_4PI;
+THX_DEV float scatterProb(const ScatterTabs& t, f3 inDir, f3 outDir, Counters<ST>& cnt) {
     float cos_theta = dot(inDir, outDir);
-    float log_p = lookUp(m->log_phase, 0.5f * (cos_theta + 1.0f), 0.0f, cnt);
-    return thx_exp(log_p);
+    float log_p = lookUpRef(t.logPhase, 0.5f * (cos_theta + 1.0f), 0.0f, cnt);
+    return t.hasPhase ? thx_exp(log_p) : INV_4PI;
+}
+template <bool ST>
+THX_DEV float scatterProb(uint64_t medium, f3 inDir, f3 outDir, Counters<ST>& cnt) {
+    return scatterProb(scatterTabs(medium), inDir, outDir, cnt);
 }
 
 // util.sample.glsl:10-17

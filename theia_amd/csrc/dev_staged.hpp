@@ -832,12 +832,13 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 float pPP;
                 float u0, u1;
                 draw2(L, u0, u1); // random2D
-                f3 dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
+                const ScatterTabs tabs = scatterTabs(ray.medium); // both phase-function evaluations of this stage share the table headers
+                f3 dirPhase = scatter(tabs, ray.direction, u0, u1, pPP, L.cnt);
                 GuideSample ts = sampleTargetGuide(L, ray.position);
                 float pTT = ts.prob;
                 GuideSample ps = evalTargetGuide(args.p.guide, ray.position, dirPhase, args.flags);
                 float pTP = ps.prob;
-                float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
+                float pPT = scatterProb(tabs, ray.direction, ts.dir, L.cnt);
                 float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
                 float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
                 pool.sc[0 * P + slot] = make_float4(dirPhase.x, dirPhase.y, dirPhase.z, wPhase);

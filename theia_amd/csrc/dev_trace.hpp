@@ -794,12 +794,13 @@ THX_DEV void volSampleTargetMIS(Lane<V>& L, const Ray& ray, uint64_t med) {
     float pPP;
     float u0, u1;
     draw2(L, u0, u1); // random2D
-    f3 dirPhase = scatter(med, dir, u0, u1, pPP, L.cnt);
+    const ScatterTabs tabs = scatterTabs(med);
+    f3 dirPhase = scatter(tabs, dir, u0, u1, pPP, L.cnt);
     TargetSample phaseHit = intersectTarget(tg, obs, dirPhase, L.a->flags);
     TargetSample targetHit = sampleTarget(L, tg, obs, L.a->flags);
     f3 dirTarget = normalize(targetHit.position - obs);
     float pTT = targetHit.prob * jacobian_dAdW(obs, targetHit.position, targetHit.normal);
-    float pPT = scatterProb(med, dir, dirTarget, L.cnt);
+    float pPT = scatterProb(tabs, dir, dirTarget, L.cnt);
     float pTP = phaseHit.prob * jacobian_dAdW(obs, phaseHit.position, phaseHit.normal);
     float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
     float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
@@ -2046,12 +2047,13 @@ THX_DEV bool sceneStep(Lane<V>& L, Ray& ray, uint32_t& step, bool& allowResponse
                     float pPP;
                     float u0, u1;
                     draw2(L, u0, u1); // random2D
-                    dirPhase = scatter(ray.medium, ray.direction, u0, u1, pPP, L.cnt);
+                    const ScatterTabs tabs = scatterTabs(ray.medium);
+                    dirPhase = scatter(tabs, ray.direction, u0, u1, pPP, L.cnt);
                     GuideSample ts = sampleTargetGuide(L, ray.position);
                     float pTT = ts.prob;
                     GuideSample ps = evalTargetGuide(A.p.guide, ray.position, dirPhase, A.flags);
                     float pTP = ps.prob;
-                    float pPT = scatterProb(ray.medium, ray.direction, ts.dir, L.cnt);
+                    float pPT = scatterProb(tabs, ray.direction, ts.dir, L.cnt);
                     wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
                     wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
                     dirTarget = ts.dir;
