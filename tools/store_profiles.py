@@ -1,0 +1,32 @@
+#!/usr/bin/env python3
+"""Copies what tools/prof_round.sh left under gpurun_out/<tag>/ into profiles/ under the round's names:
+   tools/store_profiles.py <tag> <round, e.g. r03>"""
+import json, os, shutil, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, rnd = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", tag)
+dst = os.path.join(ROOT, "profiles")
+shutil.copy(os.path.join(src, "bench.json"), os.path.join(dst, f"{rnd}_bench_1e7.json"))
+shutil.copy(os.path.join(src, "kernel_stats.csv"), os.path.join(dst, f"{rnd}_bench_1e7_kernel_stats.csv"))
+note = (f"gpurun {tag} (kernels of round {rnd[1:].lstrip('0')}): tools/prof_traffic.sh (separate FETCH_SIZE / WRITE_SIZE passes over `bench.py --workload W --steps 3`), "
+        "2 x FETCH_SIZE (gfx950 correction of MI355X_MICROARCH.md) + WRITE_SIZE, KB per launch of 10^7 photons, production kernel. The writes are the cold-state "
+        "stores of the shading stages and the records of walks set aside, written back by the L2.")
+out = {}
+for w in ("config2", "config3", "config5", "bigmesh"):
+    f = os.path.join(src, f"traffic_{w}.json")
+    if not os.path.exists(f):
+        continue
+    d = json.loads(open(f).read().strip().splitlines()[-1])[w]
+    out[w] = {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "FETCH_SIZE_KB": round(d["FETCH_SIZE_KB"], 1), "WRITE_SIZE_KB": round(d["WRITE_SIZE_KB"], 1), "source": note}
+json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
+with open(os.path.join(dst, f"{rnd}_pmc_staged.txt"), "w") as fh:
+    fh.write("rocprofv3 --pmc (three passes, kernel-trace only) over `python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 [--workload W]`, MI355X,\n"
+             f"10^7 photons per launch; per-launch means, tools/prof_pmc_quick.sh (tools/prof_round.sh {tag}). \"staged\" = production kernel, \"staged_debug\" = instrumented.\n"
+             "Derived: lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_INSTS_VALU); vector instructions per SIMD and cycle = SQ_INSTS_VALU / (1024 SIMDs x kernel time x 2.4 GHz),\n"
+             "to be held against the 1.8-2.95 cycles per instruction a SIMD needs with four wavefronts resident (profiles/r03_valu_rates.txt).\n\n")
+    for w in ("config2", "config3", "config5"):
+        f = os.path.join(src, f"pmc_{w}.txt")
+        if os.path.exists(f):
+            fh.write(w + "\n" + "".join(l for l in open(f) if l.strip()) + "\n")
+b = json.load(open(os.path.join(src, "bench.json")))
+print("bench:", round(b["value"], 1), "Mphoton-steps/s, kernel", round(b["roofline"]["kernel_ms"], 3), "ms; traffic", {k: v["hbm_bytes_per_launch"] for k, v in out.items()})
