@@ -500,11 +500,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         // ===== LDS round trip 2: are my ring cells empty (they are, unless the claimer of the
         // previous lap is ~10^4 cycles late), the claim itself (CAS on the ring head), and,
         // speculatively, the entries the claim would give this wavefront.
-        uint32_t chkA = Q_EMPTY, chkB = Q_EMPTY, casOld = 0, spec = Q_EMPTY;
-        if (cellA != kNoCell) chkA = ldsRead16(cellA);
-        if (cellB != kNoCell) chkB = ldsRead16(cellB);
-        if (lane == 0 && n0 > 0u) casOld = atomicCAS(&pool.ctr[cHead((int)qa)], ha, ha + n0);
-        if (lane == 1 && n1 > 0u) casOld = atomicCAS(&pool.ctr[cHead(S_TS)], hb, hb + n1);
+        uint32_t casOld = 0;
         uint32_t claimCell = kNoCell;
         uint32_t wantTag = 0;
         if (lane < n0) {
@@ -514,7 +510,17 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             claimCell = pool.queue(S_TS) + ((hb + (lane - n0)) & pool.mask(S_TS));
             wantTag = pool.lapTag(S_TS, hb + (lane - n0));
         }
-        if (claimCell != kNoCell) spec = ldsRead16(claimCell);
+        // (the three reads go out together, for every lane: a lane without a cell reads an unused counter word -- as reads
+        // inside `if`s each of them was a branch with its own wait for the LDS, three round trips instead of one)
+        const uint32_t noCell = 2u * (pool.ctrWord + 24u);
+        uint32_t chkA = ldsRead16(cellA != kNoCell ? cellA : noCell);
+        uint32_t chkB = ldsRead16(cellB != kNoCell ? cellB : noCell);
+        uint32_t spec = ldsRead16(claimCell != kNoCell ? claimCell : noCell);
+        if (lane == 0 && n0 > 0u) casOld = atomicCAS(&pool.ctr[cHead((int)qa)], ha, ha + n0);
+        if (lane == 1 && n1 > 0u) casOld = atomicCAS(&pool.ctr[cHead(S_TS)], hb, hb + n1);
+        chkA = cellA != kNoCell ? chkA : Q_EMPTY;
+        chkB = cellB != kNoCell ? chkB : Q_EMPTY;
+        spec = claimCell != kNoCell ? spec : Q_EMPTY;
 
         // ---- publish the entries of the finished stage. What the stage stored (cold chunks in global memory, hot chunks in
         // LDS) has to be visible before an entry is: the release fence waits for those stores -- here, behind the two LDS round
