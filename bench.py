@@ -290,7 +290,16 @@ def main() -> None:
         except Exception:
             traffic = None
 
-    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic}
+    # what the vector units were doing, from the committed PMC passes (like `traffic`: collected separately, not in this run)
+    issue = None
+    ifile = os.path.join(ROOT, "profiles", "issue.json")
+    if os.path.exists(ifile):
+        try:
+            issue = json.load(open(ifile)).get(args.workload)
+        except Exception:
+            issue = None
+
+    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "issue": issue}
     roof.update(m.roofline(m.steps_local))
     roof["note"] = ("bound = the north star's algorithmic-HBM contract: `achieved` = SURVEY.md 8(d) per-unit bytes x the counted units "
                     "(units_per_step) / kernel time; `achieved_layout` prices the same counts with the bytes this build's records "

@@ -28,5 +28,25 @@ with open(os.path.join(dst, f"{rnd}_pmc_staged.txt"), "w") as fh:
         f = os.path.join(src, f"pmc_{w}.txt")
         if os.path.exists(f):
             fh.write(w + "\n" + "".join(l for l in open(f) if l.strip()) + "\n")
+# what the vector units do, per workload: derived from the PMC passes and the kernel times of the bench line
+import re
 b = json.load(open(os.path.join(src, "bench.json")))
+kernel_ms = {"config2": b["roofline"]["kernel_ms"]}
+for sec in b.get("secondary", []):
+    kernel_ms["config3" if "config 3" in sec["workload"] else "config5"] = sec["kernel_ms"]
+issue = {}
+for w in ("config2", "config3", "config5"):
+    f = os.path.join(src, f"pmc_{w}.txt")
+    if not os.path.exists(f) or w not in kernel_ms:
+        continue
+    t = open(f).read()
+    st = t[t.index("== staged\n"):]
+    g = lambda n: float(re.search(n + r"\s+n=\s*\d+ mean=([0-9.e+]+)", st).group(1))
+    valu, thr = g("SQ_INSTS_VALU"), g("SQ_THREAD_CYCLES_VALU")
+    cycles = kernel_ms[w] * 1e-3 * 2.4e9 * 1024  # SIMD cycles of the launch at the 2.4 GHz peak clock
+    issue[w] = {"vector_instructions": valu, "scalar_instructions": g("SQ_INSTS_SALU"), "vector_memory_reads": g("SQ_INSTS_VMEM_RD"),
+                "lds_instructions": g("SQ_INSTS_LDS"), "lane_utilisation": thr / (64.0 * valu), "simd_cycles_per_vector_instruction": cycles / valu,
+                "source": f"profiles/{rnd}_pmc_staged.txt (rocprofv3 --pmc, production kernel, per launch of 10^7 photons); a SIMD with four wavefronts "
+                          "resident issues a vector instruction every 1.8-2.95 cycles depending on its encoding (profiles/r03_valu_rates.txt)"}
+json.dump(issue, open(os.path.join(dst, "issue.json"), "w"), indent=1)
 print("bench:", round(b["value"], 1), "Mphoton-steps/s, kernel", round(b["roofline"]["kernel_ms"], 3), "ms; traffic", {k: v["hbm_bytes_per_launch"] for k, v in out.items()})
