@@ -303,15 +303,17 @@ def test_parked_walks_change_nothing(hip_backend, scene, monkeypatch):
 def test_walk_variants_change_nothing(hip_backend, scene, monkeypatch):
     """The walk exists in several compiled forms the host picks by the scene (dev_trace.hpp: Variant, Walker<V, FAST>): pair
     records read from a copy in LDS or through the vector cache, 16- or 32-bit stack entries, the whole stack in LDS or its
-    deep part in global memory (where a lane takes the branchy visit instead of the straight-line one). All of them walk the
-    same tree in the same order: every photon's events are the same bit for bit, and so are the traversal counters."""
+    deep part in global memory (where a lane takes the branchy visit instead of the straight-line one); the scheduler's rings are
+    as long as the pool or the next power of two. All of them trace the same photons through the same tree in the same order:
+    every photon's events are the same bit for bit, and so are the traversal counters."""
     make = {"config2": lambda: S.config2_sphere(batch=20000, stats=True, track=True),
             "config3": lambda: S.config3_cube_torus(batch=20000, polarized=True, stats=True, track=True),
             "suzanne-grid": lambda: S.config5_suzanne_grid(batch=20000, n_side=4, polarized=True, stats=True, track=True)}[scene]
     runs = {}
     for name, env in (("default", {}), ("records through the vector cache", {"THX_LDS_NODES": "0"}), ("records in LDS", {"THX_LDS_NODES": "1"}),
                       ("32-bit stack entries", {"THX_STACK32": "1"}), ("3 stack entries in LDS", {"THX_STACK_LDS": "3", "THX_LDS_NODES": "0"}),
-                      ("32-bit entries, 2 of them in LDS", {"THX_STACK32": "1", "THX_STACK_LDS": "2"})):
+                      ("32-bit entries, 2 of them in LDS", {"THX_STACK32": "1", "THX_STACK_LDS": "2"}),
+                      ("rings of a power of two", {"THX_RING_POW2": "1"})):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)

@@ -69,6 +69,8 @@ struct thx_tracer {
     uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_trace.hpp: Walker::save)
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
+    bool exactRings = false;      // staged kernel: ring capacity = pool rounded up to 64 (else: to a power of two)
+    uint32_t ringCap = 0;         // staged kernel: cells per ring
     size_t ldsNodeBytes = 0;      // staged kernel: LDS copy of the scene's pair records (0: the walk reads them through the vector cache)
     size_t ldsNodeOffset = 0;     // ... and its byte offset in the workgroup's LDS
     uint32_t block = kTraceBlock;
@@ -427,11 +429,21 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // Deep scenes (large per-thread stacks) leave a pool much smaller than the workgroup:
         // batches run half empty then. Fewer wavefronts with fuller batches win while the pool
         // holds less than 3/4 photon per thread.
-        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block);
+        // Rings of exactly the pool's size (rounded up to 64) instead of the next power of two: their positions are turned
+        // into cells by a reciprocal multiplication that is exact below 2^25 appends per ring and launch; a generous bound
+        // on those -- photons of the busiest workgroup x steps x 16 (two shadow rays, walks set aside and taken up again)
+        // -- decides (THX_RING_POW2=1 forces the power of two). The kernel checks its ring counters against the limit.
+        {
+            const uint64_t perWg = std::max<uint64_t>(((uint64_t)desc->capacity + ctx->prop.multiProcessorCount - 1) / (uint64_t)ctx->prop.multiProcessorCount, kPoolBest);
+            t->exactRings = perWg * (uint64_t)(desc->path_length + 2) * 16u < (1ull << 25);
+            if (const char* env = std::getenv("THX_RING_POW2")) t->exactRings = t->exactRings && std::atoi(env) == 0;
+        }
+        const bool xr = t->exactRings;
+        t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0, xr);
         if (!std::getenv("THX_THREADS"))
             while (t->block > 512 && 4u * t->pool < 3u * t->block) {
                 t->block -= 128;
-                t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block);
+                t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0, xr);
             }
         t->pool = std::min(t->pool, kPoolBest);
         if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in ...
@@ -440,7 +452,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // (THX_LDS_NODES=0 / 1: never / whenever it fits at all)
         if ((t->mode & 8u) && t->block == kStagedBlock) {
             const size_t nodeBytes = (size_t)scene->nPairs * sizeof(NodePair);
-            const uint32_t poolN = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, nodeBytes);
+            const uint32_t poolN = std::min(stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, nodeBytes, xr), kPoolBest);
             bool use = nodeBytes <= kLdsNodeMaxBytes && poolN >= kLdsNodeMinPool;
             if (const char* env = std::getenv("THX_LDS_NODES")) use = std::atoi(env) != 0 && nodeBytes + 32 * 1024 <= budget && poolN >= 128;
             if (use) {
@@ -450,16 +462,17 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
             }
         }
         if (const char* env = std::getenv("THX_POOL")) t->pool = (uint32_t)std::min(2048, std::max(64, std::atoi(env)));
-        t->ldsNodeOffset = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block);
-        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodeBytes);
+        t->ringCap = stagedRingCap(t->pool, xr);
+        t->ldsNodeOffset = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, 0, xr);
+        t->lds = stagedLdsBytes(pol, desc->n_bins, stackBytes, t->pool, t->block, t->ldsNodeBytes, xr);
         if (t->lds > budget + 2048) { delete t; return fail(THX_ERR_INVALID, "THX_POOL does not fit the LDS of a compute unit"); }
     } else {
         t->stackLds = t->stackDepth;
         t->lds = traceLdsBytes(desc->kind, desc->n_bins, t->block, t->stackDepth, t->stack16);
     }
     if (std::getenv("THX_VERBOSE"))
-        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u stackDepth=%u (LDS %u) stack16=%d ldsNodes=%zu B\n",
-                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->stackDepth, t->stackLds, (int)t->stack16, t->ldsNodeBytes);
+        std::fprintf(stderr, "[thx] tracer kind=%u pol=%d staged=%d block=%u lds=%zu pool=%u rings=%u stackDepth=%u (LDS %u) stack16=%d ldsNodes=%zu B\n",
+                     (unsigned)desc->kind, (int)pol, (int)t->staged, t->block, t->lds, t->pool, t->ringCap, t->stackDepth, t->stackLds, (int)t->stack16, t->ldsNodeBytes);
     // replay streams its queue once: a few workgroups per CU hide the load latency
     int perCU = replay ? 8 : t->variant.occupancy(t->mode, t->block, t->lds);
     if (perCU <= 0) { delete t; return fail(THX_ERR_HIP, "kernel does not fit on the device (occupancy 0)"); }
@@ -633,6 +646,11 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.lds_node_pairs = t->ldsNodeBytes ? t->scene->nPairs : 0u;
     a.refill_below = t->refillBelow;
     a.pool = t->pool;
+    a.ring_cap = t->ringCap;
+    if (t->ringCap) { // ceil(2^37 / d): floor(pos * magic / 2^37) == pos / d for pos < 2^37 / d (>= 2^25: d <= 4096)
+        a.ring_magic = (uint32_t)(((1ull << 37) + t->ringCap - 1) / t->ringCap);
+        a.ring_magic_ts = (uint32_t)(((1ull << 37) + 2ull * t->ringCap - 1) / (2ull * t->ringCap));
+    }
     a.slabs = t->slabs[cfg];
     a.cold = t->cold;
     a.stats = t->stats;

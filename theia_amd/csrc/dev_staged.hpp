@@ -104,8 +104,13 @@ struct StagedLayout {
 #endif
     static constexpr uint32_t C_SHADOW2 = NCOLD - 1u;
     static constexpr uint32_t NCH = NHOT; // state chunks per photon in LDS
-    // ring capacity of a queue: power of two >= pool (the TS ring takes two of them)
-    static constexpr uint32_t qcap(uint32_t pool) {
+    // Ring capacity of a queue (the TS ring takes two of them): at least the pool. Round 3: the next multiple of 64 instead of
+    // the next power of two -- a pool of 1184 photons paid for rings of 2048 cells (32 KB of LDS, 28 B per photon); with
+    // 1216-cell rings the same LDS holds ~190 photons more. A ring position then turns into (lap, cell) by a multiplication
+    // with a reciprocal (Pool::cell), exact while a ring sees fewer than 2^25 appends per launch; the host keeps the power of
+    // two for launches that could get there (`exact` = false).
+    static constexpr uint32_t qcap(uint32_t pool, bool exact) {
+        if (exact) return (pool + 63u) & ~63u;
         uint32_t c = 64;
         while (c < pool) c <<= 1;
         return c;
@@ -113,18 +118,18 @@ struct StagedLayout {
     // dynamic LDS: [hist][state+scratch (NCH+NSC)*P float4][stack depth*T]
     //              [rings: 6 x qcap u16, TS ring 2 qcap u16][counters]
     //              [Variant::LDSN: copy of the scene's pair records]
-    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes = 0) {
-        return nodeOffset(n_bins, stackBytesPerThread, pool, threads) + nodeBytes;
+    static size_t bytes(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes = 0, bool exact = false) {
+        return nodeOffset(n_bins, stackBytesPerThread, pool, threads, exact) + nodeBytes;
     }
     // byte offset of the node copy = everything in front of it (a multiple of 16: pools are multiples of 16 photons)
-    static size_t nodeOffset(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads) {
+    static size_t nodeOffset(uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, bool exact = false) {
         size_t hist = ((size_t)n_bins * 4 + 15) & ~(size_t)15;
-        return hist + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool) * 2 + C_NUM * 4;
+        return hist + (size_t)(NCH + NSC) * pool * 16 + (size_t)stackBytesPerThread * threads + (size_t)8 * qcap(pool, exact) * 2 + C_NUM * 4;
     }
     // largest pool (multiple of 16, <= THX_POOL_MAX) that fits `budget` bytes of LDS
-    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes = 0) {
+    static uint32_t poolFor(uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes = 0, bool exact = false) {
         uint32_t p = THX_POOL_MAX;
-        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, nodeBytes) > budget) p -= 16;
+        while (p > 64 && bytes(n_bins, stackBytesPerThread, p, threads, nodeBytes, exact) > budget) p -= 16;
         return p;
     }
     // bytes of global memory one workgroup needs for its cold chunks
@@ -146,15 +151,21 @@ struct Pool {
         return make_float4(v.x, v.y, v.z, v.w);
     }
     THX_DEV void stCold(uint32_t k, uint32_t slot, float4 v) const { cold[slot * Lay::NCOLD + k] = vec4{v.x, v.y, v.z, v.w}; }
-    uint32_t P, cap, capShift; // pool size, ring capacity (power of two >= P) and its log2
+    uint32_t P, cap;           // pool size, ring capacity (>= P)
+    uint32_t magic, magicTS;   // ceil(2^37 / cap), ceil(2^37 / (2 cap)): position -> lap by multiplication
     // ring s holds slot ids; the TS ring (last) has room for 2 cap entries (two shadow rays per photon)
     uint32_t qHalf, ctrWord; // LDS half-word index of ring 0, LDS word index of the counters
     // LDS half-word index of ring s
     THX_DEV uint32_t queue(int s) const { return qHalf + (uint32_t)(s == S_TS ? 6 : (s > S_TS ? s - 1 : s)) * cap; }
-    THX_DEV uint32_t mask(int s) const { return (s == S_TS ? 2u * cap : cap) - 1u; }
-    // lap tag of ring position `pos` (bit 14 of the cell): a claimer never takes the entry of
-    // the previous lap for its own, however late that lap's claimer empties the cell
-    THX_DEV uint32_t lapTag(int s, uint32_t pos) const { return ((pos >> (s == S_TS ? capShift + 1u : capShift)) & 1u) << 14; }
+    // LDS half-word index of the cell of ring position `pos` (positions count up for the whole launch) and the lap tag of
+    // that position (bit 14 of the cell's entry): a claimer never takes the entry of the previous lap for its own, however
+    // late that lap's claimer empties the cell
+    THX_DEV uint32_t cell(int s, uint32_t pos, uint32_t& tag) const {
+        const uint32_t d = s == S_TS ? 2u * cap : cap;
+        const uint32_t lap = (uint32_t)(((uint64_t)pos * (uint64_t)(s == S_TS ? magicTS : magic)) >> 37);
+        tag = (lap & 1u) << 14;
+        return queue(s) + (pos - lap * d);
+    }
     THX_DEV uint32_t* flagsWord(uint32_t slot) const { return reinterpret_cast<uint32_t*>(&st[2 * P + slot]) + 2; }
 };
 
@@ -371,8 +382,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     pool.cold = (THX_GLOBAL typename Pool<V>::vec4*)(args.cold) + (size_t)blockIdx.x * Lay::NCOLD * P;
     const uint32_t stackWord0 = histWords + (Lay::NCH + Lay::NSC) * P * 4;
     pool.q = reinterpret_cast<uint16_t*>(ldsWords() + stackWord0 + args.stack_wave_words * (T >> 6));
-    pool.cap = Lay::qcap(P);
-    pool.capShift = 31u - (uint32_t)__builtin_clz(pool.cap);
+    pool.cap = args.ring_cap;
+    pool.magic = args.ring_magic;
+    pool.magicTS = args.ring_magic_ts;
     pool.ctr = reinterpret_cast<uint32_t*>(pool.q + 8 * pool.cap);
     pool.qHalf = 2u * (stackWord0 + args.stack_wave_words * (T >> 6));
     pool.ctrWord = pool.qHalf / 2u + 4u * pool.cap;
@@ -452,16 +464,21 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
         const unsigned long long hv = ldsRead64(pool.ctrWord / 2u + qLane); // {head, tail} / {cursor, abort}
         const uint32_t hvx = (uint32_t)hv, hvy = (uint32_t)(hv >> 32);
+        // (rings that are not a power of two long: Pool::cell is exact below 2^25 appends; the host sizes them so only for
+        // launches that stay far below -- should one get there all the same, it ends like a tripped watchdog, loudly)
+        if (__ballot(qLane < 7u && hvy >= (1u << 25)) != 0ull && (pool.cap & (pool.cap - 1u)) != 0u) ldsWrite32(pool.ctrWord + C_ABORT, 1u);
 
         // ring cells of this lane's entries
         uint32_t cellA = kNoCell, cellB = kNoCell; // LDS half-word indices
         if (pushA) {
-            cellA = pool.queue(dstA) + (posA & pool.mask(dstA));
-            entA |= pool.lapTag(dstA, posA);
+            uint32_t tag;
+            cellA = pool.cell(dstA, posA, tag);
+            entA |= tag;
         }
         if (hasB) {
-            cellB = pool.queue(S_TS) + (posB & pool.mask(S_TS));
-            entB |= pool.lapTag(S_TS, posB);
+            uint32_t tag;
+            cellB = pool.cell(S_TS, posB, tag);
+            entB |= tag;
         }
 
         // ---- pick the next batch: the fullest ring; both walk rings count as one
@@ -504,11 +521,9 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         uint32_t claimCell = kNoCell;
         uint32_t wantTag = 0;
         if (lane < n0) {
-            claimCell = pool.queue((int)qa) + ((ha + lane) & pool.mask((int)qa));
-            wantTag = pool.lapTag((int)qa, ha + lane);
+            claimCell = pool.cell((int)qa, ha + lane, wantTag);
         } else if (lane < n0 + n1) {
-            claimCell = pool.queue(S_TS) + ((hb + (lane - n0)) & pool.mask(S_TS));
-            wantTag = pool.lapTag(S_TS, hb + (lane - n0));
+            claimCell = pool.cell(S_TS, hb + (lane - n0), wantTag);
         }
         // (the three reads go out together, for every lane: a lane without a cell reads an unused counter word -- as reads
         // inside `if`s each of them was a branch with its own wait for the LDS, three round trips instead of one)

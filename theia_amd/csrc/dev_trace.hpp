@@ -52,6 +52,9 @@ struct LaunchArgs {
     uint32_t lds_node_pairs;   // ... and how many records it holds (all of the scene's)
     uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active
     uint32_t pool;             // staged kernel: photons held in LDS per workgroup
+    uint32_t ring_cap;         // staged kernel: cells per ring (>= pool; the shadow-ray ring has twice as many) ...
+    uint32_t ring_magic;       // ... ceil(2^37 / ring_cap) and
+    uint32_t ring_magic_ts;    // ... ceil(2^37 / (2 ring_cap)): ring position -> lap (dev_staged.hpp: Pool::cell)
     float* slabs;              // [gridDim.x][n_bins] partial histograms
     uint32_t* spill;           // [waves of the grid][stack_depth - stack_lds][64] deep stack entries, or null
     uint32_t park_below;       // staged kernel: a walk batch sets its last rays aside once fewer than this many lanes walk (0: never)

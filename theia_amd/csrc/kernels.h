@@ -22,7 +22,8 @@ constexpr uint32_t kStackLds16 = 16;   // staged kernel: entries of them kept in
 // scenes of many instances spread their walks most (every instance visit is a detour of its own): kParkBelowInstanced
 constexpr uint32_t kParkBelow = 10, kParkBelowDeep = 16, kParkDeepFrom = 16, kParkRounds = 2;
 constexpr uint32_t kParkBelowInstanced = 24, kParkInstancedFrom = 16;
-constexpr uint32_t kStackLds32 = 10;   // measured on MI355X (profiles/r02_stack_spill.txt): 81 920 triangles 7.27 -> 6.06 ms, 5.2 M triangles 13.2 -> 10.9 ms
+constexpr uint32_t kStackLds32 = 12;   // measured on MI355X (profiles/r02_stack_spill.txt): 81 920 triangles 7.27 -> 6.06 ms, 5.2 M triangles 13.2 -> 10.9 ms;
+                                       // round 3, with the LDS the exact-size rings freed: 10 -> 12 entries, 5.2 M triangles 6.65 -> 6.51 ms
 
 // dynamic LDS bytes of a tracing workgroup (lane kernel)
 inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block, uint32_t depth, bool stack16) {
@@ -32,8 +33,10 @@ inline size_t traceLdsBytes(uint32_t kind, uint32_t n_bins, uint32_t block, uint
 }
 // dynamic LDS bytes of the staged scene kernel (dev_staged.hpp: StagedLayout)
 // (nodeBytes: the copy of the scene's pair records the Variant::LDSN kernels keep behind everything else)
-size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes = 0);
-uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes = 0);
+// (exactRings: ring capacity = the pool rounded up to 64 instead of to a power of two, dev_staged.hpp: StagedLayout::qcap)
+size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes = 0, bool exactRings = false);
+uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes = 0, bool exactRings = false);
+uint32_t stagedRingCap(uint32_t pool, bool exactRings);
 // global memory (bytes) of one workgroup's cold photon state (dev_staged.hpp: StagedLayout::coldBytes)
 size_t stagedColdBytes(bool polarized, uint32_t pool);
 constexpr uint32_t kStagedBlock = 1024;

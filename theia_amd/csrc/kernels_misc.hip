@@ -26,12 +26,15 @@ const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis) {
     return table[(kind & 1u) * 4 + (pol ? 2 : 0) + (mis ? 1 : 0)];
 }
 
-size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes) {
-    return polarized ? StagedLayout<true>::bytes(n_bins, stackBytesPerThread, pool, threads, nodeBytes) : StagedLayout<false>::bytes(n_bins, stackBytesPerThread, pool, threads, nodeBytes);
+size_t stagedLdsBytes(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, uint32_t pool, uint32_t threads, size_t nodeBytes, bool exactRings) {
+    return polarized ? StagedLayout<true>::bytes(n_bins, stackBytesPerThread, pool, threads, nodeBytes, exactRings)
+                     : StagedLayout<false>::bytes(n_bins, stackBytesPerThread, pool, threads, nodeBytes, exactRings);
 }
-uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes) {
-    return polarized ? StagedLayout<true>::poolFor(n_bins, stackBytesPerThread, budget, threads, nodeBytes) : StagedLayout<false>::poolFor(n_bins, stackBytesPerThread, budget, threads, nodeBytes);
+uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerThread, size_t budget, uint32_t threads, size_t nodeBytes, bool exactRings) {
+    return polarized ? StagedLayout<true>::poolFor(n_bins, stackBytesPerThread, budget, threads, nodeBytes, exactRings)
+                     : StagedLayout<false>::poolFor(n_bins, stackBytesPerThread, budget, threads, nodeBytes, exactRings);
 }
+uint32_t stagedRingCap(uint32_t pool, bool exactRings) { return StagedLayout<false>::qcap(pool, exactRings); }
 size_t stagedColdBytes(bool polarized, uint32_t pool) { return polarized ? StagedLayout<true>::coldBytes(pool) : StagedLayout<false>::coldBytes(pool); }
 static_assert(kStagedBlock == kSchedThreads, "staged block size");
 
