@@ -44,9 +44,11 @@ constexpr uint32_t kStagedBlock = 1024;
 // kLdsNodeMinPool photons (measured: profiles/r03_lds_nodes.txt)
 constexpr size_t kLdsNodeMaxBytes = 48 * 1024;
 constexpr uint32_t kLdsNodeMinPool = 1056;
-// staged kernel: photons per workgroup beyond which a larger pool no longer pays (config 2: 1264 -> 2.82 ms, 1552 -> 2.88;
-// configs 3 / 5 and the large meshes are flat between 1264 and 1440: profiles/r03_lds_nodes.txt)
-constexpr uint32_t kPoolBest = 1344;
+// staged kernel: photons per workgroup beyond which a larger pool no longer pays. The faster the stages, the more photons a
+// workgroup can turn over: 1264 at the end of round 2, 1344 with 64 B per photon, and with the kernels of the end of round 3
+// config 2 read through the vector cache (THX_LDS_NODES=0) runs 2.58 / 2.48 / 2.48 ms at 1344 / 1472 / 1600; config 5 and the
+// large meshes are flat from 1344 on (gpurun_out/r03/sweep20-22.txt)
+constexpr uint32_t kPoolBest = 1472;
 
 // one function pair per compiled variant (trace_variant.hip, built once per
 // KIND x POL x MIS); mode bit 0 selects the instrumented (statistics + track) kernel,
