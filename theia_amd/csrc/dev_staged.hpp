@@ -7,8 +7,8 @@
 // walk for the primary ray, ~45 % need MIS sampling plus shadow rays, ~50 % are
 // being born, and a wavefront pays for every path any of its lanes takes.
 //
-// How: a workgroup owns a pool of up to 1024 photons in LDS (structure of float4
-// arrays, 112 B per photon, 144 B polarized) and a queue per stage
+// How: a workgroup owns a pool of 1100-1472 photons (structure of float4 arrays: 64 B per
+// photon in LDS, 48 / 80 B in an L2-resident global array, see StagedLayout) and a queue per stage
 //     BIRTH -> A (free path, guide) -> T0 (primary BVH walk + surface hit)
 //           -> BM (propagate, no hit) -> M (MIS sampling)
 //           -> TS (shadow-ray walk + detector response) -> C (scatter) -> A ...
@@ -21,10 +21,10 @@
 // their own RNG stream (= photon index) and dimension, so the order in which they
 // advance does not change any per-photon result; arithmetic, draw order and event
 // order are those of the lane kernel (the stage bodies call the same device
-// functions). Rings hold 16-bit entries in LDS with a cell hand-off (EMPTY <-> entry
-// with a lap tag) between the appending and the claiming wavefront; an append is one
-// LDS atomic per lane on the ring tail. DESIGN.md section 3.1 has the measurements
-// behind every choice made here.
+// functions). Rings hold 16-bit entries in LDS (as many cells as the pool has photons,
+// rounded up to 64) with a cell hand-off (EMPTY <-> entry with a lap tag) between the
+// appending and the claiming wavefront; an append is one LDS atomic per lane on the ring
+// tail. DESIGN.md section 3.1 has the measurements behind every choice made here.
 #pragma once
 #include "dev_trace.hpp"
 
@@ -87,7 +87,7 @@ struct StagedLayout {
     // direction + wavelength, meta (index, RNG dimension, flags incl. the pending-walk counter, shadow-ray length) --
     // and COLD chunks only the shading stages touch: contributions + medium, medium constants[, Stokes vector,
     // polarization reference]. Hot chunks and the scratch live in LDS, the cold ones in global memory (one array per
-    // workgroup, 32 / 64 B per photon: L2 resident): 112 / 144 -> 80 B of LDS per photon. Photons in flight per CU are
+    // workgroup, 32 / 64 B per photon: L2 resident): 112 / 144 -> 80 B of LDS per photon (round 2). Photons in flight per CU are
     // what the throughput follows: pool 800 -> 1232 on config 3, 704 -> 1024 (and 12 -> 16 wavefronts) on
     // config 5, 1024 -> 1264 on config 2; measured -12 % / -15 % / -3 % kernel time.
     // Round 3: of the two scratch chunks (sampled distances of a primary ray / direction + weight of the two MIS shadow
