@@ -1123,6 +1123,9 @@ THX_DEV float slabChildFar(const float4 c, const QRay& r, float tmax) {
 // ... in one select: entry distance, or +inf for a miss (a hit's distance is finite: the reciprocals are clamped). What
 // the branch-free inner-node loop orders the children by: min / max / <= on these do the work of the four-way branch.
 THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax) {
+#ifdef THX_SLAB_MINMAX
+    return slabChildFar(c, r, tmax);
+#else
     const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
     const uint32_t nxy = __builtin_amdgcn_perm(wh, wl, r.sxy), fxy = __builtin_amdgcn_perm(wl, wh, r.sxy);
     const uint32_t nfz = __builtin_amdgcn_perm(wz, wz, r.sz);
@@ -1132,6 +1135,7 @@ THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax) {
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
     const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
     return tn <= tf * kSlabSlack ? tn : INFINITY;
+#endif
 }
 // the root box of a tree = its whole frame, q = 0 .. 65535
 THX_DEV bool slabRoot(const QRay& r, float tmax) {
@@ -1446,6 +1450,17 @@ struct Walker {
         const uint32_t below = V::S16 ? (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64] : stack32[(int32_t)(sp << 6) - 64];
         L.cnt.add(ST_NODES, 2);
         const float tl = slabChildInf(lc, sr, h.t), tr = slabChildInf(rc, sr, h.t);
+#ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
+        {
+            float sink;
+#pragma unroll
+            for (int e = 0; e < THX_EXTRA_ISSUE; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(tl));
+        }
+#endif
+#ifdef THX_EXTRA_NOP // experiment: N x 16 cycles in which this wavefront issues nothing (latency, no issue slots)
+#pragma unroll
+        for (int e = 0; e < THX_EXTRA_NOP; ++e) asm volatile("s_nop 15");
+#endif
         const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
         const bool leftFirst = tl <= tr;
         const uint32_t nearRef = leftFirst ? ml : mr, farRef = leftFirst ? mr : ml;
