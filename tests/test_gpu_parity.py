@@ -312,6 +312,7 @@ def test_walk_variants_change_nothing(hip_backend, scene, monkeypatch):
     runs = {}
     for name, env in (("default", {}), ("records through the vector cache", {"THX_LDS_NODES": "0"}), ("records in LDS", {"THX_LDS_NODES": "1"}),
                       ("32-bit stack entries", {"THX_STACK32": "1"}), ("3 stack entries in LDS", {"THX_STACK_LDS": "3", "THX_LDS_NODES": "0"}),
+                      ("records in LDS, 3 stack entries in LDS", {"THX_STACK_LDS": "3", "THX_LDS_NODES": "1"}),
                       ("32-bit entries, 2 of them in LDS", {"THX_STACK32": "1", "THX_STACK_LDS": "2"}),
                       ("rings of a power of two", {"THX_RING_POW2": "1"})):
         with monkeypatch.context() as m:

@@ -450,7 +450,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (stackAllLds) t->mode |= 8u; // ... and with the whole stack in LDS
         // Small scenes: the walk reads its pair records from a copy in LDS if that leaves a pool of kLdsNodeMinPool photons
         // (THX_LDS_NODES=0 / 1: never / whenever it fits at all)
-        if ((t->mode & 8u) && t->block == kStagedBlock) {
+        if ((t->mode & 4u) && t->block == kStagedBlock) { // (16-bit stack entries: the variants that exist with the copy)
             const size_t nodeBytes = (size_t)scene->nPairs * sizeof(NodePair);
             const uint32_t poolN = std::min(stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, nodeBytes, xr), kPoolBest);
             bool use = nodeBytes <= kLdsNodeMaxBytes && poolN >= kLdsNodeMinPool;

@@ -21,9 +21,11 @@ struct Variant {
     // records from a copy in LDS (scenes whose whole node array fits next to the photon pool): an LDS read returns in
     // 64 cycles whatever the other wavefronts do, a 16-B gather through the vector cache in 150 (alone) to 600 (sixteen
     // wavefronts gathering) when it hits and the L2's 500+ when it does not (profiles/r03_mem_latency.txt).
+    // 4: as 1 (16-bit entries, deep part of the stack in global memory) with the pair records in LDS: deep scenes whose
+    // records still fit.
     static constexpr bool S16 = STACK_ != 0;
     static constexpr bool SPILL = STACK_ != 2 && STACK_ != 3;
-    static constexpr bool LDSN = STACK_ == 3;
+    static constexpr bool LDSN = STACK_ == 3 || STACK_ == 4;
 };
 
 // ray.glsl:22-36 (+163-170 polarized part)

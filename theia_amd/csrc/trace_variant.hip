@@ -108,6 +108,8 @@ using PlainT = Variant<THX_POL != 0, THX_MIS != 0, false, false, 2>; // ... and 
 using DebugT = Variant<THX_POL != 0, THX_MIS != 0, true, true, 2>;
 using PlainN = Variant<THX_POL != 0, THX_MIS != 0, false, false, 3>; // ... and the pair records in LDS
 using DebugN = Variant<THX_POL != 0, THX_MIS != 0, true, true, 3>;
+using PlainM = Variant<THX_POL != 0, THX_MIS != 0, false, false, 4>; // 16-bit entries, deep part in global memory, pair records in LDS
+using DebugM = Variant<THX_POL != 0, THX_MIS != 0, true, true, 4>;
 
 #if THX_KIND == 1
 // staged (regrouped-in-LDS) form of the scene tracer, see dev_staged.hpp
@@ -118,9 +120,9 @@ __global__ void __launch_bounds__(kSchedThreads) sceneStagedKernel(const LaunchA
 #endif
 
 // staged kernel variants: 0/1 nothing known about the stack, 2/3 16-bit entries, 4/5 ... all in LDS, 6/7 ... and the
-// pair records too; odd = instrumented
+// pair records too, 8/9 16-bit entries with the deep part in global memory and the pair records in LDS; odd = instrumented
 static inline uint32_t stagedVariantIndex(uint32_t mode) {
-    return ((mode & 1u) ? 1u : 0u) | ((mode & 4u) ? ((mode & 8u) ? ((mode & 16u) ? 6u : 4u) : 2u) : 0u);
+    return ((mode & 1u) ? 1u : 0u) | ((mode & 4u) ? ((mode & 8u) ? ((mode & 16u) ? 6u : 4u) : ((mode & 16u) ? 8u : 2u)) : 0u);
 }
 
 #define THX_CAT_(a, b, c, d) a##b##_##c##_##d
@@ -136,11 +138,12 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
 #if THX_KIND == 1
     if (mode & 2u) {
         // > 64 KB of dynamic LDS needs an explicit opt-in (once per kernel)
-        const void* fn[8] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
+        const void* fn[10] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
                              reinterpret_cast<const void*>(sceneStagedKernel<PlainS>), reinterpret_cast<const void*>(sceneStagedKernel<DebugS>),
                              reinterpret_cast<const void*>(sceneStagedKernel<PlainT>), reinterpret_cast<const void*>(sceneStagedKernel<DebugT>),
-                             reinterpret_cast<const void*>(sceneStagedKernel<PlainN>), reinterpret_cast<const void*>(sceneStagedKernel<DebugN>)};
-        static bool optedIn[8] = {false, false, false, false, false, false, false, false};
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainN>), reinterpret_cast<const void*>(sceneStagedKernel<DebugN>),
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainM>), reinterpret_cast<const void*>(sceneStagedKernel<DebugM>)};
+        static bool optedIn[10] = {false, false, false, false, false, false, false, false, false, false};
         const uint32_t k = stagedVariantIndex(mode);
         if (!optedIn[k]) {
             hipError_t e = hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -155,7 +158,9 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
         case 4: hipLaunchKernelGGL((sceneStagedKernel<PlainT>), dim3(grid), dim3(block), lds, stream, args); break;
         case 5: hipLaunchKernelGGL((sceneStagedKernel<DebugT>), dim3(grid), dim3(block), lds, stream, args); break;
         case 6: hipLaunchKernelGGL((sceneStagedKernel<PlainN>), dim3(grid), dim3(block), lds, stream, args); break;
-        default: hipLaunchKernelGGL((sceneStagedKernel<DebugN>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 7: hipLaunchKernelGGL((sceneStagedKernel<DebugN>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 8: hipLaunchKernelGGL((sceneStagedKernel<PlainM>), dim3(grid), dim3(block), lds, stream, args); break;
+        default: hipLaunchKernelGGL((sceneStagedKernel<DebugM>), dim3(grid), dim3(block), lds, stream, args); break;
         }
         return hipGetLastError();
     }
@@ -182,7 +187,9 @@ int THX_FN(traceOccupancy_)(uint32_t mode, uint32_t block, size_t lds) {
         case 4: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainT>, (int)block, lds); break;
         case 5: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugT>, (int)block, lds); break;
         case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainN>, (int)block, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugN>, (int)block, lds); break;
+        case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugN>, (int)block, lds); break;
+        case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainM>, (int)block, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugM>, (int)block, lds); break;
         }
         return e == hipSuccess ? n : -1;
     }
