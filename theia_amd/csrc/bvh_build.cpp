@@ -196,11 +196,14 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame, bool tlas) {
     const BvhNode& rn = out.nodes[root];
     for (int k = 0; k < 3; ++k) {
         const float lo = rn.lo[k], hi = rn.hi[k];
-        frame.origin[k] = lo;
-        // 65533 steps span the extent (one step of padding on either side stays inside 16 bit)
-        float step = (hi - lo) / 65533.0f;
+        // 65531 steps span the extent, from q = 2 to q = 65533: the "one more step outwards" of every plane stays inside 16 bit
+        // AND clear of the clamps at both ends of the range (the walk's decoding is good to half a step: dev_trace.hpp, QRay)
+        float step = (hi - lo) / 65531.0f;
         step = std::max(step, 1e-7f * std::max(std::fabs(lo), std::fabs(hi)) + 1e-30f);
-        while (dequant(65534u, step, lo) < hi) step = std::nextafter(step, INFINITY);
+        float origin = lo - 2.0f * step;
+        while (dequant(2u, step, origin) > lo) origin = std::nextafter(origin, -INFINITY);
+        while (dequant(65533u, step, origin) < hi) step = std::nextafter(step, INFINITY);
+        frame.origin[k] = origin;
         frame.step[k] = step;
     }
     frame.pad = 0;
@@ -228,9 +231,7 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame, bool tlas) {
             const BvhNode& ch = out.nodes[n.leftFirst + c];
             uint32_t l[3], h[3];
             for (int k = 0; k < 3; ++k) { l[k] = qlo(ch.lo[k], k); h[k] = qhi(ch.hi[k], k); }
-            w[4 * c + 0] = l[0] | (l[1] << 16);
-            w[4 * c + 1] = h[0] | (h[1] << 16);
-            w[4 * c + 2] = l[2] | (h[2] << 16);
+            for (int k = 0; k < 3; ++k) w[4 * c + k] = l[k] | (h[k] << 16);
         }
         w[3] = self(n.leftFirst, self);
         w[7] = self(n.leftFirst + 1, self);
@@ -279,9 +280,7 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame, bool tlas) {
             const BvhNode& cn = out.nodes[ch[c]];
             uint32_t l[3], h[3];
             for (int a = 0; a < 3; ++a) { l[a] = qlo(cn.lo[a], a); h[a] = qhi(cn.hi[a], a); }
-            w[4 * c + 0] = l[0] | (l[1] << 16);
-            w[4 * c + 1] = h[0] | (h[1] << 16);
-            w[4 * c + 2] = l[2] | (h[2] << 16);
+            for (int a = 0; a < 3; ++a) w[4 * c + a] = l[a] | (h[a] << 16);
         }
         uint32_t deepest = 0;
         for (int c = 0; c < k; ++c) {

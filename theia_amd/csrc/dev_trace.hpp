@@ -1005,12 +1005,14 @@ THX_DEV bool woopTri(const WoopRay& w, f3 org, f3 p0, f3 p1, f3 p2, float& t_io,
 // corner in one v_pk_fma_f32 (the loaded float4 holds them in an aligned register
 // pair). The boxes are padded by the builder and the interval test carries a 4e-7
 // slack, so the rounding of this form cannot drop a box that holds a hit.
-// 1/d is clamped to +-1e30: with an infinite reciprocal (axis-parallel ray, d = 0) the
+// 1/d is clamped to +-1e24: with an infinite reciprocal (axis-parallel ray, d = 0) the
 // far plane of a slab the origin lies in would come out as inf - inf = NaN, v_max would
-// return the near plane's -inf for it and the box would be culled. With 1e30 both planes
-// stay finite (|plane| * 1e30 < FLT_MAX for coordinates below 1e8 m) and keep their signs:
-// the padding of the boxes (2e-6 relative) is far above the 6e-8 relative rounding of the
-// product.
+// return the near plane's -inf for it and the box would be culled. With 1e24 both planes
+// stay finite (|plane| * 1e24 and the quantised form's 2^23 * step * 1e24 are far below FLT_MAX
+// for any scene measured in metres) and keep their signs: the padding of the boxes (2e-6
+// relative) is far above the 6e-8 relative rounding of the product. (A ray flatter than
+// 1e-24 is tested as if it were that steep: it reaches a slab it starts outside of EARLIER
+// than the true ray would, never later -- conservative.)
 typedef float v2f __attribute__((ext_vector_type(2)));
 struct SlabRay {
     v2f inv_xy, noi_xy; // 1/d and -(o/d), x and y
@@ -1022,9 +1024,9 @@ struct SlabRay {
 // (kSlabSlack, raised from 4e-7 to 1e-6 with this) covers whatever the distance; the ray/triangle test -- what decides a
 // hit and its coordinates -- keeps its exact divisions (woopSetup), so hits stay bitwise those of the oracle's brute force.
 #ifdef THX_SLAB_EXACT_DIV
-THX_DEV float slabInv(float d) { return fminf(fmaxf(1.0f / d, -1.0e30f), 1.0e30f); }
+THX_DEV float slabInv(float d) { return fminf(fmaxf(1.0f / d, -1.0e24f), 1.0e24f); }
 #else
-THX_DEV float slabInv(float d) { return fminf(fmaxf(__builtin_amdgcn_rcpf(d), -1.0e30f), 1.0e30f); }
+THX_DEV float slabInv(float d) { return fminf(fmaxf(__builtin_amdgcn_rcpf(d), -1.0e24f), 1.0e24f); }
 #endif
 constexpr float kSlabSlack = 1.000001f;
 THX_DEV SlabRay slabRay(f3 o, f3 d) {
@@ -1055,12 +1057,20 @@ struct QRay {
     v2f a_xy, b_xy;
     float a_z, b_z;
 #ifndef THX_SLAB_MINMAX
-    // byte selectors (v_perm_b32) that pick a box's near planes by the signs of the ray: sxy from the {lo.x|lo.y,
-    // hi.x|hi.y} word pair (the far planes come out of the same selector with the operands swapped), sz puts
-    // {near z | far z} of the lo.z|hi.z word in order
-    uint32_t sxy, sz;
+    // byte selectors (v_perm_b32) that turn a box's near / far plane of an axis -- picked by the sign of the ray from the
+    // axis' lo | hi << 16 word -- straight into the float 2^23 + q (see qPlane)
+    uint32_t snx, sny, snz, sfx, sfy, sfz;
 #endif
 };
+// A 16-bit plane index as a float without a conversion: the bytes of q under the exponent of 2^23 ARE the float 2^23 + q
+// (one v_perm_b32 from the record's word and the constant; a v_cvt_f32_u32 with a 16-bit source selector issues no faster
+// than the v_perm_b32 that had to pick the half-word for it anyway: profiles/r03_valu_rates.txt). The ray's offset takes
+// the 2^23 back out: t = (2^23 + q) a + (b - 2^23 a), one fma as before. Price: b - 2^23 a is rounded at the size of
+// 2^23 a, i.e. to half a quantisation step -- the planes a ray sees lie up to half a step off. The builder moves every
+// plane one whole step outwards (bvh_build.cpp: qlo / qhi, frames with two steps of room at either end), so the boxes stay
+// conservative, and hits are decided by the triangle test alone.
+constexpr uint32_t kPlaneMagic = 0x4B000000u; // 2^23 as float
+constexpr float kPlaneBase = 8388608.0f;
 THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origin, rootRef}, f1 = {step, -}
     const float ix = slabInv(d.x), iy = slabInv(d.y), iz = slabInv(d.z);
     QRay r;
@@ -1069,48 +1079,32 @@ THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origi
     r.a_z = f1.z * iz;
     r.b_z = __builtin_fmaf(f0.z, iz, -(o.z * iz));
 #ifndef THX_SLAB_MINMAX
-    r.sxy = (r.a_xy.x < 0.0f ? 0x0504u : 0x0100u) | (r.a_xy.y < 0.0f ? 0x07060000u : 0x03020000u);
-    r.sz = r.a_z < 0.0f ? 0x01000302u : 0x03020100u;
+    r.b_xy = v2f{__builtin_fmaf(-kPlaneBase, r.a_xy.x, r.b_xy.x), __builtin_fmaf(-kPlaneBase, r.a_xy.y, r.b_xy.y)};
+    r.b_z = __builtin_fmaf(-kPlaneBase, r.a_z, r.b_z);
+    // v_perm_b32 D, word, magic, sel: selector bytes 4..7 = bytes of the word, 0..3 = bytes of the magic (2: 0x00, 3: 0x4B)
+    constexpr uint32_t LO = 0x03020504u, HI = 0x03020706u;
+    r.snx = r.a_xy.x < 0.0f ? HI : LO; r.sfx = r.a_xy.x < 0.0f ? LO : HI;
+    r.sny = r.a_xy.y < 0.0f ? HI : LO; r.sfy = r.a_xy.y < 0.0f ? LO : HI;
+    r.snz = r.a_z < 0.0f ? HI : LO;    r.sfz = r.a_z < 0.0f ? LO : HI;
 #endif
     return r;
 }
-// a 16-bit half of a word as float: one SDWA conversion (the build runs without the compiler's own SDWA folding, see the
-// Makefile; these two, on values that are nothing but loaded words run through v_perm_b32, are written out)
-THX_DEV float u16lo(uint32_t w) {
-#ifdef THX_NO_SDWA_ASM
-    return (float)(w & 0xFFFFu);
-#else
-    float f;
-    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_0" : "=v"(f) : "v"(w));
-    return f;
-#endif
-}
-THX_DEV float u16hi(uint32_t w) {
-#ifdef THX_NO_SDWA_ASM
-    return (float)(w >> 16);
-#else
-    float f;
-    asm("v_cvt_f32_u32_sdwa %0, %1 dst_sel:DWORD dst_unused:UNUSED_PAD src0_sel:WORD_1" : "=v"(f) : "v"(w));
-    return f;
-#endif
-}
-// one child of a pair record: c.x = lo.x | lo.y << 16, c.y = hi.x | hi.y << 16, c.z = lo.z | hi.z << 16
+THX_DEV float qPlane(uint32_t word, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(word, kPlaneMagic, sel)); }
+// one child of a pair record: c.x = lo.x | hi.x << 16, c.y = lo.y | hi.y << 16, c.z = lo.z | hi.z << 16
 THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
-    const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
+    const uint32_t wx = __float_as_uint(c.x), wy = __float_as_uint(c.y), wz = __float_as_uint(c.z);
 #ifndef THX_SLAB_MINMAX
-    // Near and far plane of every axis picked by the sign of the ray (one v_perm_b32 per word) instead of computing
-    // both distances and taking min / max: t = q a + b is monotonic in q, so the values are the same ones.
-    const uint32_t nxy = __builtin_amdgcn_perm(wh, wl, r.sxy), fxy = __builtin_amdgcn_perm(wl, wh, r.sxy);
-    const uint32_t nfz = __builtin_amdgcn_perm(wz, wz, r.sz);
-    const v2f tn_xy = __builtin_elementwise_fma(v2f{u16lo(nxy), u16hi(nxy)}, r.a_xy, r.b_xy);
-    const v2f tf_xy = __builtin_elementwise_fma(v2f{u16lo(fxy), u16hi(fxy)}, r.a_xy, r.b_xy);
-    const float tn_z = __builtin_fmaf(u16lo(nfz), r.a_z, r.b_z), tf_z = __builtin_fmaf(u16hi(nfz), r.a_z, r.b_z);
+    // Near and far plane of every axis picked by the sign of the ray instead of computing both distances and taking
+    // min / max: t = q a + b is monotonic in q, so the values are the same ones.
+    const v2f tn_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.snx), qPlane(wy, r.sny)}, r.a_xy, r.b_xy);
+    const v2f tf_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.sfx), qPlane(wy, r.sfy)}, r.a_xy, r.b_xy);
+    const float tn_z = __builtin_fmaf(qPlane(wz, r.snz), r.a_z, r.b_z), tf_z = __builtin_fmaf(qPlane(wz, r.sfz), r.a_z, r.b_z);
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
     const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
     return tn <= tf * kSlabSlack ? tn : -1.0f;
 #else
-    const v2f t0 = __builtin_elementwise_fma(v2f{(float)(wl & 0xFFFFu), (float)(wl >> 16)}, r.a_xy, r.b_xy);
-    const v2f t1 = __builtin_elementwise_fma(v2f{(float)(wh & 0xFFFFu), (float)(wh >> 16)}, r.a_xy, r.b_xy);
+    const v2f t0 = __builtin_elementwise_fma(v2f{(float)(wx & 0xFFFFu), (float)(wy & 0xFFFFu)}, r.a_xy, r.b_xy);
+    const v2f t1 = __builtin_elementwise_fma(v2f{(float)(wx >> 16), (float)(wy >> 16)}, r.a_xy, r.b_xy);
     const float tz0 = __builtin_fmaf((float)(wz & 0xFFFFu), r.a_z, r.b_z), tz1 = __builtin_fmaf((float)(wz >> 16), r.a_z, r.b_z);
     float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
@@ -1124,26 +1118,38 @@ THX_DEV float slabChildFar(const float4 c, const QRay& r, float tmax) {
 }
 // ... in one select: entry distance, or +inf for a miss (a hit's distance is finite: the reciprocals are clamped). What
 // the branch-free inner-node loop orders the children by: min / max / <= on these do the work of the four-way branch.
-THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax) {
+// (`inf`: +infinity held in a vector register by the caller -- as a literal the compiler materialises it again in every trip
+// of the loop. minRaw: v_min_f32 as it is -- fminf() on a value that comes out of another block, like the closest hit so far,
+// is preceded by a v_max_f32 x, x that quiets a signalling NaN it cannot rule out, again in every trip.)
+THX_DEV float minRaw(float a, float b) {
+    float r;
+    asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax, float inf) {
 #ifdef THX_SLAB_MINMAX
-    return slabChildFar(c, r, tmax);
+    const float t = slabChildFar(c, r, tmax);
+    return t < INFINITY ? t : inf;
 #else
-    const uint32_t wl = __float_as_uint(c.x), wh = __float_as_uint(c.y), wz = __float_as_uint(c.z);
-    const uint32_t nxy = __builtin_amdgcn_perm(wh, wl, r.sxy), fxy = __builtin_amdgcn_perm(wl, wh, r.sxy);
-    const uint32_t nfz = __builtin_amdgcn_perm(wz, wz, r.sz);
-    const v2f tn_xy = __builtin_elementwise_fma(v2f{u16lo(nxy), u16hi(nxy)}, r.a_xy, r.b_xy);
-    const v2f tf_xy = __builtin_elementwise_fma(v2f{u16lo(fxy), u16hi(fxy)}, r.a_xy, r.b_xy);
-    const float tn_z = __builtin_fmaf(u16lo(nfz), r.a_z, r.b_z), tf_z = __builtin_fmaf(u16hi(nfz), r.a_z, r.b_z);
+    const uint32_t wx = __float_as_uint(c.x), wy = __float_as_uint(c.y), wz = __float_as_uint(c.z);
+    const v2f tn_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.snx), qPlane(wy, r.sny)}, r.a_xy, r.b_xy);
+    const v2f tf_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.sfx), qPlane(wy, r.sfy)}, r.a_xy, r.b_xy);
+    const float tn_z = __builtin_fmaf(qPlane(wz, r.snz), r.a_z, r.b_z), tf_z = __builtin_fmaf(qPlane(wz, r.sfz), r.a_z, r.b_z);
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
-    const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
-    return tn <= tf * kSlabSlack ? tn : INFINITY;
+    const float tf = fminf(fminf(tf_xy.x, tf_xy.y), minRaw(tf_z, tmax));
+    return tn <= tf * kSlabSlack ? tn : inf;
 #endif
 }
 // the root box of a tree = its whole frame, q = 0 .. 65535
 THX_DEV bool slabRoot(const QRay& r, float tmax) {
-    const v2f t0 = r.b_xy;
-    const v2f t1 = __builtin_elementwise_fma(v2f{65535.0f, 65535.0f}, r.a_xy, r.b_xy);
-    const float tz0 = r.b_z, tz1 = __builtin_fmaf(65535.0f, r.a_z, r.b_z);
+#ifndef THX_SLAB_MINMAX
+    constexpr float q0 = kPlaneBase, q1 = kPlaneBase + 65535.0f;
+#else
+    constexpr float q0 = 0.0f, q1 = 65535.0f;
+#endif
+    const v2f t0 = __builtin_elementwise_fma(v2f{q0, q0}, r.a_xy, r.b_xy);
+    const v2f t1 = __builtin_elementwise_fma(v2f{q1, q1}, r.a_xy, r.b_xy);
+    const float tz0 = __builtin_fmaf(q0, r.a_z, r.b_z), tz1 = __builtin_fmaf(q1, r.a_z, r.b_z);
     float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
     float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
     return tn <= tf * kSlabSlack;
@@ -1199,6 +1205,7 @@ struct Walker {
     QRay sr, wsr;
     WoopRay w;
     QueryHit h;
+    float infReg; // +inf in a register of its own (slabChildInf)
 #ifdef THX_STAGE_PROFILE
     unsigned long long pInner = 0, pLeaf = 0, pOther = 0, pRounds = 0, pTrips = 0;
     uint32_t pLane = 0;
@@ -1233,6 +1240,7 @@ struct Walker {
                 stack32[-64] = WALK_DONE;
             }
         }
+        asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(infReg));
         sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false; overflow = false;
         w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
         h.valid = false; h.instance = 0; h.prim = 0; h.t = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
@@ -1451,7 +1459,7 @@ struct Walker {
         const float4 lc = rec[0], rc = rec[1];
         const uint32_t below = V::S16 ? (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64] : stack32[(int32_t)(sp << 6) - 64];
         L.cnt.add(ST_NODES, 2);
-        const float tl = slabChildInf(lc, sr, h.t), tr = slabChildInf(rc, sr, h.t);
+        const float tl = slabChildInf(lc, sr, h.t, infReg), tr = slabChildInf(rc, sr, h.t, infReg);
 #ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
         {
             float sink;

@@ -1,6 +1,7 @@
 #!/usr/bin/env python3
 """Kernel time of the scene workloads under environment overrides (development aid):
-   tools/sweep.py <photons> <workload,...> [VAR=v1,v2,... ...]   -- full cross product of the VAR lists."""
+   tools/sweep.py <photons> <workload,...> [VAR=v1,v2,... ...]   -- full cross product of the VAR lists.
+   (THEIA_AMD_LIB cannot be one of them: the library is loaded once per process -- A/B two builds with two invocations.)"""
 import itertools, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -14,6 +15,8 @@ n = int(sys.argv[1])
 WARM = int(os.environ.get("SWEEP_WARMUP", "10"))
 names = sys.argv[2].split(",")
 axes = [(a.split("=")[0], a.split("=")[1].split(",")) for a in sys.argv[3:]]
+if any(k == "THEIA_AMD_LIB" for k, _ in axes):
+    sys.exit("THEIA_AMD_LIB is read once, when the library is loaded: set it in the environment of one invocation per build")
 for name in names:
     for combo in itertools.product(*[v for _, v in axes]) if axes else [()]:
         for (k, _), v in zip(axes, combo):
