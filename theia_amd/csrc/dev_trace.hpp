@@ -1455,7 +1455,8 @@ struct Walker {
     // (harmless: the slot is free), and what a pop would return is read together with the node (harmless if it does not
     // pop; the slot below entry 0 holds WALK_DONE). Same visits in the same order as the branchy form.
     THX_DEV void visitStraight() {
-        const float4* rec = nodes + (cur >> 2); // record (cur >> 3) = two float4
+        // record (cur >> 3) = two float4 = 32 B (cur's low bits are zero: an inner node)
+        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + (cur << 2));
         const float4 lc = rec[0], rc = rec[1];
         const uint32_t below = V::S16 ? (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64] : stack32[(int32_t)(sp << 6) - 64];
         L.cnt.add(ST_NODES, 2);
@@ -1497,7 +1498,9 @@ struct Walker {
         // out: push() flags it); on deeper scenes a lane beyond its LDS part takes the branchy visit for those trips.
         if constexpr (FAST) {
             bool leftEarly = false;
-            while ((cur & 7u) == 0u && (V::SPILL || sp < ldsN)) {
+            // (one test per trip: it is the loop's condition and what the early exit counts)
+            bool go = (cur & 7u) == 0u && (V::SPILL || sp < ldsN);
+            while (go) {
 #ifdef THX_STAGE_PROFILE
                 pLane += 1;
                 pTrips += 1;
@@ -1511,7 +1514,10 @@ struct Walker {
 #endif
                 if (!V::SPILL || sp < ldsN) visitStraight();
                 else visitBranchy();
-                if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) { leftEarly = true; break; }
+                const bool atInner = (cur & 7u) == 0u;
+                const unsigned long long goMask = __builtin_amdgcn_ballot_w64(atInner); // (the comparison's own mask)
+                go = atInner && (V::SPILL || sp < ldsN);
+                if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(goMask) < innerKeep) { leftEarly = true; break; }
             }
             if (cur == WALK_DONE) sp = 0; // (popping the sentinel slot took the stack pointer below zero)
             if (V::SPILL || __ballot(leftEarly) != 0ull) goto innerDone;
