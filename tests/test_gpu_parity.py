@@ -14,6 +14,8 @@ tools/parity_margins.py: identical event codes for 100 % of 20 000 photons on ev
 curves within 4e-8 -- the tolerances here leave room for a handful of libm-noise flips, not for
 a bug. Only the volume tracer without target sampling is looser, see there.)
 """
+import sys
+
 import numpy as np
 import pytest
 
@@ -318,6 +320,9 @@ def test_walk_variants_change_nothing(hip_backend, scene, monkeypatch):
         with monkeypatch.context() as m:
             for k, v in env.items():
                 m.setenv(k, v)
+            # (unbuffered and uncaptured: should a form take the process down, the log says which one)
+            sys.__stderr__.write(f"[walk form] {scene}: {name}\n")
+            sys.__stderr__.flush()
             sc = make()
             hist = S.run_batches(sc, 1)[0]
             runs[name] = (hist, sc.tracer.program.read_stats(), sc.tracer.program.read_track(sc.tracer.batchSize))
