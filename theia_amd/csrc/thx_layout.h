@@ -24,8 +24,9 @@ static_assert(sizeof(BvhNode) == 32, "node must be 32 B");
 // 16-B loads instead of four -- the walk is bound by the L1's gather rate, one cycle per lane and
 // load instruction). The child boxes are quantised to 16 bit per coordinate in the frame of their
 // tree (TLAS, or the mesh's BLAS): coordinate = origin + q * step, rounded outwards.
-//   w[0] = L.lo.x | L.lo.y << 16   w[1] = L.hi.x | L.hi.y << 16   w[2] = L.lo.z | L.hi.z << 16   w[3] = ref L
-//   w[4] = R.lo.x | R.lo.y << 16   w[5] = R.hi.x | R.hi.y << 16   w[6] = R.lo.z | R.hi.z << 16   w[7] = ref R
+//   w[0] = L.lo.x | L.hi.x << 16   w[1] = L.lo.y | L.hi.y << 16   w[2] = L.lo.z | L.hi.z << 16   w[3] = ref L
+//   w[4] = R.lo.x | R.hi.x << 16   w[5] = R.lo.y | R.hi.y << 16   w[6] = R.lo.z | R.hi.z << 16   w[7] = ref R
+//   (one word per axis: the walk picks the near / far plane of an axis out of its word with one v_perm_b32, dev_trace.hpp: qPlane)
 //   ref = (index << 3) | count: count == 0 -> index of the child's own pair record, count > 0 -> first
 //   triangle record (BLAS) / first instance slot (TLAS) of the leaf
 struct alignas(16) NodePair {
