@@ -300,7 +300,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
         total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
     s->info.bytes_total = total;
     // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_trace.hpp: Walker,
-    // processRayQuery): half a NodePair per child box; a TriRecord; a WalkInstance (80) per instance entry; the triangle's TriRecord (48) + NormalRecord (48) + Geometry (24) +
+    // processRayQuery): half a NodePair per child box; a TriRecord; a WalkInstance (80) per instance entry; the triangle's TriRecord (64) + NormalRecord (48) + Geometry (24) +
     // Material (24) + the instance record (112) per reconstructed hit
     s->info.layout_box_bytes = sizeof(NodePair) / 2;
     s->info.layout_triangle_bytes = sizeof(TriRecord);

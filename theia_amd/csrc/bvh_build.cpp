@@ -373,9 +373,11 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
             TriRecord tr;
             std::memset(&tr, 0, sizeof(tr));
             const uint32_t* ix = md.indices + 3 * (size_t)p.id;
-            std::memcpy(tr.v0, md.vertices + 6 * (size_t)ix[0], 12);
-            std::memcpy(tr.v1, md.vertices + 6 * (size_t)ix[1], 12);
-            std::memcpy(tr.v2, md.vertices + 6 * (size_t)ix[2], 12);
+            for (int k = 0; k < 3; ++k) { // x y z x y
+                const float* vtx = md.vertices + 6 * (size_t)ix[k];
+                std::memcpy(tr.v[k], vtx, 12);
+                std::memcpy(tr.v[k] + 3, vtx, 8);
+            }
             tr.prim = p.id;
             out.tris.push_back(tr);
             NormalRecord nr;

@@ -948,14 +948,28 @@ struct QueryHit {
 #endif
 };
 
+// three consecutive floats at a 4-byte aligned address (a vertex of a TriRecord from byte 0, 4 or 8)
+struct P3 {
+    float x, y, z;
+};
+THX_DEV f3 loadP3(const char* p) {
+    const P3 v = *reinterpret_cast<const P3*>(p);
+    return f3{v.x, v.y, v.z};
+}
+
 struct WoopRay {
-    int kx, ky, kz;
+    uint32_t rot;      // 4 kx: byte offset into a stored vertex (x y z x y) at which (kx, ky, kz) start
     float Sx, Sy, Sz;
+    f3 o;              // the ray's origin in the order (kx, ky, kz)
 };
 
-// Watertight ray/triangle intersection (Woop, Benthin, Wald 2013): shear
-// constants per (object-space) ray.
-THX_DEV WoopRay woopSetup(f3 d) {
+// Watertight ray/triangle intersection (Woop, Benthin, Wald 2013): shear constants per (object-space) ray. kz is the
+// dominant axis of the direction, (kx, ky, kz) a rotation of (x, y, z) -- which the triangle records offer as a byte
+// offset (thx_layout.h: TriRecord). The original also exchanges kx and ky when d[kz] < 0, to keep the winding for
+// culling; nothing is culled here, and the exchange does nothing but negate U, V, W, det and T together -- exactly
+// (a b - c d rounds to the negative of c d - a b) -- so t, the barycentrics and every decision come out bit for bit
+// the same without it (tests: hits bitwise those of the oracle, which does exchange).
+THX_DEV WoopRay woopSetup(f3 d, f3 org) {
     WoopRay w;
     float ax = fabsf(d.x), ay = fabsf(d.y), az = fabsf(d.z);
     int kz = 0;
@@ -963,28 +977,37 @@ THX_DEV WoopRay woopSetup(f3 d) {
     if (az > (kz == 0 ? ax : ay)) kz = 2;
     int kx = kz + 1; if (kx == 3) kx = 0;
     int ky = kx + 1; if (ky == 3) ky = 0;
-    if (comp(d, kz) < 0.0f) { int t = kx; kx = ky; ky = t; }
-    w.kx = kx; w.ky = ky; w.kz = kz;
+    w.rot = 4u * (uint32_t)kx;
     w.Sx = comp(d, kx) / comp(d, kz);
     w.Sy = comp(d, ky) / comp(d, kz);
     w.Sz = 1.0f / comp(d, kz);
+    w.o = f3{comp(org, kx), comp(org, ky), comp(org, kz)};
     return w;
 }
 
-THX_DEV bool woopTri(const WoopRay& w, f3 org, f3 p0, f3 p1, f3 p2, float& t_io, float& b1,
+// p0, p1, p2: the vertices in the order (kx, ky, kz) (loadP3 at TriRecord vertex + w.rot)
+THX_DEV bool woopTri(const WoopRay& w, f3 p0, f3 p1, f3 p2, float& t_io, float& b1,
                      float& b2) {
-    f3 A = p0 - org, B = p1 - org, C = p2 - org;
-    float Akz = comp(A, w.kz), Bkz = comp(B, w.kz), Ckz = comp(C, w.kz);
-    float Ax = comp(A, w.kx) - w.Sx * Akz, Ay = comp(A, w.ky) - w.Sy * Akz;
-    float Bx = comp(B, w.kx) - w.Sx * Bkz, By = comp(B, w.ky) - w.Sy * Bkz;
-    float Cx = comp(C, w.kx) - w.Sx * Ckz, Cy = comp(C, w.ky) - w.Sy * Ckz;
+    f3 A = p0 - w.o, B = p1 - w.o, C = p2 - w.o;
+    float Akz = A.z, Bkz = B.z, Ckz = C.z;
+    float Ax = A.x - w.Sx * Akz, Ay = A.y - w.Sy * Akz;
+    float Bx = B.x - w.Sx * Bkz, By = B.y - w.Sy * Bkz;
+    float Cx = C.x - w.Sx * Ckz, Cy = C.y - w.Sy * Ckz;
     float U = Cx * By - Cy * Bx;
     float Vv = Ax * Cy - Ay * Cx;
     float W = Bx * Ay - By * Ax;
     if (U == 0.0f || Vv == 0.0f || W == 0.0f) { // edge-on: decide in double
-        U = (float)((double)Cx * (double)By - (double)Cy * (double)Bx);
-        Vv = (float)((double)Ax * (double)Cy - (double)Ay * (double)Cx);
-        W = (float)((double)Bx * (double)Ay - (double)By * (double)Ax);
+        // (The one place where leaving out the exchange could show: a difference that cancels to zero is +0 whichever way
+        // round it is taken, not the negative of the other. Where the original exchanges (d[kz] < 0) take the differences
+        // its way round and negate the result: the same value when it is not zero, and the zero that keeps the SIGN of a
+        // zero barycentric coordinate what the original gives.)
+        const bool ex = w.Sz < 0.0f;
+        const double cb = (double)Cx * (double)By, bc = (double)Cy * (double)Bx;
+        const double ac = (double)Ax * (double)Cy, ca = (double)Ay * (double)Cx;
+        const double ba = (double)Bx * (double)Ay, ab = (double)By * (double)Ax;
+        U = ex ? -(float)(bc - cb) : (float)(cb - bc);
+        Vv = ex ? -(float)(ca - ac) : (float)(ac - ca);
+        W = ex ? -(float)(ab - ba) : (float)(ba - ab);
     }
     if ((U < 0.0f || Vv < 0.0f || W < 0.0f) && (U > 0.0f || Vv > 0.0f || W > 0.0f)) return false;
     float det = (U + Vv) + W;
@@ -1192,7 +1215,7 @@ template <class V, bool FAST = false>
 struct Walker {
     Lane<V>& L;
     const float4* nodes;
-    const float4* tris;
+    const char* tris; // TriRecord array, as bytes
     uint32_t depth, ldsN;
     bool s16;
     THX_GLOBAL uint32_t* spill; // this wavefront's deep entries (beyond ldsN): entry e of lane l at e * 64 + l (wave-uniform: lives in SGPRs)
@@ -1213,7 +1236,7 @@ struct Walker {
 
     THX_DEV explicit Walker(Lane<V>& lane) : L(lane) {
         nodes = walkNodes(L);
-        tris = reinterpret_cast<const float4*>(L.a->scene.tris);
+        tris = reinterpret_cast<const char*>(L.a->scene.tris);
         depth = L.a->stack_depth;
         ldsN = L.a->stack_lds;
         // Deep entries: the host sizes the LDS part for what rays typically use and lets the rest of the worst case
@@ -1242,7 +1265,7 @@ struct Walker {
         }
         asm volatile("v_mov_b32 %0, 0x7f800000" : "=v"(infReg));
         sp = 0; cur = WALK_DONE; curInst = 0; inBlas = false; overflow = false;
-        w.kx = 0; w.ky = 1; w.kz = 2; w.Sx = 0; w.Sy = 0; w.Sz = 0;
+        w.rot = 0; w.Sx = 0; w.Sy = 0; w.Sz = 0; w.o = f3{0, 0, 0};
         h.valid = false; h.instance = 0; h.prim = 0; h.t = 0.0f; h.b1 = 0.0f; h.b2 = 0.0f;
     }
     // The host sizes the stack for the scene (hierarchy depth + 2), so a full stack means a broken
@@ -1296,7 +1319,7 @@ struct Walker {
                    (m1.x * dir.x + m1.y * dir.y) + m1.z * dir.z,
                    (m2.x * dir.x + m2.y * dir.y) + m2.z * dir.z};
         sr = qRay(f0, f1, ao, od);
-        w = woopSetup(od);
+        w = woopSetup(od, ao);
         return __float_as_uint(f0.w);
     }
 
@@ -1586,19 +1609,20 @@ struct Walker {
         } else {
             // leaves hold <= 4 triangles; fetch them in pairs before testing so that a
             // leaf costs two memory round trips instead of four (tests stay in order)
-            const float4* tr = tris + 3 * (size_t)first;
+            const char* tr = tris + ((size_t)first * sizeof(TriRecord) + w.rot);
 #pragma unroll
             for (uint32_t i0 = 0; i0 < 4; i0 += 2) {
                 if (i0 >= count) break;
                 const bool two = i0 + 1 < count;
-                float4 a0 = tr[3 * i0], b0 = tr[3 * i0 + 1], c0 = tr[3 * i0 + 2];
-                float4 a1 = a0, b1 = b0, c1 = c0;
-                if (two) { a1 = tr[3 * i0 + 3]; b1 = tr[3 * i0 + 4]; c1 = tr[3 * i0 + 5]; }
+                const char* t0 = tr + i0 * sizeof(TriRecord);
+                f3 a0 = loadP3(t0), b0 = loadP3(t0 + 20), c0 = loadP3(t0 + 40);
+                f3 a1 = a0, b1 = b0, c1 = c0;
+                if (two) { a1 = loadP3(t0 + 64); b1 = loadP3(t0 + 84); c1 = loadP3(t0 + 104); }
                 L.cnt.add(ST_TRIS, two ? 2u : 1u);
-                if (woopTri(w, ao, f3{a0.x, a0.y, a0.z}, f3{b0.x, b0.y, b0.z}, f3{c0.x, c0.y, c0.z}, h.t, h.b1, h.b2)) {
+                if (woopTri(w, a0, b0, c0, h.t, h.b1, h.b2)) {
                     h.valid = true; h.instance = curInst; h.prim = first + i0;
                 }
-                if (two && woopTri(w, ao, f3{a1.x, a1.y, a1.z}, f3{b1.x, b1.y, b1.z}, f3{c1.x, c1.y, c1.z}, h.t, h.b1, h.b2)) {
+                if (two && woopTri(w, a1, b1, c1, h.t, h.b1, h.b2)) {
                     h.valid = true; h.instance = curInst; h.prim = first + i0 + 1u;
                 }
             }
@@ -1673,10 +1697,10 @@ THX_DEV int processRayQuery(Lane<V>& L, f3 rayDir, uint64_t rayMedium, const Que
     const InstanceRecord* inst = sc.instances + q.instance;
     const GeometryGLSL geom = sc.geometries[q.instance];
     hit.customId = inst->customIndex;
-    const float4* tv = reinterpret_cast<const float4*>(sc.tris + q.prim);
+    const char* tv = reinterpret_cast<const char*>(sc.tris + q.prim);
     const float4* tn = reinterpret_cast<const float4*>(sc.normals + q.prim);
-    const float4 v0 = tv[0], v1 = tv[1], v2 = tv[2], m0 = tn[0], m1 = tn[1], m2 = tn[2];
-    f3 p0 = f3{v0.x, v0.y, v0.z}, p1 = f3{v1.x, v1.y, v1.z}, p2 = f3{v2.x, v2.y, v2.z};
+    const f3 p0 = loadP3(tv), p1 = loadP3(tv + 20), p2 = loadP3(tv + 40);
+    const float4 m0 = tn[0], m1 = tn[1], m2 = tn[2];
     f3 n0 = f3{m0.x, m0.y, m0.z}, n1v = f3{m1.x, m1.y, m1.z}, n2v = f3{m2.x, m2.y, m2.z};
     float bx = q.b1, by = q.b2;
     f3 e1 = p1 - p0, e2 = p2 - p0;

@@ -42,16 +42,15 @@ struct alignas(16) TreeFrame {
 };
 static_assert(sizeof(TreeFrame) == 32, "tree frame must be 32 B");
 
-// Triangle record in BVH leaf order, 48 B = three 16-B loads.
+// Triangle record in BVH leaf order, 64 B (half a cache line, never across two). Every vertex is stored as x y z x y:
+// the ray/triangle test wants the coordinates in the order (kx, ky, kz) with kz the ray's dominant axis -- a rotation of
+// (x, y, z) -- and reads it as three consecutive floats from byte 0, 4 or 8 of the vertex (one 12-B load) instead of
+// picking nine values with two selects each (dev_trace.hpp: woopSetup / woopTri).
 struct alignas(16) TriRecord {
-    float v0[3];
+    float v[3][5]; // vertex k: x y z x y
     uint32_t prim; // index into the mesh's Index buffer
-    float v1[3];
-    uint32_t pad0;
-    float v2[3];
-    uint32_t pad1;
 };
-static_assert(sizeof(TriRecord) == 48, "triangle record must be 48 B");
+static_assert(sizeof(TriRecord) == 64, "triangle record must be 64 B");
 
 // Vertex normals of a triangle in BVH leaf order, 48 B, next to its TriRecord: with them a hit is reconstructed from
 // two records addressed by the hit itself, not through geometry -> index triple -> three vertices (three dependent loads).
