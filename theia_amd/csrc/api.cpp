@@ -250,6 +250,11 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     thx_scene* s = new (std::nothrow) thx_scene();
     if (!s) return fail(THX_ERR_INVALID, "out of host memory");
     s->ctx = ctx;
+    // one record of padding behind the last triangle: the walk asks for a leaf's triangles two at a time, whether or not
+    // the second one belongs to the leaf (dev_trace.hpp: Walker::advance)
+    const size_t nTriangles = built.tris.size();
+    built.tris.emplace_back();
+    std::memset(&built.tris.back(), 0, sizeof(TriRecord));
     int rc;
     void* p;
 #define UP(vec, field, T)                                                          \
@@ -287,12 +292,12 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     s->view.nInstances = n_instances;
 
     s->info.n_nodes = (uint32_t)built.nodes.size();
-    s->info.n_triangles = (uint32_t)built.tris.size();
+    s->info.n_triangles = (uint32_t)nTriangles;
     s->info.n_instances = n_instances;
     s->info.max_depth = built.maxDepth;
     s->info.bytes_nodes = built.pairs.size() * sizeof(NodePair) + built.frames.size() * sizeof(TreeFrame);
     s->nPairs = (uint32_t)built.pairs.size();
-    s->info.bytes_triangles = built.tris.size() * (sizeof(TriRecord) + sizeof(NormalRecord));
+    s->info.bytes_triangles = nTriangles * (sizeof(TriRecord) + sizeof(NormalRecord));
     s->info.bytes_instances = built.instances.size() * sizeof(InstanceRecord);
     uint64_t total = s->info.bytes_nodes + s->info.bytes_triangles + s->info.bytes_instances +
                      built.walkInstances.size() * sizeof(WalkInstance) + geo.size() * sizeof(GeometryGLSL);

@@ -1615,9 +1615,11 @@ struct Walker {
                 if (i0 >= count) break;
                 const bool two = i0 + 1 < count;
                 const char* t0 = tr + i0 * sizeof(TriRecord);
-                f3 a0 = loadP3(t0), b0 = loadP3(t0 + 20), c0 = loadP3(t0 + 40);
-                f3 a1 = a0, b1 = b0, c1 = c0;
-                if (two) { a1 = loadP3(t0 + 64); b1 = loadP3(t0 + 84); c1 = loadP3(t0 + 104); }
+                // (the record behind is asked for at once, whether or not it belongs to the leaf -- the array ends with a record of
+                // padding: as "copy the first, load the second if the leaf has one" the copies waited for the first record
+                // before the second was requested, two round trips again)
+                const f3 a0 = loadP3(t0), b0 = loadP3(t0 + 20), c0 = loadP3(t0 + 40);
+                const f3 a1 = loadP3(t0 + 64), b1 = loadP3(t0 + 84), c1 = loadP3(t0 + 104);
                 L.cnt.add(ST_TRIS, two ? 2u : 1u);
                 if (woopTri(w, a0, b0, c0, h.t, h.b1, h.b2)) {
                     h.valid = true; h.instance = curInst; h.prim = first + i0;
