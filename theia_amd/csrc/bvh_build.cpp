@@ -16,7 +16,7 @@ namespace thx {
 
 namespace {
 
-constexpr uint32_t kSmallMeshTriangles = 16384;
+constexpr uint32_t kSmallMeshTriangles = 1u << 20;
 
 struct Box {
     float lo[3], hi[3];
@@ -353,8 +353,9 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
         }
         std::vector<BvhNode> local;
         // The walk handles up to 4 triangles per leaf (two pairs), but a wavefront pays for the fullest leaf any of its
-        // lanes holds: small leaves win although they deepen the tree -- 2 on meshes whose hierarchy stays in the
-        // caches, 3 on larger ones where every extra level is a memory round trip (profiles/r02_park.txt).
+        // lanes holds: small leaves win although they deepen the tree -- 2 up to a million triangles (round 3, with the cheaper
+        // inner-node visit: 81 920 triangles -2.3 % against 3), 3 beyond, where 2 is no faster and the hierarchy a third larger
+        // (profiles/r02_park.txt, profiles/r03_inner_loop.txt item 19).
         uint32_t leafMax = md.n_triangles > kSmallMeshTriangles ? 3u : 2u;
         if (const char* e = std::getenv("THX_LEAF_MAX")) leafMax = std::min(4u, std::max(1u, (uint32_t)std::atoi(e)));
         auto [root, depth] = buildTree(prims, local, leafMax, blasLimit);
