@@ -1009,9 +1009,10 @@ THX_DEV bool woopTri(const WoopRay& w, f3 p0, f3 p1, f3 p2, float& t_io, float& 
         Vv = ex ? -(float)(ca - ac) : (float)(ac - ca);
         W = ex ? -(float)(ab - ba) : (float)(ba - ab);
     }
-    if ((U < 0.0f || Vv < 0.0f || W < 0.0f) && (U > 0.0f || Vv > 0.0f || W > 0.0f)) return false;
+    // (one decision instead of a chain of short-circuit branches: every one of those is a hand-over to the scalar unit and back)
+    const int mixed = (int)(fminf(fminf(U, Vv), W) < 0.0f) & (int)(fmaxf(fmaxf(U, Vv), W) > 0.0f);
     float det = (U + Vv) + W;
-    if (det == 0.0f) return false;
+    if ((mixed | (int)(det == 0.0f)) != 0) return false;
     float Az = w.Sz * Akz, Bz = w.Sz * Bkz, Cz = w.Sz * Ckz;
     float T = (U * Az + Vv * Bz) + W * Cz;
     float rcpDet = 1.0f / det;
