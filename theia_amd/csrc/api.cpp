@@ -305,12 +305,14 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
         total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
     s->info.bytes_total = total;
     // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_trace.hpp: Walker,
-    // processRayQuery): half a NodePair per child box; a TriRecord; a WalkInstance (80) per instance entry; the triangle's TriRecord (64) + NormalRecord (48) + Geometry (24) +
-    // Material (24) + the instance record (112) per reconstructed hit
+    // processRayQuery): half a NodePair per child box; the three 12-B vertex loads of a triangle test (its TriRecord is 64 B: every
+    // vertex is stored as x y z x y and read from byte 0 / 4 / 8); a WalkInstance (80) per instance entry; per reconstructed hit the
+    // triangle's three vertices (36) + NormalRecord (48) + Geometry (24) + Material (24) + the instance record (112)
+    constexpr uint32_t kTriangleLoadBytes = 36;
     s->info.layout_box_bytes = sizeof(NodePair) / 2;
-    s->info.layout_triangle_bytes = sizeof(TriRecord);
+    s->info.layout_triangle_bytes = kTriangleLoadBytes;
     s->info.layout_instance_bytes = sizeof(WalkInstance);
-    s->info.layout_hit_bytes = sizeof(TriRecord) + sizeof(NormalRecord) + sizeof(GeometryGLSL) + sizeof(MaterialGLSL) + sizeof(InstanceRecord);
+    s->info.layout_hit_bytes = kTriangleLoadBytes + sizeof(NormalRecord) + sizeof(GeometryGLSL) + sizeof(MaterialGLSL) + sizeof(InstanceRecord);
     *out = s;
     return THX_OK;
 }
