@@ -400,8 +400,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     const bool pol = (desc->flags & THX_FLAG_POLARIZED) != 0;
     const bool mis = (desc->flags & THX_FLAG_DISABLE_MIS) == 0;
     if (!replay) t->variant = traceVariant(desc->kind, pol, mis);
-    // the record response is compiled into the instrumented variants only
-    t->debug = record || (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK)) != 0;
+    // the record response and the Sobol sampler are compiled into the instrumented variants only
+    t->debug = record || (desc->flags & (THX_FLAG_STATISTICS | THX_FLAG_TRACK | THX_FLAG_RNG_SOBOL)) != 0;
     t->block = replay ? kReplayBlock : kTraceBlock;
     if (scene) {
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);

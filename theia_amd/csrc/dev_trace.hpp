@@ -14,6 +14,10 @@ struct Variant {
     static constexpr bool MIS = MIS_;       // !DISABLE_MIS
     static constexpr bool STATS = STATS_;   // EventStatisticCallback + traversal counters
     static constexpr bool TRACK = TRACK_;   // per-event dump
+    // The scrambled Sobol sampler (THX_FLAG_RNG_SOBOL) is compiled into the instrumented variants only, which the host picks for
+    // it: inlined behind a run-time flag at each of the ~50 places a kernel draws a number it made the production kernels a
+    // quarter larger than the 64 KB of instruction cache two CUs share (round 3: 72 KB -> 55 KB).
+    static constexpr bool QRNG = STATS_;
     // What is known about the traversal stack at compile time. 0: nothing (entry width and the split between LDS and global
     // memory are decided at run time); 1: 16-bit entries (scenes below 8 190 nodes / triangles / instances); 2: 16-bit
     // entries and the whole stack in LDS (such scenes no deeper than the LDS share). Every push and pop loses a
@@ -109,16 +113,20 @@ struct Lane {
 // scrambled Sobol sampler (its seed travels in philox.key[0])
 template <class V>
 THX_DEV float draw(Lane<V>& L) {
-    if (L.a->flags & THX_FLAG_RNG_SOBOL) return rndSobol(L.a->p.philox.key[0], L.idx, L.dim);
+    if constexpr (V::QRNG) {
+        if (L.a->flags & THX_FLAG_RNG_SOBOL) return rndSobol(L.a->p.philox.key[0], L.idx, L.dim);
+    }
     return rnd(L.a->p.philox, L.idx, L.dim);
 }
 // random2D(idx, dim): two consecutive Philox draws (random.philox.glsl:79-82), or the first two Sobol
 // dimensions at one scrambled index (random.sobol.glsl:178-193)
 template <class V>
 THX_DEV void draw2(Lane<V>& L, float& u0, float& u1) {
-    if (L.a->flags & THX_FLAG_RNG_SOBOL) {
-        rndSobol2(L.a->p.philox.key[0], L.idx, L.dim, u0, u1);
-        return;
+    if constexpr (V::QRNG) {
+        if (L.a->flags & THX_FLAG_RNG_SOBOL) {
+            rndSobol2(L.a->p.philox.key[0], L.idx, L.dim, u0, u1);
+            return;
+        }
     }
     u0 = rnd(L.a->p.philox, L.idx, L.dim);
     u1 = rnd(L.a->p.philox, L.idx, L.dim);
