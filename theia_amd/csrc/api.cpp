@@ -420,8 +420,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     }
     t->mode = (t->debug ? 1u : 0u) | (t->staged ? 2u : 0u);
     if (t->staged) {
-        t->block = kStagedBlock;
-        if (const char* env = std::getenv("THX_THREADS")) t->block = (uint32_t)std::min<int>(kStagedBlock, std::max(64, std::atoi(env) / 64 * 64));
+        const uint32_t fullBlock = t->debug ? kStagedBlockDebug : kStagedBlock;
+        t->block = fullBlock;
+        if (const char* env = std::getenv("THX_THREADS")) t->block = (uint32_t)std::min<int>((int)fullBlock, std::max(64, std::atoi(env) / 64 * 64));
         size_t budget = (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor - 2048; // whole CU, one workgroup
         if (const char* env = std::getenv("THX_POOL_LDS_KB")) budget = (size_t)std::max(16, std::atoi(env)) * 1024;
         // Deep hierarchies: rays use the worst-case depth rarely, so only the first kStackLds entries (THX_STACK_LDS)
@@ -457,7 +458,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (stackAllLds) t->mode |= 8u; // ... and with the whole stack in LDS
         // Small scenes: the walk reads its pair records from a copy in LDS if that leaves a pool of kLdsNodeMinPool photons
         // (THX_LDS_NODES=0 / 1: never / whenever it fits at all)
-        if ((t->mode & 4u) && t->block == kStagedBlock) { // (16-bit stack entries: the variants that exist with the copy)
+        if ((t->mode & 4u) && t->block == fullBlock) { // (16-bit stack entries: the variants that exist with the copy)
             const size_t nodeBytes = (size_t)scene->nPairs * sizeof(NodePair);
             const uint32_t poolN = std::min(stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, nodeBytes, xr), kPoolBest);
             bool use = nodeBytes <= kLdsNodeMaxBytes && poolN >= kLdsNodeMinPool;

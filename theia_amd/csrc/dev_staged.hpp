@@ -31,6 +31,11 @@
 namespace thx {
 
 constexpr uint32_t kSchedThreads = 1024; // upper bound of the workgroup size
+// ... of the instrumented variants (statistics, track record, hit queue, Sobol sampler): 12 wavefronts leave every lane 168
+// registers instead of 128. At 128 they kept 25-30 values in scratch memory, and three times in round 3 a harmless change elsewhere
+// made ONE of them misbehave (photons traced differently, a tripped watchdog, a wild address) while the production variants, which
+// never spill, and the other instrumented ones stayed exact (profiles/r03_inner_loop.txt items 10, 16, 22): no spills any more.
+constexpr uint32_t kSchedThreadsDebug = 768;
 #ifndef THX_POOL_MAX
 #define THX_POOL_MAX 2048 // upper bound of the photon pool of a workgroup (ring entries: 11-bit slot id, bit 11 = a walk taken up again)
 #endif
@@ -328,7 +333,7 @@ THX_DEV int postPrimary(Lane<V>& L, const Pool<V>& pool, uint32_t slot, const Qu
 // The walk of one batch: one ray per lane, fresh or taken up again (Walker::start), round by round until every
 // lane is through -- or until so few are left that they are set aside (`parked`, see LaunchArgs::park_below).
 template <class V>
-THX_DEV QueryHit walkBatch(Lane<V>& L, f3 org, f3 dir, float tmax, bool resumed, THX_GLOBAL uint32_t* area, bool& parked) {
+THX_DEV QueryHit walkBatch(Lane<V>& L, f3 org, f3 dir, float tmax, bool resumed, THX_GLOBAL uint32_t* area, bool& parked, uint32_t freeRing2, uint32_t busyMin) {
     Walker<V, true> wk(L);
     wk.start(org, dir, tmax, resumed, area);
     uint32_t rounds = 0;
@@ -336,11 +341,18 @@ THX_DEV QueryHit walkBatch(Lane<V>& L, f3 org, f3 dir, float tmax, bool resumed,
         const unsigned long long walking = __ballot(!wk.done());
         if (walking == 0ull) break;
         if (rounds >= L.a->park_rounds && (uint32_t)__popcll(walking) < L.a->park_below) {
-            if (!wk.done()) {
-                wk.save(area);
-                parked = true;
+            // Setting rays aside frees the wavefront for a fuller batch -- worth it while the workgroup has photons for every
+            // wavefront. At the end of a launch, when the pool runs empty, it only adds hand-overs to the life of the last
+            // photons, which is what the launch then waits for: with fewer photons in flight than 3/4 of the lanes (of the pool), walk on.
+            const unsigned long long fr = ldsRead64(freeRing2); // {head, tail} of the ring of free slots
+            const uint32_t inFlight = L.a->pool - ((uint32_t)(fr >> 32) - (uint32_t)fr);
+            if (inFlight >= busyMin) {
+                if (!wk.done()) {
+                    wk.save(area);
+                    parked = true;
+                }
+                break;
             }
-            break;
         }
 #ifdef THX_STAGE_PROFILE
         if (L.prof != nullptr && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(__ballot(1))) {
@@ -691,7 +703,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
 #endif
                 QueryHit h = walkBatch(L, f3{c0.x, c0.y, c0.z}, dir, tmax, resumed,
                                        (THX_GLOBAL uint32_t*)(args.park) + ((size_t)(blockIdx.x * P + slot) * 2u + (which == 2u ? 1u : 0u)) * (8u + args.stack_depth),
-                                       parked);
+                                       parked, pool.ctrWord / 2u + (uint32_t)S_BIRTH, (min(T, P) * 3u) >> 2);
 #ifdef THX_STAGE_PROFILE
                 // per wave: cycles until the first lane / the whole wave is through the walk
                 const unsigned long long wt1 = __builtin_amdgcn_s_memtime();

@@ -36,7 +36,7 @@ uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerTh
 }
 uint32_t stagedRingCap(uint32_t pool, bool exactRings) { return StagedLayout<false>::qcap(pool, exactRings); }
 size_t stagedColdBytes(bool polarized, uint32_t pool) { return polarized ? StagedLayout<true>::coldBytes(pool) : StagedLayout<false>::coldBytes(pool); }
-static_assert(kStagedBlock == kSchedThreads, "staged block size");
+static_assert(kStagedBlock == kSchedThreads && kStagedBlockDebug == kSchedThreadsDebug, "staged block sizes");
 
 // estimator.reduce.glsl:17-35: out[b] = norm * sum_h slab[h][b] with compensated
 // (Kahan) summation. The reference walks the slabs with one thread per bin; with

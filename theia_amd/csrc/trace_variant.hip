@@ -114,7 +114,7 @@ using DebugM = Variant<THX_POL != 0, THX_MIS != 0, true, true, 4>;
 #if THX_KIND == 1
 // staged (regrouped-in-LDS) form of the scene tracer, see dev_staged.hpp
 template <class V>
-__global__ void __launch_bounds__(kSchedThreads) sceneStagedKernel(const LaunchArgs args) {
+__global__ void __launch_bounds__(V::STATS ? kSchedThreadsDebug : kSchedThreads) sceneStagedKernel(const LaunchArgs args) {
     sceneStagedBody<V>(args);
 }
 #endif
