@@ -430,7 +430,8 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
         if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
         // one more slot per lane below entry 0 (dev_trace.hpp: Walker<V, FAST>)
-        const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth;
+        // (the variants compiled for a stack that is all in LDS do not check for a full stack: only where it cannot fill up)
+        const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth && t->stackDepth >= scene->info.max_depth + 2;
         t->stackSlots = t->stackLds + 1u;
         const uint32_t stackBytes = t->stackSlots * (t->stack16 ? 2u : 4u);
         // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %.

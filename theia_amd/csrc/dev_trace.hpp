@@ -1158,6 +1158,11 @@ THX_DEV float minRaw(float a, float b) {
     asm("v_min_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
     return r;
 }
+THX_DEV float maxRaw(float a, float b) {
+    float r;
+    asm("v_max_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
 THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax, float inf) {
 #ifdef THX_SLAB_MINMAX
     const float t = slabChildFar(c, r, tmax);
@@ -1507,7 +1512,8 @@ struct Walker {
         const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
         const bool leftFirst = tl <= tr;
         const uint32_t nearRef = leftFirst ? ml : mr, farRef = leftFirst ? mr : ml;
-        const bool both = fmaxf(tl, tr) < INFINITY, none = fminf(tl, tr) == INFINITY;
+        // (raw: the distances are selects between a plane distance and the +inf register, which the compiler would canonicalise first)
+        const bool both = maxRaw(tl, tr) < INFINITY, none = minRaw(tl, tr) == INFINITY;
         if (V::S16) stack16[sp << 6] = (uint16_t)farRef;
         else stack32[sp << 6] = farRef;
         sp = sp + (both ? 1u : 0u) - (none ? 1u : 0u);
@@ -1526,12 +1532,14 @@ struct Walker {
         const uint32_t innerKeep = ((uint32_t)__popcll(__ballot((cur & 7u) == 0u)) * (uint32_t)THX_INNER_KEEP) >> 3;
 #if !defined(THX_BVH4) && !defined(THX_BRANCHY_INNER)
         // Staged kernel: straight-line visits (visitStraight) while a lane's stack top is inside the LDS part. Variants with
-        // the whole stack in LDS run nothing else (the loop below is there for a full stack, which the host's sizing rules
-        // out: push() flags it); on deeper scenes a lane beyond its LDS part takes the branchy visit for those trips.
+        // the whole stack in LDS run nothing else and do not look at the stack pointer at all: the host picks them only
+        // when the stack holds the hierarchy's depth + 2 entries, which a walk cannot exceed (a stack made shallower by the
+        // THX_STACK_DEPTH test hook runs the split-stack variants, whose push() flags the overflow). On deeper scenes a lane
+        // beyond its LDS part takes the branchy visit for those trips.
         if constexpr (FAST) {
             bool leftEarly = false;
             // (one test per trip: it is the loop's condition and what the early exit counts)
-            bool go = (cur & 7u) == 0u && (V::SPILL || sp < ldsN);
+            bool go = (cur & 7u) == 0u;
             while (go) {
 #ifdef THX_STAGE_PROFILE
                 pLane += 1;
@@ -1548,7 +1556,7 @@ struct Walker {
                 else visitBranchy();
                 const bool atInner = (cur & 7u) == 0u;
                 const unsigned long long goMask = __builtin_amdgcn_ballot_w64(atInner); // (the comparison's own mask)
-                go = atInner && (V::SPILL || sp < ldsN);
+                go = atInner;
                 if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(goMask) < innerKeep) { leftEarly = true; break; }
             }
             if (cur == WALK_DONE) sp = 0; // (popping the sentinel slot took the stack pointer below zero)
