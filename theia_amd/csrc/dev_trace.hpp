@@ -1537,13 +1537,15 @@ struct Walker {
         // THX_STACK_DEPTH test hook runs the split-stack variants, whose push() flags the overflow). On deeper scenes a lane
         // beyond its LDS part takes the branchy visit for those trips.
         if constexpr (FAST) {
-            bool leftEarly = false;
-            // (one test per trip: it is the loop's condition and what the early exit counts)
+            // (one test per trip: it is the loop's condition and what the early exit counts; ONE way out of the loop -- with a
+            // `break` for the early exit next to the per-lane condition the compiler kept two sets of masks up to date, 17 scalar
+            // instructions per trip, and a wavefront's trip lasts about as many times 8 cycles as it has instructions of ANY kind)
             bool go = (cur & 7u) == 0u;
             while (go) {
 #ifdef THX_STAGE_PROFILE
                 pLane += 1;
                 pTrips += 1;
+#ifndef THX_PROF_LEAN // (the per-trip occupancy counters are two LDS atomics in the middle of the loop: -DTHX_PROF_LEAN times the loop without them)
                 {
                     const unsigned long long m = __ballot(1);
                     if (L.prof != nullptr && (threadIdx.x & 63u) == (uint32_t)__builtin_ctzll(m)) {
@@ -1552,15 +1554,15 @@ struct Walker {
                     }
                 }
 #endif
+#endif
                 if (!V::SPILL || sp < ldsN) visitStraight();
                 else visitBranchy();
                 const bool atInner = (cur & 7u) == 0u;
                 const unsigned long long goMask = __builtin_amdgcn_ballot_w64(atInner); // (the comparison's own mask)
-                go = atInner;
-                if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(goMask) < innerKeep) { leftEarly = true; break; }
+                go = atInner && (THX_INNER_KEEP == 0 || (uint32_t)__popcll(goMask) >= innerKeep);
             }
             if (cur == WALK_DONE) sp = 0; // (popping the sentinel slot took the stack pointer below zero)
-            if (V::SPILL || __ballot(leftEarly) != 0ull) goto innerDone;
+            goto innerDone; // (lanes still at an inner node -- early exit -- go on in the next round)
         }
 #endif
         while ((cur & 7u) == 0u) {
