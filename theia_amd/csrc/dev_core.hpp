@@ -192,46 +192,75 @@ THX_DEV f3 perpendicularTo(f3 a, f3 b) {
 
 // random.philox.glsl:15-52. counter = baseCount + (i << 2) with carry chain
 // and roll-over, key = key + stream; ten rounds.
-THX_DEV void philox4x32(const thx_philox_params& p, uint32_t stream, uint32_t i, uint32_t out[4]) {
+THX_DEV void philoxCounter(const thx_philox_params& p, uint32_t i, uint32_t& sx, uint32_t& sy, uint32_t& sz, uint32_t& sw) {
     uint32_t carry = i << 2;
-    uint32_t sx = p.offset[0], sy = p.offset[1], sz = p.offset[2], sw = p.offset[3];
+    sx = p.offset[0]; sy = p.offset[1]; sz = p.offset[2]; sw = p.offset[3];
     uint32_t t;
     t = sx + carry; carry = t < sx ? 1u : 0u; sx = t;
     t = sy + carry; carry = t < sy ? 1u : 0u; sy = t;
     t = sz + carry; carry = t < sz ? 1u : 0u; sz = t;
     t = sw + carry; carry = t < sw ? 1u : 0u; sw = t;
     sx += carry;
-    uint32_t kx = p.key[0], ky = p.key[1];
+}
+THX_DEV void philoxKey(const thx_philox_params& p, uint32_t stream, uint32_t& kx, uint32_t& ky) {
+    kx = p.key[0]; ky = p.key[1];
+    uint32_t t, carry;
     t = kx + stream; carry = t < kx ? 1u : 0u; kx = t;
     t = ky + carry; carry = t < ky ? 1u : 0u; ky = t;
     kx += carry;
     // (the key words are final here: without this the compiler carries the carry flag through all ten rounds and
     // spends an add-with-carry and a move on every key bump instead of one add)
     asm volatile("" : "+v"(kx), "+v"(ky));
-    constexpr uint32_t M0 = 0xD2511F53u, M1 = 0xCD9E8D57u;
+}
+constexpr uint32_t kPhiloxM0 = 0xD2511F53u, kPhiloxM1 = 0xCD9E8D57u;
+// one round on one block: one 32x32->64 multiply (v_mad_u64_u32) per product instead of mul_hi + mul_lo
+THX_DEV void philoxRound(uint32_t& sx, uint32_t& sy, uint32_t& sz, uint32_t& sw, uint32_t kx, uint32_t ky) {
+    const uint64_t p0 = (uint64_t)kPhiloxM0 * (uint64_t)sx;
+    const uint64_t p1 = (uint64_t)kPhiloxM1 * (uint64_t)sz;
+    const uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
+    const uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
+    const uint32_t nx = hi1 ^ sy ^ kx, nz = hi0 ^ sw ^ ky;
+    sx = nx; sy = lo1; sz = nz; sw = lo0;
+}
+THX_DEV void philox4x32(const thx_philox_params& p, uint32_t stream, uint32_t i, uint32_t out[4]) {
+    uint32_t sx, sy, sz, sw, kx, ky;
+    philoxCounter(p, i, sx, sy, sz, sw);
+    philoxKey(p, stream, kx, ky);
 #pragma unroll
     for (int r = 0; r < 10; ++r) {
-        // one 32x32->64 multiply (v_mad_u64_u32) per product instead of mul_hi + mul_lo:
-        // integer multiplies are quarter rate, so this halves the cost of a round
-        const uint64_t p0 = (uint64_t)M0 * (uint64_t)sx;
-        const uint64_t p1 = (uint64_t)M1 * (uint64_t)sz;
-        uint32_t hi0 = (uint32_t)(p0 >> 32), lo0 = (uint32_t)p0;
-        uint32_t hi1 = (uint32_t)(p1 >> 32), lo1 = (uint32_t)p1;
-        uint32_t nx = hi1 ^ sy ^ kx, nz = hi0 ^ sw ^ ky;
-        sx = nx; sy = lo1; sz = nz; sw = lo0;
+        philoxRound(sx, sy, sz, sw, kx, ky);
         kx += 0x9E3779B9u;
         ky += 0xBB67AE85u;
     }
     out[0] = sx; out[1] = sy; out[2] = sz; out[3] = sw;
 }
+// the blocks of dimensions i and i + 1 of one stream together (random2D): one key, one key schedule, two counters
+THX_DEV void philox4x32_pair(const thx_philox_params& p, uint32_t stream, uint32_t i, uint32_t a[4], uint32_t b[4]) {
+    uint32_t ax, ay, az, aw, bx, by, bz, bw, kx, ky;
+    philoxCounter(p, i, ax, ay, az, aw);
+    philoxCounter(p, i + 1u, bx, by, bz, bw);
+    philoxKey(p, stream, kx, ky);
+#pragma unroll
+    for (int r = 0; r < 10; ++r) {
+        philoxRound(ax, ay, az, aw, kx, ky);
+        philoxRound(bx, by, bz, bw, kx, ky);
+        kx += 0x9E3779B9u;
+        ky += 0xBB67AE85u;
+    }
+    a[0] = ax; a[1] = ay; a[2] = az; a[3] = aw;
+    b[0] = bx; b[1] = by; b[2] = bz; b[3] = bw;
+}
 
 // random.philox.glsl:54-77: the cached block is never reused by the reference
 // (philoxBufferCount stays 0), so random_s(stream,i) == philox(stream,i)[i & 3].
+THX_DEV uint32_t philoxWord(const uint32_t s[4], uint32_t i) {
+    const uint32_t l = i & 3u;
+    return l == 0 ? s[0] : (l == 1 ? s[1] : (l == 2 ? s[2] : s[3]));
+}
 THX_DEV uint32_t random_u32(const thx_philox_params& p, uint32_t stream, uint32_t i) {
     uint32_t s[4];
     philox4x32(p, stream, i, s);
-    uint32_t l = i & 3u;
-    return l == 0 ? s[0] : (l == 1 ? s[1] : (l == 2 ? s[2] : s[3]));
+    return philoxWord(s, i);
 }
 // random.util.glsl:4-9 (uint->float conversion: round to nearest even)
 THX_DEV float normalizeUint(uint32_t i) {
@@ -242,6 +271,14 @@ THX_DEV float rnd(const thx_philox_params& p, uint32_t stream, uint32_t& dim) {
     float r = normalizeUint(random_u32(p, stream, dim));
     dim += 1;
     return r;
+}
+// two consecutive draws (random.philox.glsl:79-82 random2D): the same two numbers as two calls of rnd()
+THX_DEV void rnd2(const thx_philox_params& p, uint32_t stream, uint32_t& dim, float& u0, float& u1) {
+    uint32_t a[4], b[4];
+    philox4x32_pair(p, stream, dim, a, b);
+    u0 = normalizeUint(philoxWord(a, dim));
+    u1 = normalizeUint(philoxWord(b, dim + 1u));
+    dim += 2;
 }
 
 // random.sobol.glsl: shuffled, Owen-scrambled Sobol sampler (Burley 2020), padded to higher

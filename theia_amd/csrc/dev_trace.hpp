@@ -128,8 +128,7 @@ THX_DEV void draw2(Lane<V>& L, float& u0, float& u1) {
             return;
         }
     }
-    u0 = rnd(L.a->p.philox, L.idx, L.dim);
-    u1 = rnd(L.a->p.philox, L.idx, L.dim);
+    rnd2(L.a->p.philox, L.idx, L.dim, u0, u1);
 }
 
 // ray.glsl:136-143
