@@ -506,7 +506,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (nb) e = hipMalloc((void**)&t->cold, nb);
         const size_t sb = sizeof(uint32_t) * 64u * (t->block / 64u) * (size_t)(t->stackDepth - t->stackLds) * t->gridMax;
         if (e == hipSuccess && sb) e = hipMalloc((void**)&t->spill, sb);
-        const size_t pb = sizeof(uint32_t) * 2u * (8u + t->stackDepth) * (size_t)t->pool * t->gridMax;
+        const size_t pb = sizeof(uint32_t) * 2u * (8u + std::max(t->stackDepth, 8u)) * (size_t)t->pool * t->gridMax; // (a walk is taken up again with eight entries at once)
         if (e == hipSuccess) e = hipMalloc((void**)&t->park, pb);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);

@@ -702,7 +702,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 const unsigned long long wt0 = __builtin_amdgcn_s_memtime();
 #endif
                 QueryHit h = walkBatch(L, f3{c0.x, c0.y, c0.z}, dir, tmax, resumed,
-                                       (THX_GLOBAL uint32_t*)(args.park) + ((size_t)(blockIdx.x * P + slot) * 2u + (which == 2u ? 1u : 0u)) * (8u + args.stack_depth),
+                                       (THX_GLOBAL uint32_t*)(args.park) + ((size_t)(blockIdx.x * P + slot) * 2u + (which == 2u ? 1u : 0u)) * (8u + max(args.stack_depth, 8u)),
                                        parked, pool.ctrWord / 2u + (uint32_t)S_BIRTH, (min(T, P) * 3u) >> 2);
 #ifdef THX_STAGE_PROFILE
                 // per wave: cycles until the first lane / the whole wave is through the walk
