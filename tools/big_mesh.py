@@ -8,9 +8,20 @@ sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
 import numpy as np
 from theia_amd import workloads as S
 
-n = int(sys.argv[1]) if len(sys.argv) > 1 else 1_000_000
-levels = [int(a) for a in sys.argv[2:]] or [0, 2, 3, 4, 5]
+prod = "--prod" in sys.argv  # production kernel variant (no counters): kernel time only
+argv = [a for a in sys.argv if a != "--prod"]
+n = int(argv[1]) if len(argv) > 1 else 1_000_000
+levels = [int(a) for a in argv[2:]] or [0, 2, 3, 4, 5]
 for k in levels:
+    if prod:
+        sc = S.config2_sphere(batch=n, subdivide=k)
+        ms = []
+        for i in range(12):
+            S.run_batches(sc, 1)
+            ms.append(sc.tracer.program.last_kernel_ms(0))
+        li = sc.tracer.program.launch_info(n)
+        print(f"k={k} tris={1280 * 4**k:8d} block={li['block']:4d} pool-lds={li['lds_bytes']} kernel={np.median(ms[-5:]):8.3f} ms (production variant)", flush=True)
+        continue
     t0 = time.time()
     sc = S.config2_sphere(batch=n, stats=True, subdivide=k)
     info = sc.scene.info if hasattr(sc.scene, "info") else {}
