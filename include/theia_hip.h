@@ -31,6 +31,12 @@ extern "C" {
 #define THX_ERR_DEVICE (-5)      /* a kernel reported an error through the tracer's device error word (THX_DEVERR_*) */
 #define THX_DEVERR_WATCHDOG 1u   /* the staged kernel's scheduler watchdog tripped: the batch is incomplete */
 
+/* Slots. Every call that takes a `cfg` / `slot` index addresses one of THX_MAX_SLOTS result slots of a tracer (partial
+ * histograms, reduced curve, readback buffer). Slots 0 and 1 are the two pipeline configs of the reference
+ * (docs/pipeline/pipeline.md:32-38); a host that keeps more than two batches in flight (theia_amd.hp.pipeline.PipelineScheduler
+ * does, behind the two-config facade) uses the others as well. Slots beyond 1 are allocated on first use. */
+#define THX_MAX_SLOTS 16
+
 typedef struct thx_ctx thx_ctx;
 typedef struct thx_scene thx_scene;
 typedef struct thx_tracer thx_tracer;
@@ -300,14 +306,35 @@ int thx_scene_query_ms(const thx_scene* scene, float* ms);
 int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scene_or_null,
                       thx_tracer** out);
 int thx_tracer_destroy(thx_tracer* tracer);
-/* launches one batch for pipeline config `cfg` (0/1) on `stream`
- * (hipStream_t; NULL = the context's stream) */
+/* launches one batch into slot `cfg` (0 / 1 = the pipeline configs, < THX_MAX_SLOTS) on `stream`
+ * (hipStream_t; NULL = the stream of the slot's lane, see thx_tracer_set_concurrency). The parameter block is
+ * consumed by the call (copied into the kernel arguments): the caller may change it right away. Tracers fed
+ * from host queues (THX_FLAG_LIGHT_HOST / _WAVELENGTH_HOST) have device queues for slots 0 and 1 only. */
 int thx_tracer_run(thx_tracer* tracer, uint32_t cfg, const thx_run_params* params, void* stream);
+/* Batches side by side. A launch of the tracing kernels ends with the life of its last photons -- up to path_length
+ * steps one after the other, ~20 us each, while its workgroups run empty (config 2: 0.22 ms per launch whatever the
+ * batch size, profiles/r03_launch_tail.txt). With `lanes` > 1, slot s runs on lane s % lanes -- a stream and a share of
+ * the tracer's scratch memory of its own -- and a launch takes at most 1 / grid_divisor of the chip's workgroups, so that
+ * several batches are in flight at once and the tail of one is covered by the others (the reference's scheduler keeps
+ * configs 0 / 1 in flight the same way, docs/pipeline/pipeline.md:74-92). lanes > grid_divisor oversubscribes the chip:
+ * workgroups of the next batch start wherever one of an earlier batch ends. (1, 1) (default): every launch takes the
+ * whole chip, all slots share the context's stream. Waits for the tracer's work in flight. lanes in [1, THX_MAX_SLOTS],
+ * grid_divisor in [1, lanes]; tracers with ONE output queue or track buffer (record / store-time responses, light
+ * sampler, hit replay, THX_FLAG_TRACK) accept (1, 1) only. The HIP runtime runs as many kernels side by side as it has
+ * hardware queues for (GPU_MAX_HW_QUEUES, read when HIP initialises; measured on MI355X: half that number). */
+int thx_tracer_set_concurrency(thx_tracer* tracer, uint32_t lanes, uint32_t grid_divisor);
 /* HistogramReducer.run (response.py:1188-1197; shader/estimator.reduce.glsl):
  * out[b] = norm * KahanSum_h slab[h][b]; d_out == 0 -> internal buffer of cfg */
 int thx_tracer_reduce(thx_tracer* tracer, uint32_t cfg, float norm, uint64_t d_out, void* stream);
 /* hp.retrieveTensor + response.result(i) (response.py:1184-1186, 1357-1365) */
 int thx_tracer_read_hist(thx_tracer* tracer, uint32_t cfg, float* out, uint32_t n_bins);
+/* Asynchronous form of thx_tracer_read_hist: _fetch_hist enqueues the copy of slot `cfg`'s reduced curve and of the device
+ * error word into a pinned host buffer of the tracer behind whatever is queued on `stream` (NULL = the slot's lane) and
+ * returns; _collect_hist waits for THAT copy only (other slots' batches keep running), performs the checks of
+ * thx_tracer_read_hist and hands the curve over. One fetch in flight per slot. (hp.retrieveTensor is a command in the
+ * reference's timeline as well; the scheduler's process thread waits for it, docs/pipeline/pipeline.md:80-88.) */
+int thx_tracer_fetch_hist(thx_tracer* tracer, uint32_t cfg, void* stream);
+int thx_tracer_collect_hist(thx_tracer* tracer, uint32_t cfg, float* out, uint32_t n_bins);
 /* Waits for the tracer's launches and returns THX_ERR_DEVICE if a kernel flagged an error in the tracer's
  * device error word (THX_DEVERR_*; the word is cleared). Every thx_tracer_read_* does the same check; call
  * this after thx_tracer_reduce into an EXTERNAL buffer (d_out != 0), which the library never reads back.

@@ -29,8 +29,9 @@ class _Tracer:
     def __init__(self, spec, scene) -> None:
         self.spec = spec
         self.scene = scene
-        self.raw = [np.zeros(spec.n_bins, np.float32) for _ in range(2)]
-        self.out = [np.zeros(spec.n_bins, np.float32) for _ in range(2)]
+        self.raw = [np.zeros(spec.n_bins, np.float32) for _ in range(capi.MAX_SLOTS)]  # result slots (0 / 1 = the pipeline configs)
+        self.out = [np.zeros(spec.n_bins, np.float32) for _ in range(capi.MAX_SLOTS)]
+        self.fetched = {}
         self.stats = np.zeros(orc.N_STATS, np.uint64)
         self.track = None
         self.hits = None  # HitRecorder queue: uint32 count + columns
@@ -263,6 +264,18 @@ class OracleBackend:
     def tracer_reduce(self, tracer: int, cfg: int, norm: float, d_out: int = 0, stream: int = 0) -> None:
         t = self._tracers[tracer]
         t.out[cfg] = (t.raw[cfg] * np.float32(norm)).astype(np.float32)
+
+    # the asynchronous readback of the HIP backend, synchronous here
+    def tracer_set_concurrency(self, tracer: int, lanes: int, grid_divisor=None) -> None:
+        if not 1 <= int(lanes) <= capi.MAX_SLOTS:
+            raise ValueError("lanes must be in [1, MAX_SLOTS]")
+
+    def tracer_fetch_hist(self, tracer: int, slot: int, stream: int = 0) -> None:
+        t = self._tracers[tracer]
+        t.fetched[slot] = t.out[slot].copy()
+
+    def tracer_collect_hist(self, tracer: int, slot: int, out: np.ndarray) -> None:
+        out[...] = self._tracers[tracer].fetched.pop(slot)
 
     def tracer_read_hist(self, tracer: int, cfg: int, n_bins: int) -> np.ndarray:
         return self._tracers[tracer].out[cfg].copy()

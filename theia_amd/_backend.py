@@ -185,6 +185,19 @@ class HipBackend:
         capi.check(self._lib.thx_tracer_read_hist(C.c_void_p(tracer), int(cfg), out.ctypes.data_as(C.POINTER(C.c_float)), int(n_bins)))
         return out
 
+    def tracer_set_concurrency(self, tracer: int, lanes: int, grid_divisor: int | None = None) -> None:
+        """`lanes` batches in flight, each on a stream of its own and at most 1 / grid_divisor of the chip's workgroups
+        (thx_tracer_set_concurrency; grid_divisor defaults to lanes)"""
+        capi.check(self._lib.thx_tracer_set_concurrency(C.c_void_p(tracer), int(lanes), int(grid_divisor or lanes)))
+
+    def tracer_fetch_hist(self, tracer: int, slot: int, stream: int = 0) -> None:
+        """enqueues the readback of slot `slot`'s curve behind its reduction (asynchronous)"""
+        capi.check(self._lib.thx_tracer_fetch_hist(C.c_void_p(tracer), int(slot), C.c_void_p(stream) if stream else None))
+
+    def tracer_collect_hist(self, tracer: int, slot: int, out: np.ndarray) -> None:
+        """waits for the readback enqueued by tracer_fetch_hist and copies the curve into `out` (float32, n_bins)"""
+        capi.check(self._lib.thx_tracer_collect_hist(C.c_void_p(tracer), int(slot), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
+
     def tracer_hist_ptr(self, tracer: int, cfg: int) -> int:
         out = C.c_uint64()
         capi.check(self._lib.thx_tracer_hist_device_ptr(C.c_void_p(tracer), int(cfg), C.byref(out)))

@@ -63,6 +63,7 @@ FLAG_GUIDE_FLAT = 1 << 23
 FLAG_RNG_SOBOL = 1 << 24
 N_STATS = 20
 TRACK_WORDS = 20
+MAX_SLOTS = 16  # THX_MAX_SLOTS: result slots of a tracer (0 / 1 = the pipeline configs)
 STAT_NAMES = (
     "created", "scattered", "hit", "detected", "volume", "lost", "decayed", "absorbed", "missed",
     "maxIter", "error", "mismatch",
@@ -190,6 +191,9 @@ _PROTOS = {
     "thx_tracer_run": (c_int, [c_void_p, c_uint32, POINTER(RunParams), c_void_p]),
     "thx_tracer_reduce": (c_int, [c_void_p, c_uint32, c_float, c_uint64, c_void_p]),
     "thx_tracer_read_hist": (c_int, [c_void_p, c_uint32, POINTER(c_float), c_uint32]),
+    "thx_tracer_set_concurrency": (c_int, [c_void_p, c_uint32, c_uint32]),
+    "thx_tracer_fetch_hist": (c_int, [c_void_p, c_uint32, c_void_p]),
+    "thx_tracer_collect_hist": (c_int, [c_void_p, c_uint32, POINTER(c_float), c_uint32]),
     "thx_tracer_check": (c_int, [c_void_p]),
     "thx_tracer_hist_device_ptr": (c_int, [c_void_p, c_uint32, POINTER(c_uint64)]),
     "thx_tracer_read_stats": (c_int, [c_void_p, POINTER(c_uint64), c_uint32]),

@@ -32,6 +32,14 @@ class _Program:
         return self._handle
 
     @property
+    def concurrent(self) -> bool:
+        """batches of this program may be in flight side by side: everything a batch writes lives in a slot of its own
+        (not so with a hit queue or a track buffer, of which the tracer has one)"""
+        spec = self._spec
+        return (spec.kind in (capi.TRACER_VOLUME_FORWARD, capi.TRACER_SCENE_FORWARD) and spec.response_kind == capi.RESPONSE_HISTOGRAM
+                and not spec.flags & capi.FLAG_TRACK)
+
+    @property
     def backend(self):
         self.handle
         return self._be
@@ -42,6 +50,15 @@ class _Program:
 
     def reduce(self, cfg: int, norm: float, d_out: int = 0) -> None:
         self.backend.tracer_reduce(self.handle, cfg, norm, d_out)
+
+    def set_concurrency(self, lanes: int, grid_divisor: int | None = None) -> None:
+        self.backend.tracer_set_concurrency(self.handle, lanes, grid_divisor)
+
+    def fetch_hist(self, slot: int) -> None:
+        self.backend.tracer_fetch_hist(self.handle, slot)
+
+    def collect_hist(self, slot: int, out: np.ndarray) -> None:
+        self.backend.tracer_collect_hist(self.handle, slot, out)
 
     def read_hist(self, cfg: int) -> np.ndarray:
         return self.backend.tracer_read_hist(self.handle, cfg, self._spec.n_bins)

@@ -24,6 +24,14 @@ using namespace thx;
 namespace {
 thread_local std::string g_error;
 
+// Batches side by side (thx_tracer_set_concurrency) need hardware queues: the HIP runtime multiplexes its streams onto
+// GPU_MAX_HW_QUEUES of them (default 4) and, measured on MI355X, runs half that many kernels at once (gpurun_out/r04/overlap*:
+// 4 queues: 2 kernels, 8: 4, 16: 8). The variable is read when HIP initialises, so it is set -- unless the user has set it --
+// when the library is loaded, which is before its first HIP call. A process that initialised HIP earlier keeps its setting.
+struct HwQueues {
+    HwQueues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
+} g_hwQueues;
+
 int fail(int code, const std::string& msg) {
     g_error = msg;
     return code;
@@ -40,10 +48,24 @@ int hipFail(hipError_t e, const char* what) {
 
 struct thx_ctx {
     int device = 0;
-    hipStream_t stream = nullptr;
+    hipStream_t stream = nullptr;          // lane 0
+    hipStream_t lanes[THX_MAX_SLOTS] = {}; // lanes[0] == stream; the others are created on first use (laneStream)
+    uint32_t nLanes = 1;
     hipDeviceProp_t prop{};
     std::mutex lock; // serialises calls on this context's tracers / scenes (launch bookkeeping, event ring)
 };
+
+// Stream of lane `l` of a context: batches in flight side by side (thx_tracer_set_concurrency) run on one stream each.
+static hipError_t laneStream(thx_ctx* ctx, uint32_t l, hipStream_t* out) {
+    if (l >= THX_MAX_SLOTS) return hipErrorInvalidValue;
+    if (!ctx->lanes[l]) {
+        hipError_t e = hipStreamCreateWithFlags(&ctx->lanes[l], hipStreamNonBlocking);
+        if (e != hipSuccess) return e;
+        ctx->nLanes = std::max(ctx->nLanes, l + 1u);
+    }
+    *out = ctx->lanes[l];
+    return hipSuccess;
+}
 
 struct thx_scene {
     thx_ctx* ctx = nullptr;
@@ -77,10 +99,20 @@ struct thx_tracer {
     size_t lds = 0;
     uint32_t gridMax = 1;
     uint32_t refillBelow = 63;
-    float* slabs[2] = {nullptr, nullptr};
+    // per slot (0 / 1 = the pipeline configs; up to THX_MAX_SLOTS batches in flight): partial histograms, reduced curve,
+    // pinned host copy {curve[n_bins], device error word} of an asynchronous readback and the event behind it
+    float* slabs[THX_MAX_SLOTS] = {};
+    float* out[THX_MAX_SLOTS] = {};
+    float* pinned[THX_MAX_SLOTS] = {};
+    hipEvent_t evFetch[THX_MAX_SLOTS] = {};
+    bool fetched[THX_MAX_SLOTS] = {};
+    uint32_t lastGrid[THX_MAX_SLOTS] = {};
+    uint32_t conc = 1;            // lanes: launches side by side (thx_tracer_set_concurrency), slot s on lane s % conc
+    uint32_t gridDiv = 1;         // ... each on at most ceil(gridMax / gridDiv) workgroups
+    uint32_t scratchWgs = 0;      // workgroups the scratch arrays below are allocated for (>= conc * laneGrid())
+    uint32_t laneGrid() const { return std::max(1u, (gridMax + gridDiv - 1u) / gridDiv); }
     float* cold = nullptr;        // staged kernel: cold chunks of the photon pools in global memory (one array per workgroup)
-    float* out[2] = {nullptr, nullptr};
-    uint32_t lastGrid[2] = {0, 0};
+    size_t coldWg = 0, spillWg = 0, parkWg = 0; // words per workgroup of cold / spill / park
     unsigned long long* stats = nullptr;
     uint32_t* devError = nullptr; // device error word (THX_DEVERR_* bits), set by the kernels' exit paths
     unsigned long long* prof = nullptr;
@@ -96,7 +128,8 @@ struct thx_tracer {
     static constexpr uint32_t kRing = 64;
     hipEvent_t evStart[kRing] = {}, evStop[kRing] = {};
     uint64_t launches = 0;       // total launches so far
-    int lastSlot[2] = {-1, -1};  // ring slot of the most recent launch per config
+    int lastSlot[THX_MAX_SLOTS];  // ring slot of the most recent launch per slot (-1: none)
+    thx_tracer() { std::fill(std::begin(lastSlot), std::end(lastSlot), -1); }
 };
 
 // 4-byte columns of a tracer's hit queue (record: response.queue.glsl:6-33, store time:
@@ -105,6 +138,39 @@ static size_t hitColumns(const thx_tracer_desc& d) {
     if (d.kind == THX_TRACER_LIGHT_SAMPLER) return (d.flags & THX_FLAG_POLARIZED) ? 15 : 8; // lightsource.queue.glsl:10-30
     if (d.response_kind == THX_RESPONSE_STORE_TIME) return d.hit_polarized ? 2 : 1;
     return d.hit_polarized ? 20 : 13;
+}
+
+// Scratch memory of the staged kernel's workgroups (cold photon chunks, deep stack entries, walks set aside) for `wgs` workgroups
+static hipError_t allocScratch(thx_tracer* t, uint32_t wgs) {
+    if (wgs <= t->scratchWgs) return hipSuccess;
+    for (void* p : {(void*)t->cold, (void*)t->spill, (void*)t->park})
+        if (p) (void)hipFree(p);
+    t->cold = nullptr; t->spill = nullptr; t->park = nullptr;
+    t->scratchWgs = 0;
+    hipError_t e = hipSuccess;
+    if (t->coldWg) e = hipMalloc((void**)&t->cold, 4 * t->coldWg * wgs);
+    if (e == hipSuccess && t->spillWg) e = hipMalloc((void**)&t->spill, 4 * t->spillWg * wgs);
+    if (e == hipSuccess && t->parkWg) e = hipMalloc((void**)&t->park, 4 * t->parkWg * wgs);
+    if (e == hipSuccess) t->scratchWgs = wgs;
+    return e;
+}
+
+// Device and pinned host buffers of result slot `slot` (0 and 1 exist from creation on; the memsets run on the null
+// stream, which is not ordered with the non-blocking lane streams: they are completed before returning)
+static int ensureSlot(thx_tracer* t, uint32_t slot) {
+    if (slot >= THX_MAX_SLOTS) return fail(THX_ERR_INVALID, "slot index out of range (THX_MAX_SLOTS)");
+    if (t->slabs[slot]) return THX_OK;
+    const size_t slabBytes = sizeof(float) * (size_t)t->gridMax * t->desc.n_bins;
+    const size_t outBytes = sizeof(float) * (t->desc.n_bins + 1u); // the curve + the device error word as of its reduction
+    THX_HIP(hipMalloc((void**)&t->slabs[slot], slabBytes));
+    THX_HIP(hipMemset(t->slabs[slot], 0, slabBytes));
+    THX_HIP(hipMalloc((void**)&t->out[slot], outBytes));
+    THX_HIP(hipMemset(t->out[slot], 0, outBytes));
+    THX_HIP(hipHostMalloc((void**)&t->pinned[slot], outBytes + 16, hipHostMallocDefault));
+    std::memset(t->pinned[slot], 0, outBytes + 16);
+    THX_HIP(hipEventCreateWithFlags(&t->evFetch[slot], hipEventDisableTiming));
+    THX_HIP(hipDeviceSynchronize());
+    return THX_OK;
 }
 
 // Reads (and clears) the tracer's device error word. The caller has synchronised the device.
@@ -120,6 +186,14 @@ static int deviceErrorCheck(thx_tracer* t) {
     if (bits & THX_DEVERR_WATCHDOG) msg += " the staged kernel's scheduler watchdog tripped (results of this batch are incomplete)";
     if (bits & ~THX_DEVERR_WATCHDOG) msg += " unknown bits " + std::to_string(bits);
     return fail(THX_ERR_DEVICE, msg);
+}
+
+// (second line of defence) a workgroup whose scheduler watchdog tripped also poisons its slab with NaN
+static int poisonCheck(const thx_tracer* t, const float* curve, uint32_t n_bins) {
+    if (t->staged)
+        for (uint32_t i = 0; i < n_bins; ++i)
+            if (std::isnan(curve[i])) return fail(THX_ERR_HIP, "the staged kernel's scheduler watchdog tripped: the light curve is invalid");
+    return THX_OK;
 }
 
 extern "C" {
@@ -154,6 +228,7 @@ int thx_ctx_create(int device, thx_ctx** out) {
     if (e != hipSuccess) { delete c; return hipFail(e, "hipGetDeviceProperties"); }
     e = hipStreamCreateWithFlags(&c->stream, hipStreamNonBlocking);
     if (e != hipSuccess) { delete c; return hipFail(e, "hipStreamCreate"); }
+    c->lanes[0] = c->stream;
     *out = c;
     return THX_OK;
 }
@@ -161,8 +236,9 @@ int thx_ctx_create(int device, thx_ctx** out) {
 int thx_ctx_destroy(thx_ctx* ctx) {
     if (!ctx) return THX_OK;
     (void)hipSetDevice(ctx->device);
-    (void)hipStreamSynchronize(ctx->stream);
-    (void)hipStreamDestroy(ctx->stream);
+    (void)hipDeviceSynchronize();
+    for (uint32_t l = 0; l < THX_MAX_SLOTS; ++l)
+        if (ctx->lanes[l]) (void)hipStreamDestroy(ctx->lanes[l]);
     delete ctx;
     return THX_OK;
 }
@@ -184,7 +260,8 @@ int thx_ctx_device_info(thx_ctx* ctx, uint32_t* n_cus, uint32_t* lds_per_cu, uin
 int thx_ctx_sync(thx_ctx* ctx) {
     if (!ctx) return fail(THX_ERR_INVALID, "null argument");
     THX_HIP(hipSetDevice(ctx->device));
-    THX_HIP(hipStreamSynchronize(ctx->stream));
+    for (uint32_t l = 0; l < ctx->nLanes; ++l)
+        if (ctx->lanes[l]) THX_HIP(hipStreamSynchronize(ctx->lanes[l]));
     return THX_OK;
 }
 
@@ -211,6 +288,7 @@ int thx_mem_upload(thx_ctx* ctx, uint64_t dev_addr, const void* src, size_t nbyt
     THX_HIP(hipSetDevice(ctx->device));
     // on the context's stream (it is non-blocking: a null-stream copy would not be ordered with
     // launches in flight that still read the old contents) and complete on return (`src` is the caller's)
+    if (ctx->nLanes > 1) THX_HIP(hipDeviceSynchronize()); // ... nor with launches on the other lanes
     THX_HIP(hipMemcpyAsync((void*)(uintptr_t)dev_addr, src, nbytes, hipMemcpyHostToDevice, ctx->stream));
     THX_HIP(hipStreamSynchronize(ctx->stream));
     return THX_OK;
@@ -489,25 +567,19 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     if (const char* env = std::getenv("THX_GRID_MULT")) mult = (uint32_t)std::max(1, std::atoi(env));
     t->gridMax = (uint32_t)ctx->prop.multiProcessorCount * (uint32_t)perCU * mult;
     if (const char* env = std::getenv("THX_REFILL")) t->refillBelow = (uint32_t)std::min(63, std::max(0, std::atoi(env)));
-    const size_t slabBytes = sizeof(float) * (size_t)t->gridMax * desc->n_bins;
+    for (uint32_t i = 0; i < 2; ++i)
+        if (int rc = ensureSlot(t, i)) { thx_tracer_destroy(t); return rc; }
     hipError_t e = hipSuccess;
-    for (int i = 0; i < 2 && e == hipSuccess; ++i) {
-        e = hipMalloc((void**)&t->slabs[i], slabBytes);
-        if (e == hipSuccess) e = hipMemset(t->slabs[i], 0, slabBytes);
-        if (e == hipSuccess) e = hipMalloc((void**)&t->out[i], sizeof(float) * desc->n_bins);
-        if (e == hipSuccess) e = hipMemset(t->out[i], 0, sizeof(float) * desc->n_bins);
-    }
     for (uint32_t i = 0; i < thx_tracer::kRing && e == hipSuccess; ++i) {
         e = hipEventCreate(&t->evStart[i]);
         if (e == hipSuccess) e = hipEventCreate(&t->evStop[i]);
     }
     if (e == hipSuccess && t->staged) {
-        const size_t nb = stagedColdBytes(pol, t->pool) * t->gridMax;
-        if (nb) e = hipMalloc((void**)&t->cold, nb);
-        const size_t sb = sizeof(uint32_t) * 64u * (t->block / 64u) * (size_t)(t->stackDepth - t->stackLds) * t->gridMax;
-        if (e == hipSuccess && sb) e = hipMalloc((void**)&t->spill, sb);
-        const size_t pb = sizeof(uint32_t) * 2u * (8u + std::max(t->stackDepth, 8u)) * (size_t)t->pool * t->gridMax; // (a walk is taken up again with eight entries at once)
-        if (e == hipSuccess) e = hipMalloc((void**)&t->park, pb);
+        // scratch of the workgroups (words per workgroup; lane l of `conc` launches side by side uses the workgroups from l * gridMax / conc on)
+        t->coldWg = stagedColdBytes(pol, t->pool) / 4;
+        t->spillWg = 64u * (t->block / 64u) * (size_t)(t->stackDepth - t->stackLds);
+        t->parkWg = 2u * (8u + std::max(t->stackDepth, 8u)) * (size_t)t->pool; // (a walk is taken up again with eight entries at once)
+        e = allocScratch(t, t->gridMax);
     }
     if (e == hipSuccess) e = hipMalloc((void**)&t->stats, sizeof(unsigned long long) * THX_N_STATS);
     if (e == hipSuccess) e = hipMemset(t->stats, 0, sizeof(unsigned long long) * THX_N_STATS);
@@ -561,10 +633,12 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
 int thx_tracer_destroy(thx_tracer* t) {
     if (!t) return THX_OK;
     (void)hipSetDevice(t->ctx->device);
-    (void)hipStreamSynchronize(t->ctx->stream);
-    for (int i = 0; i < 2; ++i) {
+    (void)hipDeviceSynchronize();
+    for (uint32_t i = 0; i < THX_MAX_SLOTS; ++i) {
         if (t->slabs[i]) (void)hipFree(t->slabs[i]);
         if (t->out[i]) (void)hipFree(t->out[i]);
+        if (t->pinned[i]) (void)hipHostFree(t->pinned[i]);
+        if (t->evFetch[i]) (void)hipEventDestroy(t->evFetch[i]);
     }
     for (uint32_t i = 0; i < thx_tracer::kRing; ++i) {
         if (t->evStart[i]) (void)hipEventDestroy(t->evStart[i]);
@@ -589,22 +663,23 @@ int thx_tracer_destroy(thx_tracer* t) {
 }
 
 static void launchGeometry(const thx_tracer* t, uint32_t batch, uint32_t* grid, uint32_t* ppw) {
+    const uint32_t gridMax = t->laneGrid(); // workgroups one launch may take
     if (t->desc.kind == THX_TRACER_HIT_REPLAY || t->desc.kind == THX_TRACER_LIGHT_SAMPLER) { // one hit per thread until the chip is full, then grid-stride
         const uint64_t need = ((uint64_t)t->desc.capacity + t->block - 1) / t->block;
-        *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, need));
+        *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(gridMax, need));
         *ppw = 0;
         return;
     }
     if (t->staged) { // one pool-owning workgroup per CU; each gets a contiguous photon range
         uint64_t need = ((uint64_t)batch + t->pool - 1) / t->pool;
-        *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, need));
+        *grid = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(gridMax, need));
         *ppw = 0;
         return;
     }
     const uint32_t wavesPerBlock = t->block / 64;
     uint64_t wavesNeeded = ((uint64_t)batch + 63) / 64;
     uint64_t blocksNeeded = (wavesNeeded + wavesPerBlock - 1) / wavesPerBlock;
-    uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(t->gridMax, blocksNeeded));
+    uint32_t g = (uint32_t)std::max<uint64_t>(1, std::min<uint64_t>(gridMax, blocksNeeded));
     uint64_t waves = (uint64_t)g * wavesPerBlock;
     uint32_t p = (uint32_t)(((uint64_t)batch + waves - 1) / waves);
     *grid = g;
@@ -622,15 +697,43 @@ int thx_tracer_launch_info(thx_tracer* t, uint32_t batch, uint32_t* grid, uint32
     return THX_OK;
 }
 
+int thx_tracer_set_concurrency(thx_tracer* t, uint32_t lanes, uint32_t grid_divisor) {
+    if (!t) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
+    if (lanes < 1 || lanes > THX_MAX_SLOTS) return fail(THX_ERR_INVALID, "lanes must be in [1, THX_MAX_SLOTS]");
+    if (grid_divisor < 1 || grid_divisor > lanes) return fail(THX_ERR_INVALID, "grid_divisor must be in [1, lanes]");
+    if (lanes > 1 && (t->hits || t->track || t->replayIn || t->lamOut))
+        return fail(THX_ERR_INVALID, "tracers with one output queue or track buffer cannot run batches side by side");
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipDeviceSynchronize()); // the lanes' shares of the scratch memory change
+    const uint32_t oldLanes = t->conc, oldDiv = t->gridDiv;
+    t->conc = lanes;
+    t->gridDiv = grid_divisor;
+    if (t->staged) {
+        hipError_t e = allocScratch(t, lanes * t->laneGrid());
+        if (e != hipSuccess) {
+            t->conc = oldLanes; t->gridDiv = oldDiv;
+            (void)allocScratch(t, t->conc * t->laneGrid());
+            return hipFail(e, "thx_tracer_set_concurrency: scratch memory");
+        }
+    }
+    return THX_OK;
+}
+
 int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, void* stream) {
     if (!t || !params) return fail(THX_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> guard(t->ctx->lock);
-    if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
+    if (cfg >= THX_MAX_SLOTS) return fail(THX_ERR_INVALID, "slot index out of range (THX_MAX_SLOTS)");
     const uint32_t batch = params->dispatch.batchSize;
     if (batch > t->desc.capacity) return fail(THX_ERR_INVALID, "batchSize cannot be larger than capacity");
     thx_ctx* ctx = t->ctx;
     THX_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    if (int rc = ensureSlot(t, cfg)) return rc;
+    const uint32_t lane = cfg % t->conc;
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) THX_HIP(laneStream(ctx, lane, &s));
+    const uint32_t hostCfg = cfg & 1u; // device queues of the host-fed sources exist for the two pipeline configs
+    if ((t->lightIn[0] || t->lamIn[0]) && cfg > 1) return fail(THX_ERR_INVALID, "tracers fed from host queues run in slots 0 and 1 only");
 
     LaunchArgs a;
     std::memset(&a, 0, sizeof(a));
@@ -643,8 +746,10 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stack_depth = t->stackDepth;
     a.stack_lds = t->stackLds;
     a.stack_wave_words = (t->staged ? t->stackSlots : t->stackLds) * (t->stack16 ? 32u : 64u);
-    a.spill = t->spill;
-    a.park = t->park;
+    // scratch of this lane's workgroups
+    const size_t wg0 = (size_t)lane * t->laneGrid();
+    a.spill = t->spill ? t->spill + wg0 * t->spillWg : nullptr;
+    a.park = t->park ? t->park + wg0 * t->parkWg : nullptr;
     a.park_below = t->scene && t->scene->info.n_instances > kParkInstancedFrom ? kParkBelowInstanced
                    : (t->stackDepth > kParkDeepFrom ? kParkBelowDeep : kParkBelow);
     a.park_rounds = kParkRounds;
@@ -661,7 +766,7 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
         a.ring_magic_ts = (uint32_t)(((1ull << 37) + 2ull * t->ringCap - 1) / (2ull * t->ringCap));
     }
     a.slabs = t->slabs[cfg];
-    a.cold = t->cold;
+    a.cold = t->cold ? t->cold + wg0 * t->coldWg : nullptr;
     a.stats = t->stats;
     a.error = t->devError;
     a.prof = t->prof;
@@ -669,11 +774,11 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.hit_capacity = t->desc.hit_capacity;
     a.hit_polarized = t->desc.hit_polarized;
     a.hit_kind = t->desc.response_kind;
-    a.light_queue = t->lightIn[cfg];
-    a.wavelength_queue = t->lamIn[cfg];
+    a.light_queue = t->lightIn[hostCfg];
+    a.wavelength_queue = t->lamIn[hostCfg];
     a.light_capacity = t->desc.light_queue_capacity;
     a.wavelength_capacity = t->desc.wavelength_queue_capacity;
-    if ((t->lightIn[cfg] && batch > t->desc.light_queue_capacity) || (t->lamIn[cfg] && batch > t->desc.wavelength_queue_capacity))
+    if ((t->lightIn[hostCfg] && batch > t->desc.light_queue_capacity) || (t->lamIn[hostCfg] && batch > t->desc.wavelength_queue_capacity))
         return fail(THX_ERR_INVALID, "batchSize exceeds the capacity of the host light / wavelength source");
     a.track = t->track;
     if (t->scene) a.scene = t->scene->view;
@@ -682,49 +787,91 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.photons_per_wave = ppw;
     t->lastGrid[cfg] = grid;
     t->lastBatch = batch;
+    // (launches side by side are not timed: an event pair per launch costs two more packets per batch on every lane, and the
+    // durations of overlapping launches say little)
+    const bool timed = t->conc == 1;
     const uint32_t slot = (uint32_t)(t->launches % thx_tracer::kRing);
-    THX_HIP(hipEventRecord(t->evStart[slot], s));
+    if (timed) THX_HIP(hipEventRecord(t->evStart[slot], s));
     if (t->desc.kind == THX_TRACER_LIGHT_SAMPLER) {
         if ((uint64_t)batch + params->photon_offset > UINT32_MAX ||
-            (t->lightIn[cfg] && batch + params->photon_offset > t->desc.light_queue_capacity) ||
-            (t->lamIn[cfg] && batch + params->photon_offset > t->desc.wavelength_queue_capacity))
+            (t->lightIn[hostCfg] && batch + params->photon_offset > t->desc.light_queue_capacity) ||
+            (t->lamIn[hostCfg] && batch + params->photon_offset > t->desc.wavelength_queue_capacity))
             return fail(THX_ERR_INVALID, "count + baseCount exceeds the capacity of the host light / wavelength source");
         THX_HIP(launchSampler(a, (t->desc.flags & THX_FLAG_POLARIZED) != 0, t->hits, t->lamOut, t->desc.capacity, s));
     } else if (t->desc.kind == THX_TRACER_HIT_REPLAY)
         THX_HIP(launchReplay(a, t->replayIn, t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) != 0, grid, s));
     else
         THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
-    THX_HIP(hipEventRecord(t->evStop[slot], s));
-    t->lastSlot[cfg] = (int)slot;
-    t->launches += 1;
+    if (timed) {
+        THX_HIP(hipEventRecord(t->evStop[slot], s));
+        t->lastSlot[cfg] = (int)slot;
+        t->launches += 1;
+    }
     return THX_OK;
 }
 
 int thx_tracer_reduce(thx_tracer* t, uint32_t cfg, float norm, uint64_t d_out, void* stream) {
     if (!t) return fail(THX_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> guard(t->ctx->lock);
-    if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
+    if (cfg >= THX_MAX_SLOTS || !t->slabs[cfg]) return fail(THX_ERR_INVALID, "no batch was launched into this slot");
     thx_ctx* ctx = t->ctx;
     THX_HIP(hipSetDevice(ctx->device));
-    hipStream_t s = stream ? (hipStream_t)stream : ctx->stream;
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) THX_HIP(laneStream(ctx, cfg % t->conc, &s));
     float* out = d_out ? (float*)(uintptr_t)d_out : t->out[cfg];
-    THX_HIP(launchReduce(t->slabs[cfg], out, t->desc.n_bins, t->lastGrid[cfg], norm, s));
+    THX_HIP(launchReduce(t->slabs[cfg], out, t->desc.n_bins, t->lastGrid[cfg], norm, d_out ? nullptr : t->devError, s));
     return THX_OK;
 }
 
 int thx_tracer_read_hist(thx_tracer* t, uint32_t cfg, float* out, uint32_t n_bins) {
     if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> guard(t->ctx->lock);
-    if (cfg > 1 || n_bins != t->desc.n_bins) return fail(THX_ERR_INVALID, "bad config index or bin count");
+    if (cfg >= THX_MAX_SLOTS || !t->out[cfg] || n_bins != t->desc.n_bins) return fail(THX_ERR_INVALID, "bad slot index or bin count");
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     if (int rc = deviceErrorCheck(t)) return rc;
     THX_HIP(hipMemcpy(out, t->out[cfg], sizeof(float) * n_bins, hipMemcpyDeviceToHost));
-    // (second line of defence) a workgroup whose scheduler watchdog tripped also poisons its slab with NaN
-    if (t->staged)
-        for (uint32_t i = 0; i < n_bins; ++i)
-            if (std::isnan(out[i])) return fail(THX_ERR_HIP, "the staged kernel's scheduler watchdog tripped: the light curve is invalid");
+    return poisonCheck(t, out, n_bins);
+}
+
+int thx_tracer_fetch_hist(thx_tracer* t, uint32_t cfg, void* stream) {
+    if (!t) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
+    if (cfg >= THX_MAX_SLOTS || !t->out[cfg]) return fail(THX_ERR_INVALID, "no batch was launched into this slot");
+    thx_ctx* ctx = t->ctx;
+    THX_HIP(hipSetDevice(ctx->device));
+    hipStream_t s = (hipStream_t)stream;
+    if (!s) THX_HIP(laneStream(ctx, cfg % t->conc, &s));
+    // (the reduction left the device error word behind the curve: one copy)
+    THX_HIP(hipMemcpyAsync(t->pinned[cfg], t->out[cfg], sizeof(float) * (t->desc.n_bins + 1u), hipMemcpyDeviceToHost, s));
+    THX_HIP(hipEventRecord(t->evFetch[cfg], s));
+    t->fetched[cfg] = true;
     return THX_OK;
+}
+
+int thx_tracer_collect_hist(thx_tracer* t, uint32_t cfg, float* out, uint32_t n_bins) {
+    if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(t->ctx->lock);
+        if (cfg >= THX_MAX_SLOTS || !t->fetched[cfg] || n_bins != t->desc.n_bins)
+            return fail(THX_ERR_INVALID, "bad slot index or bin count, or no thx_tracer_fetch_hist to collect");
+        ev = t->evFetch[cfg];
+    }
+    // the wait itself happens outside the context's lock: launches into other slots go on meanwhile
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipEventSynchronize(ev));
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
+    t->fetched[cfg] = false;
+    const size_t nb = sizeof(float) * n_bins;
+    uint32_t bits = 0;
+    std::memcpy(&bits, (const char*)t->pinned[cfg] + nb, 4);
+    if (bits != 0) { // the word is shared by the batches in flight: whoever sees it first reports (and clears) it
+        THX_HIP(hipDeviceSynchronize());
+        return deviceErrorCheck(t) == THX_OK ? fail(THX_ERR_DEVICE, "device error (already reported by another slot)") : THX_ERR_DEVICE;
+    }
+    std::memcpy(out, t->pinned[cfg], nb);
+    return poisonCheck(t, out, n_bins);
 }
 
 int thx_tracer_check(thx_tracer* t) {
@@ -736,7 +883,9 @@ int thx_tracer_check(thx_tracer* t) {
 }
 
 int thx_tracer_hist_device_ptr(thx_tracer* t, uint32_t cfg, uint64_t* out) {
-    if (!t || !out || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    if (!t || !out || cfg >= THX_MAX_SLOTS) return fail(THX_ERR_INVALID, "bad argument");
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
+    if (int rc = ensureSlot(t, cfg)) return rc;
     *out = (uint64_t)(uintptr_t)t->out[cfg];
     return THX_OK;
 }
@@ -881,7 +1030,7 @@ int thx_tracer_read_track(thx_tracer* t, float* out, size_t n_floats) {
 }
 
 int thx_tracer_last_kernel_ms(thx_tracer* t, uint32_t cfg, float* ms) {
-    if (!t || !ms || cfg > 1) return fail(THX_ERR_INVALID, "bad argument");
+    if (!t || !ms || cfg >= THX_MAX_SLOTS) return fail(THX_ERR_INVALID, "bad argument");
     std::lock_guard<std::mutex> guard(t->ctx->lock);
     if (t->lastSlot[cfg] < 0) return fail(THX_ERR_INVALID, "no launch recorded for this config");
     THX_HIP(hipSetDevice(t->ctx->device));

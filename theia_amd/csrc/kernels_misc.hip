@@ -45,8 +45,10 @@ static_assert(kStagedBlock == kSchedThreads && kStagedBlockDebug == kSchedThread
 // partials (value + compensation) are combined in a fixed butterfly order, which
 // keeps the result deterministic for given slab contents.
 // (-ffp-contract=off keeps the compensation from being folded away.)
+// `error` (optional): the tracer's device error word; its value lands behind the curve, out[n_bins], so that ONE copy brings the
+// host both (thx_tracer_fetch_hist).
 __global__ void __launch_bounds__(64) reduceKernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                   uint32_t n_bins, uint32_t n_hist, float norm) {
+                                                   uint32_t n_bins, uint32_t n_hist, float norm, const uint32_t* __restrict__ error) {
     const uint32_t bin = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     float result = 0.0f, c = 0.0f;
@@ -67,12 +69,13 @@ __global__ void __launch_bounds__(64) reduceKernel(const float* __restrict__ sla
         result = t;
     }
     if (lane == 0) out[bin] = result * norm;
+    if (error != nullptr && bin == 0 && lane == 0) out[n_bins] = __uint_as_float(*error);
 }
 
 hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
-                        float norm, hipStream_t stream) {
+                        float norm, const uint32_t* error, hipStream_t stream) {
     if (n_bins == 0) return hipSuccess;
-    hipLaunchKernelGGL(reduceKernel, dim3(n_bins), dim3(64), 0, stream, slabs, out, n_bins, n_hist, norm);
+    hipLaunchKernelGGL(reduceKernel, dim3(n_bins), dim3(64), 0, stream, slabs, out, n_bins, n_hist, norm, error);
     return hipGetLastError();
 }
 

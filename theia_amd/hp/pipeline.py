@@ -10,7 +10,11 @@ starting with `_` are private, `extra` names are python-side properties,
 `_finishParams(i)` runs right before config `i` is committed, `run(i)` returns
 the commands of config `i`, pipeline parameters are addressed as
 ``stage__param``. Commands here are callables that enqueue work on the HIP
-stream instead of Vulkan command buffers.
+stream instead of Vulkan command buffers; a stage whose work can be in flight
+while the host goes on returns `Command` objects (an `enqueue` half that only
+queues device work and a `collect` half that waits for it), which is what lets
+`PipelineScheduler` keep several batches on the device at once as the reference's
+scheduler does (docs/pipeline/pipeline.md:74-92).
 """
 from __future__ import annotations
 
@@ -20,10 +24,31 @@ from ctypes import Array, Structure
 from queue import Queue
 from typing import Any, Callable, Iterable
 
-__all__ = ["Command", "PipelineStage", "SourceCodeMixin", "Pipeline", "PipelineScheduler", "runPipeline", "DynamicTask",
+__all__ = ["Command", "DeviceCommand", "PipelineStage", "SourceCodeMixin", "Pipeline", "PipelineScheduler", "runPipeline", "DynamicTask",
            "DynamicTaskScheduler"]
 
 Command = Callable[[], None]
+
+
+class DeviceCommand:
+    """
+    A command in two halves. `enqueue(slot)` queues the device work of one batch and returns without waiting;
+    `collect(slot)` (optional) waits for exactly that work and hands its results to the host side of the stage.
+    `slot` names the device-side buffers the batch uses: the pipeline config itself when the pipeline runs one
+    batch at a time, one of `MAX_SLOTS` when a scheduler keeps more than two batches in flight (the two configs
+    then only double-buffer the HOST side: parameter blocks and result arrays). Calling the command runs both
+    halves on the config's own slot, which is what `Pipeline.run` / `runPipeline` do.
+    """
+
+    __slots__ = ("config", "enqueue", "collect")
+
+    def __init__(self, config: int, enqueue: Callable[[int], None], collect: Callable[[int], None] | None = None) -> None:
+        self.config, self.enqueue, self.collect = config, enqueue, collect
+
+    def __call__(self) -> None:
+        self.enqueue(self.config)
+        if self.collect is not None:
+            self.collect(self.config)
 
 
 def _to_python(value: Any) -> Any:
@@ -215,51 +240,123 @@ class Pipeline:
         for cmd in self._commands[i]:
             cmd()
 
+    # the two halves of run(), for schedulers that keep batches in flight ----
+    @property
+    def asynchronous(self) -> bool:
+        """True if every command of the pipeline is a `DeviceCommand`: batches can then be queued on the device
+        ahead of the one being processed, each in a slot of its own"""
+        return all(isinstance(c, DeviceCommand) for cmds in self._commands for c in cmds)
+
+    def setConcurrency(self, lanes: int, gridDivisor: int | None = None) -> None:
+        """tells the stages that launch kernels how many batches will be in flight (`Tracer.setConcurrency`)"""
+        for _, st in self._stages:
+            fn = getattr(st, "setConcurrency", None)
+            if fn is not None:
+                fn(lanes, gridDivisor)
+
+    def submit(self, i: int, slot: int | None = None) -> None:
+        """queues the commands of config `i` (already updated) on the device; plain callables run whole"""
+        slot = i if slot is None else slot
+        for cmd in self._commands[i]:
+            if isinstance(cmd, DeviceCommand):
+                cmd.enqueue(slot)
+            else:
+                cmd()
+
+    def collect(self, i: int, slot: int | None = None) -> None:
+        """waits for what `submit(i, slot)` queued and moves its results into the stages' buffers of config `i`"""
+        slot = i if slot is None else slot
+        for cmd in self._commands[i]:
+            if isinstance(cmd, DeviceCommand) and cmd.collect is not None:
+                cmd.collect(slot)
+
 
 def runPipeline(stages: Iterable, i: int = 0, *, update: bool = True) -> None:
     """Creates a throw-away pipeline from the stages and runs config `i` once."""
     Pipeline([s if isinstance(s, tuple) else (f"stage{k}", s) for k, s in enumerate(stages)]).run(i, update=update)
 
 
-class PipelineScheduler:
-    """Feeds a list of tasks (parameter dicts) through a pipeline, alternating
-    configs 0/1, and calls `processFn(config, batch, args)` after each one. Work
-    runs on a background thread; `wait()` blocks until everything submitted so
-    far has been processed."""
+def _env_int(name: str, default: int) -> int:
+    import os
 
-    def __init__(self, pipeline, *, queueSize: int = 0, processFn: Callable[[int, int, Any], None] | None = None) -> None:
+    try:
+        return int(os.environ.get(name, default))
+    except ValueError:
+        return default
+
+
+class PipelineScheduler:
+    """
+    Feeds a list of tasks (parameter dicts, or `(pipeline name, dict[, args])` tuples) through a pipeline and
+    calls `processFn(config, batch, args)` after each one, in order. As in the reference
+    (docs/pipeline/pipeline.md:74-92) three threads work on different batches at the same time:
+
+    * update   applies a task's parameters and commits them to config `batch % 2` (`Pipeline.update`),
+    * submit   queues the batch on the device (`Pipeline.submit`: kernel launches, reduction, readback -- all
+               asynchronous),
+    * process  waits for the batch's results (`Pipeline.collect`) and calls `processFn`.
+
+    A config's host side (parameter blocks, `result(config)` arrays) is reused every second batch: batch k + 2 is
+    not updated before batch k's parameters went to the device, and its results are not written before
+    `processFn` of batch k returned -- `result(config)` is valid inside `processFn`, as in the reference.
+
+    Batches in flight. A pipeline made of `DeviceCommand`s only (the tracers with a histogram response) keeps up
+    to `inFlight` batches on the device, each in a result slot of its own (`THX_MAX_SLOTS`), on `lanes` streams
+    and `1 / gridDivisor` of the chip per launch (`thx_tracer_set_concurrency`): the tail of a launch -- the
+    life of its last photons, 0.22 ms on config 2 whatever the batch size -- is covered by the other batches
+    (config 2, 20 batches of 10^6 photons: 0.42 -> 0.26 ms per batch, tools/overlap_bench.py). Any other
+    pipeline runs with the two configs as its slots (one batch on the device while the previous one is
+    processed). Defaults: lanes 8, gridDivisor 4, inFlight 16 (THEIA_AMD_LANES / THEIA_AMD_GRID_DIVISOR /
+    THEIA_AMD_IN_FLIGHT); slot s runs on lane s % lanes.
+    """
+
+    MAX_SLOTS = 16  # THX_MAX_SLOTS of include/theia_hip.h
+
+    def __init__(self, pipeline, *, queueSize: int = 0, processFn: Callable[[int, int, Any], None] | None = None,
+                 lanes: int | None = None, gridDivisor: int | None = None, inFlight: int | None = None) -> None:
         self._pipelines = pipeline if isinstance(pipeline, dict) else {None: pipeline}
         self._process = processFn
-        self._queue: Queue = Queue(queueSize)
-        self._total = 0
-        self._finished = 0
+        lanes = _env_int("THEIA_AMD_LANES", 8) if lanes is None else int(lanes)
+        gridDivisor = _env_int("THEIA_AMD_GRID_DIVISOR", 4) if gridDivisor is None else int(gridDivisor)
+        self._lanes = max(1, min(lanes, self.MAX_SLOTS))
+        self._divisor = max(1, min(gridDivisor, self._lanes))
+        deep = self._lanes > 1 and all(p.asynchronous for p in self._pipelines.values())
+        # (more slots than lanes: the submit thread then never waits for processFn of the batch whose slot it needs next)
+        inFlight = _env_int("THEIA_AMD_IN_FLIGHT", self.MAX_SLOTS) if inFlight is None else int(inFlight)
+        self._depth = max(self._lanes, min(inFlight, self.MAX_SLOTS)) if deep else 2
+        self._deep = deep
+        if deep:
+            for p in self._pipelines.values():
+                p.setConcurrency(self._lanes, self._divisor)
+        self._tasks: Queue = Queue(queueSize)   # schedule() -> update thread
+        self._toSubmit: Queue = Queue()          # update -> submit
+        self._toProcess: Queue = Queue()         # submit -> process
         self._cv = threading.Condition()
+        self._total = 0
+        self._submitted = 0   # batches whose parameters went to the device
+        self._processed = 0   # batches whose processFn returned: their slot and config are free again
+        self._finished = 0    # tasks done with, processed or dropped after an error (what wait() counts)
         self._error: BaseException | None = None
         self._alive = True
-        self._thread = threading.Thread(target=self._worker, name="theia-scheduler", daemon=True)
-        self._thread.start()
+        self._threads = [threading.Thread(target=fn, name=f"theia-scheduler-{name}", daemon=True)
+                         for name, fn in (("update", self._updateLoop), ("submit", self._submitLoop), ("process", self._processLoop))]
+        for t in self._threads:
+            t.start()
 
-    @property
-    def tasksFinished(self) -> int:
-        return self._finished
-
-    @property
-    def totalTasks(self) -> int:
-        return self._total
-
-    @property
-    def tasksScheduled(self) -> int:
-        return self._total - self._finished
+    tasksFinished = property(lambda self: self._finished)
+    totalTasks = property(lambda self: self._total)
+    tasksScheduled = property(lambda self: self._total - self._finished)
+    batchesInFlight = property(lambda self: self._depth, doc="batches this scheduler keeps on the device at once")
 
     def schedule(self, tasks: Iterable, *, timeout: float | None = None) -> None:
         for task in tasks:
             with self._cv:
                 self._total += 1
-            self._queue.put(task, timeout=timeout)
+            self._tasks.put(task, timeout=timeout)
 
     def wait(self) -> None:
         with self._cv:
-            self._cv.wait_for(lambda: self._finished >= self._total or self._error is not None)
+            self._cv.wait_for(lambda: self._finished >= self._total)  # (after an error the queued tasks are dropped: this ends soon)
         if self._error is not None:
             err, self._error = self._error, None
             raise err
@@ -267,8 +364,15 @@ class PipelineScheduler:
     def destroy(self) -> None:
         if self._alive:
             self._alive = False
-            self._queue.put(None)
-            self._thread.join(timeout=5.0)
+            self._tasks.put(None)
+            for t in self._threads:
+                t.join(timeout=5.0)
+            if self._deep:
+                for p in self._pipelines.values():
+                    try:
+                        p.setConcurrency(1, 1)
+                    except Exception:
+                        pass
 
     def __del__(self) -> None:
         try:
@@ -276,37 +380,95 @@ class PipelineScheduler:
         except Exception:
             pass
 
-    def _worker(self) -> None:
+    # -- the three threads; a batch is (index, pipeline, config, slot, args) --------------------------------
+    def _fail(self, exc: BaseException) -> None:
+        with self._cv:
+            if self._error is None:
+                self._error = exc
+            self._cv.notify_all()
+
+    def _done(self, processed: bool = False) -> None:
+        with self._cv:
+            self._finished += 1
+            self._processed += 1 if processed else 0
+            self._cv.notify_all()
+
+    def _resolve(self, task):
+        name, params, args = None, task, None
+        if isinstance(task, tuple):
+            name, params = task[0], task[1]
+            args = task[2] if len(task) > 2 else None
+        if name not in self._pipelines:
+            if name is None and len(self._pipelines) == 1:
+                name = next(iter(self._pipelines))
+            else:
+                raise ValueError(f"There is no pipeline with name {name}")
+        return self._pipelines[name], params, args
+
+    def _updateLoop(self) -> None:
         batch = 0
         while True:
-            task = self._queue.get()
+            task = self._tasks.get()
             if task is None:
+                self._toSubmit.put(None)
                 return
+            if self._error is not None:  # drop what is queued behind a failed batch
+                self._done()
+                continue
+            try:
+                pipe, params, args = self._resolve(task)
+                cfg = batch % 2
+                # the config's parameter blocks are free once batch - 2 went to the device; pipelines whose commands
+                # finish on the host (hit queues, tracks) also need its results processed
+                with self._cv:
+                    need = batch - 1
+                    self._cv.wait_for(lambda: (self._submitted if self._deep else self._processed) >= need or self._error is not None)
+                if self._error is not None:
+                    self._done()
+                    continue
+                if params:
+                    pipe.setParams(**params)
+                pipe.update(cfg)
+                self._toSubmit.put((batch, pipe, cfg, batch % self._depth if self._deep else cfg, args))
+                batch += 1
+            except BaseException as exc:
+                self._fail(exc)
+                self._done()
+
+    def _submitLoop(self) -> None:
+        while True:
+            item = self._toSubmit.get()
+            if item is None:
+                self._toProcess.put(None)
+                return
+            batch, pipe, cfg, slot, _ = item
+            try:
+                with self._cv:  # the slot's device buffers are free once batch - depth was processed
+                    need = batch - self._depth + 1
+                    self._cv.wait_for(lambda: self._processed >= need or self._error is not None)
+                if self._error is None:
+                    pipe.submit(cfg, slot)
+            except BaseException as exc:
+                self._fail(exc)
+            with self._cv:
+                self._submitted += 1
+                self._cv.notify_all()
+            self._toProcess.put(item)
+
+    def _processLoop(self) -> None:
+        while True:
+            item = self._toProcess.get()
+            if item is None:
+                return
+            batch, pipe, cfg, slot, args = item
             try:
                 if self._error is None:
-                    name, params, args = None, task, None
-                    if isinstance(task, tuple):
-                        name, params = task[0], task[1]
-                        args = task[2] if len(task) > 2 else None
-                    if name not in self._pipelines:
-                        if name is None and len(self._pipelines) == 1:
-                            name = next(iter(self._pipelines))
-                        else:
-                            raise ValueError(f"There is no pipeline with name {name}")
-                    pipe = self._pipelines[name]
-                    cfg = batch % 2
-                    if params:
-                        pipe.setParams(**params)
-                    pipe.run(cfg)
+                    pipe.collect(cfg, slot)
                     if self._process is not None:
                         self._process(cfg, batch, args)
-                    batch += 1
             except BaseException as exc:  # surfaced by wait()
-                self._error = exc
-            finally:
-                with self._cv:
-                    self._finished += 1
-                    self._cv.notify_all()
+                self._fail(exc)
+            self._done(processed=True)
 
 
 class DynamicTask:

@@ -19,7 +19,7 @@ from . import units as u
 from . import _capi as capi
 from ._program import _Program
 from .hp.glsl import _layout
-from .hp.pipeline import PipelineStage, SourceCodeMixin
+from .hp.pipeline import DeviceCommand, PipelineStage, SourceCodeMixin
 from .hp.queue import IOQueue
 
 __all__ = ["HitItem", "PolarizedHitItem", "HitTimeItem", "HitTimeAndIdItem", "TraceConfig", "HitResponse", "EmptyResponse",
@@ -273,6 +273,7 @@ class HistogramHitResponse(HitResponse):
         self._program = None  # set by the tracer (bindParams)
         self._norm = [1.0, 1.0]
         self._buffer = [np.zeros(nBins, dtype=np.float32) for _ in range(2)]
+        self._inflight = {}  # slot -> program the batch in that slot was launched on
         self._prepared = False
 
     # read-only views of what the response was built with
@@ -313,15 +314,23 @@ class HistogramHitResponse(HitResponse):
         if not self._prepared:
             raise RuntimeError("Response has not been prepared")
 
-        def reduce() -> None:
+        # Both commands only queue device work: the reduction of the slot's slabs and the copy of the reduced curve into a
+        # pinned host buffer; `collect` waits for that copy alone and fills `result(i)`. The program a batch went to is
+        # remembered per slot -- a response shared between tracers (examples/03) is bound to another one by the time the
+        # batch is collected.
+        def reduce(slot: int) -> None:
             if self._program is None:
                 raise RuntimeError("HistogramHitResponse is not bound to a tracer")
-            self._program.reduce(i, self._norm[i])
+            self._inflight[slot] = self._program
+            self._program.reduce(slot, self._norm[i])
 
-        def retrieve() -> None:
-            self._buffer[i][...] = self._program.read_hist(i)
+        def fetch(slot: int) -> None:
+            self._inflight[slot].fetch_hist(slot)
 
-        return [reduce, retrieve] if self._retrieve else [reduce]
+        def collect(slot: int) -> None:
+            self._inflight[slot].collect_hist(slot, self._buffer[i])
+
+        return [DeviceCommand(i, reduce), DeviceCommand(i, fetch, collect)] if self._retrieve else [DeviceCommand(i, reduce)]
 
 
 class KernelHistogramHitResponse(HistogramHitResponse):

@@ -23,7 +23,7 @@ from ._program import _Program
 from . import _capi as capi
 from . import units as u
 from .hp.glsl import buffer_reference, vec3
-from .hp.pipeline import PipelineStage, SourceCodeMixin
+from .hp.pipeline import DeviceCommand, PipelineStage, SourceCodeMixin
 from .light import (_LIGHTS, _layout, _WAVELENGTHS, HostLightSource, HostWavelengthSource, fillSourceParams, sourceSpec, uploadSourceQueues,
                     ConstWavelengthSource, LightSource, PencilLightSource, SphericalLightSource, UniformWavelengthSource,
                     WavelengthSource)
@@ -244,15 +244,26 @@ class Tracer(PipelineStage):
     def run(self, i):
         self._bindShared(i)
 
-        def launch() -> None:
+        def launch(slot: int = i) -> None:
             # stages may be shared between several tracers / pipelines (examples/03): bind them to
             # THIS tracer again when the batch actually runs, so that the response stage that
             # follows reduces and retrieves this tracer's result
             self._bindShared(i)
             uploadSourceQueues(self._program, i, self._source, self._wavelengthSource)
-            self._program.run(i, self._assemble(i))
+            self._program.run(slot, self._assemble(i))
 
-        return [launch]
+        # A launch only queues the kernel (its parameter block is copied into the kernel arguments). Sources fed from host
+        # queues upload into the device queue of config i, and a track recorder / hit queue has ONE buffer on the device:
+        # those batches cannot be told apart in flight, their launch stays a plain (serialising) command.
+        if isinstance(self._source, HostLightSource) or isinstance(self._wavelengthSource, HostWavelengthSource) or not self._program.concurrent:
+            return [launch]
+        return [DeviceCommand(i, launch)]
+
+    def setConcurrency(self, lanes: int, gridDivisor: int | None = None) -> None:
+        """`lanes` batches of this tracer in flight at once, each launch on 1 / gridDivisor of the chip
+        (`thx_tracer_set_concurrency`; a scheduler calls this, (1, 1) restores whole-chip launches)"""
+        if self._program.concurrent:
+            self._program.set_concurrency(lanes, gridDivisor)
 
     def _bindShared(self, i) -> None:
         for stage in (self._callback, self._response):
