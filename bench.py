@@ -15,10 +15,18 @@ the timed region. Photon-steps are counted with the EventStatisticCallback
 semantics by an instrumented, untimed replay of exactly the timed batches.
 
 The JSON line carries, besides the contract fields:
-  roofline.units_per_step   the counted traversal units behind the algorithmic bytes (recompute at will)
-  roofline.achieved / frac  SURVEY.md 8(d) contract bytes (32 B per visited box, ...) / kernel time
-  roofline.achieved_layout  the same counts priced with the bytes this build's own records move
-  secondary                 BASELINE configs 3 and 5 at the same photon count (N = 1 only)
+  roofline                  what binds the kernel on the BASELINE scenes is instruction issue, not HBM (they are cache
+                            resident): bound "issue", achieved = vector instructions per second of the dominant kernel
+                            (PMC count per launch, profiles/issue.json / live HIP-event kernel time), peak = what 1024 SIMDs
+                            issue at the measured four-wavefront rates for that instruction mix (profiles/r03_valu_rates.txt),
+                            frac = achieved / peak, lane utilisation beside it; `traffic` = HBM bytes per launch (PMC)
+  roofline.contract         the north star's algorithmic-HBM figure: SURVEY.md 8(d) bytes per counted unit x the units the
+                            instrumented kernel counted / kernel time against 8 TB/s (`contract_frac`; may exceed 1 on a
+                            cache-resident scene) and `frac_layout`, the same counts priced with this build's own records
+  secondary                 BASELINE configs 3 and 5 at the same photon count; the 5.2 M-triangle mesh, the one workload here
+                            that IS bound by HBM (bound "hbm": PMC bytes per launch / kernel time against 8 TB/s); and the
+                            flow of the reference's example 02 end to end: 20 tasks of 2^19 and of 10^6 photons through
+                            `PipelineScheduler` with a processFn that copies the curve, by wall clock (N = 1 only)
   cpu_baseline              the C oracle on the host cores: all cores, and one thread
 
 Multi-GPU (`python -m torch.distributed.run --nproc-per-node N bench.py --gpus N`):
@@ -34,6 +42,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before torch / HIP initialise: the scheduler-flow lines keep 8 launches side by side (theia_amd/__init__.py)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
     if _p not in sys.path:
@@ -42,6 +51,14 @@ for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
 HBM_PEAK_GBS = 8000.0  # MI355X HBM3E spec peak (MI355X_MICROARCH.md); ~6300 GB/s measured copy
 # bytes per counted unit of the roofline contract
 CONTRACT_BYTES = {"nodes": 32.0, "triangles": 48.0, "instances": 112.0, "hits": 132.0, "lut_reads": 8.0}
+# Cycles a SIMD needs per vector instruction of a class with four wavefronts resident (tools/valu_rates.hip ->
+# profiles/r03_valu_rates.txt), the FASTEST member of each class: v_add_f32 1.76, v_mul / v_fma_f32 1.96, transcendentals 5.26,
+# 32-bit integer (v_xor / v_and 1.76; multiplies and three-operand forms need 2.95), 64-bit integer 2.95, conversions 2.74,
+# double precision 2.95, everything else (moves, selects, compares, permutes, lane reads) priced like the cheapest instruction.
+# The peak built from these is what the vector unit could at most have issued of THIS mix: `frac` is a lower bound.
+ISSUE_CYCLES = {"add_f32": 1.76, "mul_f32": 1.96, "fma_f32": 1.96, "trans_f32": 5.26, "int32": 1.76, "int64": 2.95, "cvt": 2.74, "f64": 2.95, "other": 1.76}
+N_SIMD = 1024          # 256 CUs x 4
+CLOCK_HZ = 2.4e9       # MI355X peak engine clock (MI355X_MICROARCH.md)
 COUNTERS = ("queries", "nodes", "triangles", "instances", "hits", "lut_reads", "responses", "steps")  # statistics slots 12..19
 
 WORKLOADS = {
@@ -62,7 +79,7 @@ def parse():
     ap.add_argument("--workload", default="config2", choices=list(WORKLOADS))
     ap.add_argument("--polarized", type=int, default=-1, help="override the workload's polarization (0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 lines")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 / big mesh / scheduler flow lines")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of each CPU-oracle sample")
     return ap.parse_args()
 
@@ -179,6 +196,8 @@ class Measurement:
             "thx::sceneStagedKernel" if self.info.get("block") != 256 else "thx::traceKernel (scene forward)")
 
     def roofline(self, steps_local: int) -> dict:
+        """the north star's contract figure (SURVEY.md 8(d) bytes x counted units / kernel time against the HBM peak) and the
+        same counts priced with this build's own records"""
         units = unit_counts(self.delta)
         grid, K = self.info["grid"], self.K
         contract = priced(units, CONTRACT_BYTES, grid, self.n_bins, K) / K
@@ -190,8 +209,11 @@ class Measurement:
         return {
             "kernel": self.kernel,
             "kernel_ms": self.kernel_ms,
+            "bound": "hbm, algorithmic bytes (SURVEY.md 8(d))",
+            "peak": HBM_PEAK_GBS,
+            "unit": "GB/s",
             "achieved": contract / sec / 1e9,
-            "frac": contract / sec / 1e9 / HBM_PEAK_GBS,
+            "contract_frac": contract / sec / 1e9 / HBM_PEAK_GBS,
             "algorithmic_bytes_per_launch": contract,
             "algorithmic_bytes_per_step": contract * K / max(steps_local, 1),
             "achieved_layout": layout / sec / 1e9,
@@ -200,6 +222,84 @@ class Measurement:
             "units_per_step": {k: v / max(steps_local, 1) for k, v in units.items() if k != "steps"},
             "unit_bytes": {"contract": CONTRACT_BYTES, "layout": layout_per, "hist_flush_per_launch": grid * self.n_bins * 8.0},
         }
+
+
+def profile_json(name: str, workload: str):
+    """per-workload entry of a committed PMC summary (profiles/traffic.json, profiles/issue.json): collected in separate
+    rocprofv3 --pmc passes over this script (tools/prof_round.sh), not in this run"""
+    try:
+        return json.load(open(os.path.join(ROOT, "profiles", name))).get(workload)
+    except Exception:
+        return None
+
+
+def issue_roofline(issue, kernel_ms: float) -> dict:
+    """Vector-instruction issue of the dominant kernel against what 1024 SIMDs can issue of its instruction mix at the
+    measured four-wavefront rates. `issue` = profiles/issue.json entry (PMC counts per launch of 10^7 photons)."""
+    if not issue or not issue.get("vector_instructions"):
+        return {"bound": "issue", "unit": "G vector instructions/s", "achieved": None, "peak": None, "frac": None}
+    valu = float(issue["vector_instructions"])
+    classes = {k: float(v) for k, v in (issue.get("classes") or {}).items() if k in ISSUE_CYCLES}
+    other = max(valu - sum(classes.values()), 0.0)
+    cyc = (sum(n * ISSUE_CYCLES[k] for k, n in classes.items()) + other * ISSUE_CYCLES["other"]) / valu if classes else ISSUE_CYCLES["fma_f32"]
+    achieved = valu / (kernel_ms * 1e-3) / 1e9
+    peak = N_SIMD * CLOCK_HZ / cyc / 1e9
+    lanes = issue.get("lane_utilisation")
+    return {
+        "bound": "issue",
+        "unit": "G vector instructions/s",
+        "achieved": achieved,
+        "peak": peak,
+        "frac": achieved / peak,
+        "lane_utilisation": lanes,
+        "lane_throughput_frac": achieved / peak * lanes if lanes else None,
+        "mix_cycles_per_instruction": cyc,
+        "simd_cycles_per_vector_instruction": N_SIMD * CLOCK_HZ * kernel_ms * 1e-3 / valu,
+        "instructions_per_launch": {"vector": valu, "vector_by_class": dict(classes, other=other) if classes else None,
+                                    "scalar": issue.get("scalar_instructions"), "branch": issue.get("branch_instructions"),
+                                    "vector_memory_reads": issue.get("vector_memory_reads"), "lds": issue.get("lds_instructions")},
+        "class_cycles": ISSUE_CYCLES,
+        "source": issue.get("source"),
+    }
+
+
+def scheduler_flow(S, B: int, N: int, kernel_rate: float, reps: int = 3) -> dict:
+    """The flow of the reference's example 02 (examples/02_scene_tracing.ipynb cells 20-24: `tasks = [{}] * 20`, a
+    processFn that copies `response.result(config)`) on BASELINE config 2, end to end through `PipelineScheduler`:
+    wall clock from schedule() to the end of wait(), best of `reps` after one warm-up; steps from an instrumented
+    replay of the same tasks."""
+    import numpy as np
+
+    from theia_amd.hp import pipeline as pl
+
+    sc_i = S.config2_sphere(B, stats=True)
+    S.run_batches(sc_i, N)
+    steps = int(sc_i.tracer.program.read_stats()[19])
+    del sc_i
+    sc = S.config2_sphere(B)
+    curves = []
+    sched = pl.PipelineScheduler(pl.Pipeline(sc.stages()), processFn=lambda c, b, a: curves.append(sc.response.result(c).copy()))
+    best = float("inf")
+    for rep in range(reps + 1):
+        curves.clear()
+        sc.rng.setParams(offset=0)  # the same photons every time (and the ones the replay counted)
+        t0 = time.perf_counter()
+        sched.schedule([{}] * N)
+        sched.wait()
+        dt = time.perf_counter() - t0
+        if rep:
+            best = min(best, dt)
+    lanes, div, depth = sched._lanes, sched._divisor, sched.batchesInFlight
+    sched.destroy()
+    if len(curves) != N or not all(np.isfinite(c).all() and c.sum() > 0 for c in curves):
+        raise RuntimeError("scheduler flow: invalid light curves")
+    return {
+        "workload": f"example 02 flow on BASELINE config 2: {N} tasks of {B} photons through PipelineScheduler, processFn copies the curve",
+        "photons_per_batch": B, "batches": N, "value": steps / best / 1e6, "unit": "Mphoton-steps/s", "wall_ms": best * 1e3,
+        "ms_per_batch": best / N * 1e3, "steps_per_photon": steps / (B * N), "lanes": lanes, "grid_divisor": div, "batches_in_flight": depth,
+        "vs_kernel_rate_at_1e7": steps / best / kernel_rate if kernel_rate else None,
+        "timing": "wall clock, schedule() to the end of wait(), best of 3 after a warm-up run",
+    }
 
 
 def cpu_baseline(S, _backend, workload: str, polarized: int, seconds: float) -> dict:
@@ -280,33 +380,28 @@ def main() -> None:
         allreduce(dist, total_steps, dist.ReduceOp.SUM)
     elapsed = float(t_max.item())
     steps_all = float(total_steps.item())
+    # every rank's own clock and kernel time (stragglers show here; `ms_per_step` is the maximum over ranks)
+    per_rank = torch.zeros((world, 2), dtype=torch.float64, device=dev)
+    per_rank[rank, 0], per_rank[rank, 1] = m.elapsed / K * 1e3, m.kernel_ms
+    if dist is not None:
+        allreduce(dist, per_rank)
+    per_rank = per_rank.cpu().tolist()
     global_batch = B * world
 
-    traffic = None
-    tfile = os.path.join(ROOT, "profiles", "traffic.json")
-    if os.path.exists(tfile):
-        try:
-            traffic = json.load(open(tfile)).get(args.workload, {}).get("hbm_bytes_per_launch")
-        except Exception:
-            traffic = None
-
-    # what the vector units were doing, from the committed PMC passes (like `traffic`: collected separately, not in this run)
-    issue = None
-    ifile = os.path.join(ROOT, "profiles", "issue.json")
-    if os.path.exists(ifile):
-        try:
-            issue = json.load(open(ifile)).get(args.workload)
-        except Exception:
-            issue = None
-
-    roof = {"bound": "hbm", "peak": HBM_PEAK_GBS, "unit": "GB/s", "traffic": traffic, "issue": issue}
-    roof.update(m.roofline(m.steps_local))
-    roof["note"] = ("bound = the north star's algorithmic-HBM contract: `achieved` = SURVEY.md 8(d) per-unit bytes x the counted units "
-                    "(units_per_step) / kernel time; `achieved_layout` prices the same counts with the bytes this build's records "
-                    "actually move (16 B per box, read from a copy in LDS on small scenes). The BASELINE scenes are cache resident "
-                    "(`traffic` = HBM bytes from PMC counters), so what limits the kernel is instruction issue of divergent code and "
-                    "its dependency chains, not HBM -- which is also why `frac` can exceed 1: the contract's bytes never have to "
-                    "come out of HBM (DESIGN.md sections 3.1 and 5)")
+    traffic = (profile_json("traffic.json", args.workload) or {}).get("hbm_bytes_per_launch")
+    contract = m.roofline(m.steps_local)
+    roof = issue_roofline(profile_json("issue.json", args.workload), m.kernel_ms)
+    roof.update({"kernel": m.kernel, "kernel_ms": m.kernel_ms, "traffic": traffic, "contract": contract,
+                 "contract_frac": contract["contract_frac"], "frac_layout": contract["frac_layout"]})
+    roof["note"] = ("The BASELINE scenes are cache resident (`traffic` = HBM bytes per launch from the PMC counters, 1 % of the algorithmic "
+                    "bytes), so HBM does not bind the kernel; instruction issue of divergent code does. `frac` = vector instructions per second "
+                    "(PMC count per launch / live kernel time) over what 1024 SIMDs issue of that instruction mix at the rates measured with "
+                    "four wavefronts per SIMD, every class priced at its fastest member: a lower bound of how busy the vector units are; "
+                    "x `lane_utilisation` = share of the peak LANE throughput doing photon work. `contract` holds the north star's "
+                    "algorithmic-HBM figure (SURVEY.md 8(d) bytes x counted units / kernel time against 8 TB/s): `contract_frac` exceeds 1 "
+                    "where the build moves fewer bytes than the contract prices (16-B quantised boxes read from a copy in LDS) -- it is "
+                    "not a fraction of anything the hardware does; `frac_layout` prices the same counts with the bytes this build's loads "
+                    "ask for. The workload that IS bound by HBM is in `secondary` (5.2 M triangles, bound hbm).")
 
     result = {
         "metric": "Mphoton-steps/sec at 10^7 photons; achieved HBM GB/s vs roofline",
@@ -316,6 +411,8 @@ def main() -> None:
         "steps": K,
         "warmup": W,
         "ms_per_step": elapsed / K * 1e3,
+        "ms_per_step_per_rank": [r[0] for r in per_rank],
+        "kernel_ms_per_rank": [r[1] for r in per_rank],
         "higher_is_better": True,
         "scaling": "weak",
         "vs_baseline": None,
@@ -335,21 +432,36 @@ def main() -> None:
         "roofline": roof,
     }
 
-    # ---- the other single-GPU BASELINE configs at the same photon count (reported, not the headline)
+    # ---- the other single-GPU BASELINE configs at the same photon count, the HBM-bound mesh and the end-to-end
+    # scheduler flow (reported, not the headline)
     if rank == 0 and world == 1 and not args.no_secondary and args.workload == "config2":
         secondary = []
-        for name in ("config3", "config5"):
+        for name in ("config3", "config5", "bigmesh"):
             k2 = max(2, min(K, 3))
             s = Measurement(S, hip, torch, name, -1, B, k2, 1, 0, 1, None, dev, stream)
             r = s.roofline(s.steps_local)
-            secondary.append({
+            entry = {
                 "workload": WORKLOADS[name], "photons_per_step": B, "steps": k2, "value": s.steps_local / s.elapsed / 1e6,
                 "unit": "Mphoton-steps/s", "ms_per_step": s.elapsed / k2 * 1e3, "steps_per_photon": s.steps_local / (B * k2),
-                "kernel_ms": r["kernel_ms"], "bytes_per_step": r["algorithmic_bytes_per_step"], "achieved": r["achieved"], "frac": r["frac"],
+                "kernel_ms": r["kernel_ms"], "bytes_per_step": r["algorithmic_bytes_per_step"], "contract_frac": r["contract_frac"],
                 "layout_bytes_per_step": r["layout_bytes_per_step"], "frac_layout": r["frac_layout"], "units_per_step": r["units_per_step"],
                 "launch": s.info,
-            })
+            }
+            tr = (profile_json("traffic.json", name) or {}).get("hbm_bytes_per_launch")
+            if name == "bigmesh":  # 355 MB of BVH: the walk's gathers come out of HBM
+                entry["scene"] = s.scene_info
+                entry["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": tr,
+                                     "achieved": tr / (r["kernel_ms"] * 1e-3) / 1e9 if tr else None,
+                                     "frac": tr / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
+                                     "note": "achieved = HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes: "
+                                             "profiles/traffic.json) / live kernel time; 16-B gathers of quantised pair records, 355 MB of BVH"}
+            else:
+                entry["roofline"] = dict(issue_roofline(profile_json("issue.json", name), r["kernel_ms"]), traffic=tr)
+            secondary.append(entry)
             del s
+        kernel_rate = m.steps_local / (K * m.kernel_ms * 1e-3)  # photon-steps per second of the headline's kernel alone
+        for fb in (1 << 19, 1_000_000):
+            secondary.append(scheduler_flow(S, fb, 20, kernel_rate))
         result["secondary"] = secondary
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -277,6 +277,106 @@ def test_config3_batches_through_the_scheduler(hip_backend):
     assert np.abs(alone - curves["hip"][2]).max() <= 1e-5 * alone.sum()
 
 
+@pytest.mark.parametrize("config", ["config2", "config3"])
+def test_batches_in_flight_equal_the_serial_scheduler(hip_backend, config):
+    """The scheduler keeps 16 batches in flight on 8 lanes, each launch on a quarter of the chip
+    (thx_tracer_set_concurrency): every batch's curve equals what the two-config scheduler (one lane, whole-chip
+    launches) and a plain `Pipeline.run` loop give for the same tasks -- up to the order in which the workgroups'
+    fp32 slabs are summed (the photons are spread over another number of workgroups), 2e-6 of the curve -- and the
+    parameter change of task 7 lands in batch 7 and nowhere else."""
+    from theia_amd.hp import pipeline as pl
+
+    make = {"config2": lambda: S.config2_sphere(batch=150_000), "config3": lambda: S.config3_cube_torus(batch=60_000, polarized=True)}[config]
+    tasks = [{}] * 7 + [{"lightSource__budget": 3.0e5 if config == "config3" else 3.0e9}] + [{}] * 12
+    curves = {}
+    for mode, kw in (("in flight", {}), ("two configs", {"lanes": 1}), ("three lanes", {"lanes": 3, "gridDivisor": 2, "inFlight": 5})):
+        sc = make()
+        got = []
+        sched = pl.PipelineScheduler(pl.Pipeline(sc.stages()), processFn=lambda c, b, a: got.append((c, b, sc.response.result(c).copy())), **kw)
+        assert sched.batchesInFlight == {"in flight": 16, "two configs": 2, "three lanes": 5}[mode]
+        sched.schedule(tasks)
+        sched.wait()
+        sched.destroy()
+        assert [(c, b) for c, b, _ in got] == [(k % 2, k) for k in range(len(tasks))]
+        curves[mode] = np.array([h for _, _, h in got])
+        assert sc.rng.offset == len(tasks) * sc.tracer.nRNGSamples
+        # the scheduler handed the chip back: a plain run afterwards takes whole-chip launches again
+        assert hip_backend.tracer_launch_info(sc.tracer.program.handle, 10_000_000)["grid"] == 256
+    sc = make()
+    pipe = pl.Pipeline(sc.stages())
+    serial = []
+    for k, task in enumerate(tasks):
+        if task:
+            pipe.setParams(**task)
+        pipe.run(k % 2)
+        serial.append(sc.response.result(k % 2).copy())
+    serial = np.array(serial)
+    totals = serial.sum(axis=1, keepdims=True)
+    assert (totals > 0).all()
+    for mode, c in curves.items():
+        assert (np.abs(c - serial) <= 2e-6 * totals).all(), (mode, float((np.abs(c - serial) / totals).max()))
+    assert totals[7] > 2.5 * totals[6] and abs(totals[8] / totals[7] - 1) < 0.2  # the budget stays tripled from task 7 on
+    # batches differ from each other by far more than the modes do
+    assert np.abs(serial[0] - serial[1]).max() > 100 * np.abs(curves["in flight"][0] - serial[0]).max()
+
+
+def test_slots_lanes_and_asynchronous_readback_through_the_c_abi(hip_backend, monkeypatch):
+    """thx_tracer_set_concurrency / _fetch_hist / _collect_hist: argument checks, a batch per slot, the watchdog through
+    the asynchronous readback"""
+    from theia_amd import _capi as capi
+    from theia_amd._capi import ThxError
+    from theia_amd.hp.pipeline import Pipeline
+
+    n = 40_000
+    sc = S.config2_sphere(batch=n)
+    pipe = Pipeline(sc.stages())
+    tr, prog = sc.tracer, sc.tracer.program
+    h = prog.handle
+    for bad in ((0, 1), (capi.MAX_SLOTS + 1, 1), (4, 5)):
+        with pytest.raises(ThxError):
+            hip_backend.tracer_set_concurrency(h, *bad)
+    out = np.zeros(sc.response.nBins, np.float32)
+    with pytest.raises(ThxError, match="no thx_tracer_fetch_hist"):
+        hip_backend.tracer_collect_hist(h, 0, out)
+    with pytest.raises(ThxError, match="slot"):
+        hip_backend.tracer_run(h, capi.MAX_SLOTS, tr._assemble(0))
+    # one batch per slot, all in flight before the first one is read: same photons as batch k of a serial loop
+    hip_backend.tracer_set_concurrency(h, 4, 2)
+    assert hip_backend.tracer_launch_info(h, 10_000_000)["grid"] == 128
+    for k in range(capi.MAX_SLOTS):
+        pipe.update(k % 2)
+        hip_backend.tracer_run(h, k, tr._assemble(k % 2))
+        hip_backend.tracer_reduce(h, k, 1.0 / n)
+        hip_backend.tracer_fetch_hist(h, k)
+    got = []
+    for k in range(capi.MAX_SLOTS):
+        hip_backend.tracer_collect_hist(h, k, out)
+        got.append(out.copy())
+    hip_backend.tracer_set_concurrency(h, 1, 1)
+    ref = S.run_batches(S.config2_sphere(batch=n), capi.MAX_SLOTS)
+    for k in range(capi.MAX_SLOTS):
+        assert np.abs(got[k] - ref[k]).max() <= 2e-6 * ref[k].sum(), k
+    # a tripped watchdog comes out of the asynchronous readback as well -- once, for whichever slot is collected first
+    monkeypatch.setenv("THX_TEST_ABORT", "1")
+    hip_backend.tracer_set_concurrency(h, 2, 2)
+    for k in range(2):
+        hip_backend.tracer_run(h, k, tr._assemble(k % 2))
+        hip_backend.tracer_reduce(h, k, 1.0 / n)
+        hip_backend.tracer_fetch_hist(h, k)
+    for k in range(2):
+        with pytest.raises(ThxError, match="watchdog|device error|invalid"):
+            hip_backend.tracer_collect_hist(h, k, out)
+    monkeypatch.delenv("THX_TEST_ABORT")
+    hip_backend.tracer_set_concurrency(h, 1, 1)
+    assert np.isfinite(S.run_batches(sc, 1)[0]).all()
+    # tracers with one output queue cannot run batches side by side
+    from theia_amd.response import HitRecorder
+
+    rec = S.config2_sphere(batch=1000, response=HitRecorder())
+    with pytest.raises(ThxError, match="side by side"):
+        hip_backend.tracer_set_concurrency(rec.tracer.program.handle, 2, 2)
+
+
 @pytest.mark.parametrize("scene", ["suzanne-grid", "sphere-81920"])
 def test_parked_walks_change_nothing(hip_backend, scene, monkeypatch):
     """A walk batch sets its last rays aside and a later batch takes them up again (dev_staged.hpp: walkBatch). Whether that

@@ -8,6 +8,14 @@ here mirror the reference's `theia.*` modules for the components on that path;
 ``import theia`` / ``import hephaistos`` resolve to them through the alias
 packages at the repository root.
 """
+import os as _os
+
+# Batches in flight side by side (PipelineScheduler -> thx_tracer_set_concurrency) need hardware queues: the HIP runtime reads
+# GPU_MAX_HW_QUEUES (default 4: two kernels at once on MI355X) when it initialises, so the variable has to be in place before the
+# first HIP call of the process -- libtheia_hip.so sets it when it is loaded, this line covers processes in which another
+# library (torch) touches HIP first. A value the user has set is kept.
+_os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")
+
 from . import units  # noqa: F401
 
 __version__ = "0.1.0"
