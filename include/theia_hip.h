@@ -335,6 +335,10 @@ int thx_tracer_read_hist(thx_tracer* tracer, uint32_t cfg, float* out, uint32_t 
  * reference's timeline as well; the scheduler's process thread waits for it, docs/pipeline/pipeline.md:80-88.) */
 int thx_tracer_fetch_hist(thx_tracer* tracer, uint32_t cfg, void* stream);
 int thx_tracer_collect_hist(thx_tracer* tracer, uint32_t cfg, float* out, uint32_t n_bins);
+/* HistogramReducer on host arrays (response.py:1065-1197; shader/estimator.reduce.glsl:17-35): out[b] = norm *
+ * KahanSum_h hists[h][b] for n_hist histograms of n_bins bins -- the reducer thx_tracer_reduce runs over a tracer's own
+ * slabs, on data of the caller's (upload, one reduceKernel launch, download; synchronises) */
+int thx_reduce_histograms(thx_ctx* ctx, const float* hists, uint32_t n_hist, uint32_t n_bins, float norm, float* out);
 /* Waits for the tracer's launches and returns THX_ERR_DEVICE if a kernel flagged an error in the tracer's
  * device error word (THX_DEVERR_*; the word is cleared). Every thx_tracer_read_* does the same check; call
  * this after thx_tracer_reduce into an EXTERNAL buffer (d_out != 0), which the library never reads back.
@@ -345,6 +349,8 @@ int thx_tracer_hist_device_ptr(thx_tracer* tracer, uint32_t cfg, uint64_t* out);
 /* EventStatisticCallback (trace.py:77-187) */
 int thx_tracer_read_stats(thx_tracer* tracer, uint64_t* out, uint32_t n);
 int thx_tracer_reset_stats(thx_tracer* tracer);
+/* device address of the THX_N_STATS u64 counters (for thx_stats_allreduce) */
+int thx_tracer_stats_device_ptr(thx_tracer* tracer, uint64_t* dev_addr);
 /* development aid (library built with -DTHX_STAGE_PROFILE): per-stage cycles [0..15],
  * rounds [16..31], photons [32..47] of the staged scene kernel since the last call */
 int thx_tracer_read_stage_profile(thx_tracer* tracer, uint64_t* out48);
@@ -439,6 +445,13 @@ int thx_comm_unique_id(uint8_t out[THX_COMM_ID_BYTES]);
 int thx_comm_init(thx_ctx* ctx, const uint8_t unique_id[THX_COMM_ID_BYTES], int rank, int world_size, thx_comm** out);
 int thx_comm_destroy(thx_comm* comm);
 int thx_hist_allreduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, void* stream);
+/* SURVEY.md 8(e), the other two exchanges it names. thx_stats_allreduce: sum of n u64 counters at d_counters over all
+ * ranks, in place (the 12 event counters of callback.stat.glsl:7-20 + the traversal counters: thx_tracer_stats_device_ptr).
+ * thx_hist_gather_reduce: the deterministic form of the histogram sum -- an all-gather of the ranks' curves in rank order
+ * followed by the slab reducer's fixed-order Kahan sum (estimator.reduce.glsl:17-35) over them: every rank ends with the
+ * same bits in d_hist, run after run, whatever order RCCL's ring would have added them in. Asynchronous on `stream`. */
+int thx_stats_allreduce(thx_comm* comm, uint64_t d_counters, size_t n, void* stream);
+int thx_hist_gather_reduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, void* stream);
 
 #ifdef __cplusplus
 }

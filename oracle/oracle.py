@@ -118,6 +118,8 @@ def lib() -> C.CDLL:
         fp, u32p, u64p = C.POINTER(C.c_float), C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)
         L.orc_rng_fill.argtypes = [C.POINTER(PhiloxParams), C.c_uint32, C.c_uint32, C.c_uint32, C.c_uint32, u32p, fp]
         L.orc_rng_fill.restype = None
+        L.orc_reduce.argtypes = [fp, C.c_uint32, C.c_uint32, C.c_float, fp]
+        L.orc_reduce.restype = None
         L.orc_scene_create.argtypes = [C.POINTER(Mesh), C.c_uint32, C.POINTER(Instance), C.c_uint32]
         L.orc_scene_create.restype = C.c_void_p
         L.orc_scene_destroy.argtypes = [C.c_void_p]
@@ -160,6 +162,14 @@ def lib() -> C.CDLL:
 
 def _fp(a: np.ndarray):
     return a.ctypes.data_as(C.POINTER(C.c_float))
+
+
+def reduce(hists: np.ndarray, norm: float = 1.0) -> np.ndarray:
+    """HistogramReducer (estimator.reduce.glsl:17-35) over hists[n_hist][n_bins]"""
+    h = np.ascontiguousarray(hists, dtype=np.float32)
+    out = np.empty(h.shape[1], dtype=np.float32)
+    lib().orc_reduce(_fp(h), h.shape[0], h.shape[1], float(norm), _fp(out))
+    return out
 
 
 def rng_fill(key: int, offset: int, base_stream: int, n_streams: int, first_dim: int, n_samples: int):

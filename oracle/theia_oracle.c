@@ -2186,6 +2186,21 @@ static void scn_traceMain(Ctx* x, const SceneArgs* a, uint32_t local_idx) {
 
 typedef void (*photon_fn)(Ctx*, const void*, uint32_t);
 
+/* estimator.reduce.glsl:17-35: one thread per bin walks the histograms in order with a compensated (Kahan) sum, then * norm
+ * (`precise` in the shader: no reassociation, no contraction -- volatile keeps the compiler from folding the compensation) */
+void orc_reduce(const float* hists, uint32_t n_hist, uint32_t n_bins, float norm, float* out) {
+    for (size_t bin = 0; bin < n_bins; ++bin) {
+        float result = 0.0f, comp = 0.0f;
+        for (uint32_t n = 0; n < n_hist; ++n) {
+            volatile float y = hists[(size_t)n * n_bins + bin] - comp;
+            volatile float t = result + y;
+            comp = (t - result) - y;
+            result = t;
+        }
+        out[bin] = result * norm;
+    }
+}
+
 static int run_blocks(const orc_common* c, Ctx* proto, photon_fn fn, const void* args,
                       int n_threads, float* hist_out, uint64_t stats[20], float* track,
                       uint32_t track_events) {
@@ -2219,17 +2234,7 @@ static int run_blocks(const orc_common* c, Ctx* proto, photon_fn fn, const void*
 #pragma omp critical
         for (int k = 0; k < ST_COUNT; ++k) total[k] += x.cnt.stats[k];
     }
-    /* estimator.reduce.glsl:17-35 (Kahan over slabs, then * norm) */
-    for (size_t bin = 0; bin < nb; ++bin) {
-        float result = 0.0f, comp = 0.0f;
-        for (uint32_t n = 0; n < n_blocks; ++n) {
-            volatile float y = slabs[(size_t)n * nb + bin] - comp;
-            volatile float t = result + y;
-            comp = (t - result) - y;
-            result = t;
-        }
-        hist_out[bin] = result * c->normalization;
-    }
+    orc_reduce(slabs, n_blocks, (uint32_t)nb, c->normalization, hist_out);
     free(slabs);
     if (stats) memcpy(stats, total, sizeof(uint64_t) * ST_COUNT);
     return 0;

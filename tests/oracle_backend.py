@@ -277,6 +277,9 @@ class OracleBackend:
     def tracer_collect_hist(self, tracer: int, slot: int, out: np.ndarray) -> None:
         out[...] = self._tracers[tracer].fetched.pop(slot)
 
+    def reduce_histograms(self, hists, norm: float = 1.0) -> np.ndarray:
+        return orc.reduce(hists, norm)
+
     def tracer_read_hist(self, tracer: int, cfg: int, n_bins: int) -> np.ndarray:
         return self._tracers[tracer].out[cfg].copy()
 

@@ -261,3 +261,49 @@ def test_hip_functions_equal_the_oracles(hip):
     finally:
         _backend._backend = prev
         oracle.close()
+
+
+@pytest.mark.parametrize("n_hist,n_bins", [(1, 7), (63, 1), (64, 30), (65, 100), (256, 100), (777, 33), (4096, 8)])
+def test_histogram_reducer_on_its_own(backend, n_hist, n_bins):
+    """`HistogramReducer` (response.py:1065-1197, estimator.reduce.glsl:17-35): out[b] = norm * compensated sum over the
+    histograms of bin b. (i) Random slabs spanning 30 orders of magnitude with both signs, denormals and exact zeros: within
+    Kahan's bound 2 eps sum|x| of the float64 sum, whatever the number of histograms. (ii) What compensation is for -- one
+    large slab and many small ones: within an ulp of the float64 sum where a plain fp32 loop is off by dozens. Same bounds
+    for the oracle's serial loop and for HIP (one wavefront per bin: Kahan partials per lane, fixed butterfly)."""
+    eps = float(np.finfo(np.float32).eps)
+    gen = np.random.default_rng(SEED + 17 * n_hist + n_bins)
+    mag = 10.0 ** gen.uniform(-36.0, -6.0, (n_hist, n_bins))
+    slabs = (mag * gen.choice([-1.0, 1.0], (n_hist, n_bins))).astype(np.float32)
+    slabs[gen.random((n_hist, n_bins)) < 0.1] = 0.0
+    slabs.reshape(-1)[:: max(1, slabs.size // 11)] = np.float32(1e-41)  # denormals
+    norm = np.float32(0.37)
+    got = _backend.get().reduce_histograms(slabs, norm).astype(np.float64)
+    exact = slabs.astype(np.float64).sum(axis=0) * np.float64(norm)
+    scale = np.abs(slabs.astype(np.float64)).sum(axis=0) * np.float64(norm)
+    assert (np.abs(got - exact) <= 2 * eps * scale + eps * np.abs(exact) + 1e-44).all(), float((np.abs(got - exact) / np.maximum(scale, 1e-300)).max() / eps)
+
+    big = np.full((n_hist, n_bins), 0.1, np.float32)
+    big[0, :] = np.float32(1.0e4) * (1 + np.arange(n_bins, dtype=np.float32))
+    got = _backend.get().reduce_histograms(big, 1.0).astype(np.float64)
+    exact = big.astype(np.float64).sum(axis=0)
+    assert (np.abs(got - exact) <= 1.01 * np.spacing(exact.astype(np.float32)).astype(np.float64)).all()
+    if n_hist >= 777:
+        plain = np.zeros(n_bins, np.float32)
+        for h in big:
+            plain += h
+        assert np.abs(plain.astype(np.float64) - exact).min() > 20 * np.abs(got - exact).max()
+
+
+def test_histogram_reducer_edge_cases(backend):
+    be = _backend.get()
+    inf = np.float32(np.inf)
+    slabs = np.zeros((5, 4), np.float32)
+    slabs[2, 0], slabs[3, 1], slabs[1, 2], slabs[4, 2] = inf, -inf, inf, -inf
+    out = be.reduce_histograms(slabs, 2.0)
+    # an infinite slab poisons its bin and no other: the compensation term (t - result) - y is inf - inf = NaN from there on, in the
+    # shader's loop as here -- the bin comes out non-finite, never as a plausible number
+    assert not np.isfinite(out[:3]).any() and out[3] == 0.0
+    assert np.array_equal(be.reduce_histograms(np.full((300, 3), 0.1, np.float32), 1.0), np.full(3, np.float32(30.0)))  # 300 x 0.1f, compensated
+    assert np.array_equal(be.reduce_histograms(np.zeros((0, 6), np.float32), 1.0), np.zeros(6, np.float32))  # nothing to sum
+    one = np.arange(9, dtype=np.float32)[None, :]
+    assert np.array_equal(be.reduce_histograms(one, 0.5), one[0] * np.float32(0.5))

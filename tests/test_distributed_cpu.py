@@ -34,13 +34,20 @@ def _worker(rank, world, port, n_total, out_dir):
     dist = distributed.init_from_env("gloo")
     _backend.install(OracleBackend(threads=2))
     begin, end = distributed.shard_range(n_total, rank, world)
-    sc = S.config2_sphere(end - begin)
+    sc = S.config2_sphere(end - begin, stats=True)
     sc.response.normalization = 1.0 / n_total
     sc.tracer.photonOffset = begin
-    hist = torch.from_numpy(S.run_batches(sc, 1)[0].copy())
+    mine = S.run_batches(sc, 1)[0].copy()
+    hist = torch.from_numpy(mine.copy())
     distributed.reduce_histograms(hist, dist)
+    # the deterministic form (all-gather + fixed-order Kahan) and the u64 counter sum of SURVEY.md 8(e)
+    exact = torch.from_numpy(mine.copy())
+    distributed.gather_reduce_histograms(exact, dist)
+    counters = distributed.reduce_counters(sc.tracer.program.read_stats(), dist)
+    np.save(os.path.join(out_dir, f"exact{rank}.npy"), exact.numpy())
     if rank == 0:
         np.save(os.path.join(out_dir, "reduced.npy"), hist.numpy())
+        np.save(os.path.join(out_dir, "counters.npy"), counters)
     dist.barrier()
     dist.destroy_process_group()
 
@@ -68,3 +75,12 @@ def test_two_rank_gloo_reduce_equals_single_process(tmp_path, oracle_backend):
     full = S.run_batches(S.config2_sphere(n), 1)[0]
     assert full.sum() > 0
     assert np.abs(reduced - full).max() <= 1e-5 * full.sum()  # same photons, different fp32 summation order
+    # gather + fixed-order Kahan: the same bits on both ranks, and the same curve
+    e0, e1 = np.load(tmp_path / "exact0.npy"), np.load(tmp_path / "exact1.npy")
+    assert np.array_equal(e0, e1) and np.abs(e0 - full).max() <= 1e-5 * full.sum()
+    # the event counters of the two shards add up to those of the whole batch
+    sc = S.config2_sphere(n, stats=True)
+    S.run_batches(sc, 1)
+    whole = sc.tracer.program.read_stats()
+    counters = np.load(tmp_path / "counters.npy")
+    assert counters[0] == n and np.array_equal(counters[:12], whole[:12]) and counters[19] == whole[19]

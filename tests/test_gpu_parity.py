@@ -583,6 +583,16 @@ def test_rccl_allreduce_through_the_c_abi(hip_backend):
     back = np.empty_like(curve)
     capi.check(capi.lib().thx_mem_download(hip_backend._ctx, back.ctypes.data_as(C.c_void_p), addr.value, back.nbytes))  # syncs the stream
     assert np.array_equal(back, curve)
+    # the deterministic form (all-gather + the slab reducer's fixed-order Kahan sum) and the u64 counter sum of SURVEY 8(e)
+    hip_backend.hist_gather_reduce(comm, addr.value, curve.size)
+    capi.check(capi.lib().thx_mem_download(hip_backend._ctx, back.ctypes.data_as(C.c_void_p), addr.value, back.nbytes))
+    assert np.array_equal(back, curve)
+    sc = S.config2_sphere(batch=5000, stats=True)
+    S.run_batches(sc, 1)
+    before = sc.tracer.program.read_stats()
+    assert before[0] == 5000
+    hip_backend.stats_allreduce(comm, hip_backend.tracer_stats_ptr(sc.tracer.program.handle), capi.N_STATS)
+    assert np.array_equal(sc.tracer.program.read_stats(), before)  # (read_stats synchronises the device)
     capi.check(capi.lib().thx_mem_free(hip_backend._ctx, addr.value))
     hip_backend.comm_destroy(comm)
     with pytest.raises(capi.ThxError):

@@ -143,3 +143,45 @@ def test_tracer_on_sobol_agrees_with_philox(backend):
                 sc = make(batch=64 * 1024, rng=TRN.SobolQRNG(seed=0xC0FFEE, advanceSeed=7), **kw)
             totals[name] = np.mean([h.sum() for h in S.run_batches(sc, 4)])
         assert totals["philox"] > 0 and abs(totals["sobol"] / totals["philox"] - 1.0) < 0.05, totals
+
+
+def test_streaming_kernels_draw_from_the_sobol_sampler(backend):
+    """The small kernels around the path -- `LightSampler`, `HitReplay` with a store-time response, the target probe -- have
+    one compiled variant each and take the generator their stage was given. (Round 3 compiled the Sobol sampler out of every
+    variant without statistics; these three then drew Philox numbers keyed with the Sobol seed, silently.) The first draw of
+    stream k is `python_sobol(seed, k, 0)`: the sampled wavelength, the acceptance of hit k and the observer's x show it."""
+    import theia.light as TL
+    import theia.response as TR
+    import theia.target as TT
+    from theia.testing import TargetSampler
+    from theia.scene import RectBBox
+
+    seed, n = 0xBADC0DE, 200
+    u = np.array([python_sobol(seed, k, 0) for k in range(n)], dtype=np.float32)
+    assert 0.3 < u.mean() < 0.7
+
+    # lightsource.sample.glsl: sampleWavelength draws first (wavelengthsource.uniform.glsl:12-16: mix(lam_min, lam_max, u))
+    lam0, lam1 = 300.0, 700.0
+    sampler = TL.LightSampler(TL.SphericalLightSource(), TL.UniformWavelengthSource(lambdaRange=(lam0, lam1)), n, rng=TRN.SobolQRNG(seed=seed))
+    pl.runPipeline(sampler.collectStages())
+    got = np.array(sampler.wavelengthQueue.view(0)["wavelength"][:n])
+    want = np.float32(lam0) * (np.float32(1.0) - u) + np.float32(lam1) * u
+    assert np.allclose(got, want, rtol=1e-6, atol=0), np.abs(got - want).max()
+
+    # response.time.store.glsl: a hit is kept if random() < value; hit k of a replay is stream k, dimension 0
+    response = TR.StoreTimeHitResponse(TR.UniformValueResponse())
+    replay = TR.HitReplay(n, response, rng=TRN.SobolQRNG(seed=seed))
+    q = replay.queue.view(0)
+    q["time"], q["contrib"], q["objectId"] = np.arange(n, dtype=np.float32), np.full(n, 0.5, np.float32), np.arange(n, dtype=np.int32)
+    pl.runPipeline(replay.collectStages())
+    r = response.result(0)
+    kept = np.sort(np.array(r["objectId"][: r.count]))
+    assert np.array_equal(kept, np.nonzero(u < np.float32(0.5))[0]) and 0 < len(kept) < n
+
+    # target.sample.glsl: the observer's x is the first draw, mixed into the box
+    probe = TargetSampler(n, TT.SphereTarget(position=(0.0, 0.0, 0.0), radius=1.0), rng=TRN.SobolQRNG(seed=seed),
+                          sampleBox=RectBBox((-2.0, -3.0, -4.0), (6.0, 3.0, 4.0)))
+    pl.runPipeline(probe.collectStages())
+    x = probe.getResults(0)["observer"][:, 0]
+    want = np.float32(-2.0) * (np.float32(1.0) - u) + np.float32(6.0) * u
+    assert np.allclose(x, want, rtol=1e-5, atol=1e-6), np.abs(x - want).max()

@@ -180,6 +180,26 @@ class HipBackend:
     def hist_allreduce(self, comm: int, d_hist: int, n_floats: int, stream: int = 0) -> None:
         capi.check(self._lib.thx_hist_allreduce(C.c_void_p(comm), int(d_hist), int(n_floats), C.c_void_p(stream) if stream else None))
 
+    def stats_allreduce(self, comm: int, d_counters: int, n: int, stream: int = 0) -> None:
+        capi.check(self._lib.thx_stats_allreduce(C.c_void_p(comm), int(d_counters), int(n), C.c_void_p(stream) if stream else None))
+
+    def hist_gather_reduce(self, comm: int, d_hist: int, n_floats: int, stream: int = 0) -> None:
+        """deterministic histogram sum: all-gather + fixed-order Kahan (thx_hist_gather_reduce)"""
+        capi.check(self._lib.thx_hist_gather_reduce(C.c_void_p(comm), int(d_hist), int(n_floats), C.c_void_p(stream) if stream else None))
+
+    def tracer_stats_ptr(self, tracer: int) -> int:
+        out = C.c_uint64()
+        capi.check(self._lib.thx_tracer_stats_device_ptr(C.c_void_p(tracer), C.byref(out)))
+        return int(out.value)
+
+    def reduce_histograms(self, hists, norm: float = 1.0) -> np.ndarray:
+        """HistogramReducer on a host array [n_hist][n_bins] (thx_reduce_histograms)"""
+        h = np.ascontiguousarray(hists, dtype=np.float32)
+        out = np.empty(h.shape[1], dtype=np.float32)
+        capi.check(self._lib.thx_reduce_histograms(self._ctx, h.ctypes.data_as(C.POINTER(C.c_float)), h.shape[0], h.shape[1], float(norm),
+                                                   out.ctypes.data_as(C.POINTER(C.c_float))))
+        return out
+
     def tracer_read_hist(self, tracer: int, cfg: int, n_bins: int) -> np.ndarray:
         out = np.empty(int(n_bins), dtype=np.float32)
         capi.check(self._lib.thx_tracer_read_hist(C.c_void_p(tracer), int(cfg), out.ctypes.data_as(C.POINTER(C.c_float)), int(n_bins)))

@@ -194,6 +194,8 @@ _PROTOS = {
     "thx_tracer_set_concurrency": (c_int, [c_void_p, c_uint32, c_uint32]),
     "thx_tracer_fetch_hist": (c_int, [c_void_p, c_uint32, c_void_p]),
     "thx_tracer_collect_hist": (c_int, [c_void_p, c_uint32, POINTER(c_float), c_uint32]),
+    "thx_reduce_histograms": (c_int, [c_void_p, POINTER(c_float), c_uint32, c_uint32, c_float, POINTER(c_float)]),
+    "thx_tracer_stats_device_ptr": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_check": (c_int, [c_void_p]),
     "thx_tracer_hist_device_ptr": (c_int, [c_void_p, c_uint32, POINTER(c_uint64)]),
     "thx_tracer_read_stats": (c_int, [c_void_p, POINTER(c_uint64), c_uint32]),
@@ -220,6 +222,8 @@ _PROTOS = {
     "thx_comm_init": (c_int, [c_void_p, c_void_p, c_int, c_int, POINTER(c_void_p)]),
     "thx_comm_destroy": (c_int, [c_void_p]),
     "thx_hist_allreduce": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
+    "thx_stats_allreduce": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
+    "thx_hist_gather_reduce": (c_int, [c_void_p, c_uint64, c_size_t, c_void_p]),
 }
 EXPORTED_SYMBOLS = tuple(_PROTOS.keys())
 

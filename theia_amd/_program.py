@@ -52,7 +52,17 @@ class _Program:
         self.backend.tracer_reduce(self.handle, cfg, norm, d_out)
 
     def set_concurrency(self, lanes: int, grid_divisor: int | None = None) -> None:
-        self.backend.tracer_set_concurrency(self.handle, lanes, grid_divisor)
+        """`lanes` batches in flight, each launch on 1 / grid_divisor of the chip. A tracer prepared for very large batches
+        cannot cut its launches that small (the library bounds the ring positions of a workgroup): the divisor is halved
+        until it fits -- such batches hide the tail of a launch by their size anyway."""
+        div = int(grid_divisor or lanes)
+        while True:
+            try:
+                return self.backend.tracer_set_concurrency(self.handle, lanes, div)
+            except capi.ThxError as err:
+                if "grid_divisor too large" not in str(err) or div == 1:
+                    raise
+                div //= 2
 
     def fetch_hist(self, slot: int) -> None:
         self.backend.tracer_fetch_hist(self.handle, slot)

@@ -486,6 +486,9 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // 16-bit stack entries are read sign-extended (0xFFFE / 0xFFFF = leave the instance / done): every ref = index << 3 | count
         // of the scene has to stay below 0x8000
         t->stack16 = scene->nPairs < 4096 * kRecordSlots && scene->info.n_triangles < 4096 && scene->info.n_instances < 4096;
+        // (what the bound stands for, checked on the value itself: the largest ref any stack entry of this scene can hold)
+        const uint32_t maxIndex = std::max(std::max(scene->nPairs / kRecordSlots, scene->info.n_triangles), scene->info.n_instances);
+        if (t->stack16 && ((maxIndex << 3) | 7u) >= 0x8000u) { delete t; return fail(THX_ERR_INVALID, "internal: 16-bit stack entries picked for a scene with refs >= 0x8000"); }
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
         // test hook: a stack shallower than the scene needs (the walk then flags ERROR_CODE_TRACE_ABORT)
         if (const char* env = std::getenv("THX_STACK_DEPTH")) t->stackDepth = (uint32_t)std::min<int>(kStackDepth, std::max(1, std::atoi(env)));
@@ -520,8 +523,13 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // into cells by a reciprocal multiplication that is exact below 2^25 appends per ring and launch; a generous bound
         // on those -- photons of the busiest workgroup x steps x 16 (two shadow rays, walks set aside and taken up again)
         // -- decides (THX_RING_POW2=1 forces the power of two). The kernel checks its ring counters against the limit.
+        // (decided below, once pool and grid are final)
+        // Bound from the values a launch actually uses: a workgroup traces ceil(batch / grid) photons with grid = min(CUs, ceil(batch
+        // / pool)), i.e. at most max(ceil(capacity / CUs), the largest pool) -- kPoolMax covers THX_POOL and every pool the
+        // sizing below can pick.
         {
-            const uint64_t perWg = std::max<uint64_t>(((uint64_t)desc->capacity + ctx->prop.multiProcessorCount - 1) / (uint64_t)ctx->prop.multiProcessorCount, kPoolBest);
+            const uint64_t cus = (uint64_t)std::max(1, ctx->prop.multiProcessorCount);
+            const uint64_t perWg = std::max<uint64_t>(((uint64_t)desc->capacity + cus - 1) / cus, kPoolMax);
             t->exactRings = perWg * (uint64_t)(desc->path_length + 2) * 16u < (1ull << 25);
             if (const char* env = std::getenv("THX_RING_POW2")) t->exactRings = t->exactRings && std::atoi(env) == 0;
         }
@@ -704,6 +712,14 @@ int thx_tracer_set_concurrency(thx_tracer* t, uint32_t lanes, uint32_t grid_divi
     if (grid_divisor < 1 || grid_divisor > lanes) return fail(THX_ERR_INVALID, "grid_divisor must be in [1, lanes]");
     if (lanes > 1 && (t->hits || t->track || t->replayIn || t->lamOut))
         return fail(THX_ERR_INVALID, "tracers with one output queue or track buffer cannot run batches side by side");
+    // rings of exactly the pool's size turn positions into cells exactly below 2^25 appends per ring and launch (thx_tracer_create):
+    // the same generous bound, with the photons of a workgroup of a launch on 1 / grid_divisor of the chip
+    if (t->staged && t->exactRings) {
+        const uint64_t grid = std::max<uint64_t>(1, (t->gridMax + grid_divisor - 1) / grid_divisor);
+        const uint64_t perWg = std::max<uint64_t>(((uint64_t)t->desc.capacity + grid - 1) / grid, kPoolMax);
+        if (perWg * (uint64_t)(t->desc.path_length + 2) * 16u >= (1ull << 25))
+            return fail(THX_ERR_INVALID, "grid_divisor too large for this tracer's capacity: a workgroup's ring positions could pass 2^25 (use a smaller divisor or capacity)");
+    }
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize()); // the lanes' shares of the scratch memory change
     const uint32_t oldLanes = t->conc, oldDiv = t->gridDiv;
@@ -1148,6 +1164,31 @@ int thx_rng_fill_sobol(thx_ctx* ctx, uint32_t seed, uint32_t base_stream, uint32
     return THX_OK;
 }
 
+int thx_reduce_histograms(thx_ctx* ctx, const float* hists, uint32_t n_hist, uint32_t n_bins, float norm, float* out) {
+    if (!ctx || !out || (!hists && n_hist)) return fail(THX_ERR_INVALID, "null argument");
+    if (n_bins == 0) return THX_OK;
+    std::lock_guard<std::mutex> guard(ctx->lock);
+    THX_HIP(hipSetDevice(ctx->device));
+    float *d_in = nullptr, *d_out = nullptr;
+    const size_t nb = sizeof(float) * (size_t)n_hist * n_bins;
+    THX_HIP(hipMalloc((void**)&d_in, nb ? nb : 16));
+    hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * n_bins);
+    if (e == hipSuccess && nb) e = hipMemcpyAsync(d_in, hists, nb, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = launchReduce(d_in, d_out, n_bins, n_hist, norm, nullptr, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(float) * n_bins, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    (void)hipFree(d_in);
+    if (d_out) (void)hipFree(d_out);
+    if (e != hipSuccess) return hipFail(e, "thx_reduce_histograms");
+    return THX_OK;
+}
+
+int thx_tracer_stats_device_ptr(thx_tracer* t, uint64_t* dev_addr) {
+    if (!t || !dev_addr) return fail(THX_ERR_INVALID, "null argument");
+    *dev_addr = (uint64_t)(uintptr_t)t->stats;
+    return THX_OK;
+}
+
 } // extern "C"
 
 // ------------------------------------------------------------------ RCCL
@@ -1161,6 +1202,7 @@ struct RcclApi {
     int (*commInitRank)(void**, int, Id128, int) = nullptr;
     int (*commDestroy)(void*) = nullptr;
     int (*allReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*allGather)(const void*, void*, size_t, int, void*, hipStream_t) = nullptr;
     const char* (*getErrorString)(int) = nullptr;
 };
 RcclApi g_rccl;
@@ -1177,9 +1219,10 @@ bool loadRccl(std::string& why) {
     g_rccl.commInitRank = reinterpret_cast<decltype(g_rccl.commInitRank)>(dlsym(g_rccl.lib, "ncclCommInitRank"));
     g_rccl.commDestroy = reinterpret_cast<decltype(g_rccl.commDestroy)>(dlsym(g_rccl.lib, "ncclCommDestroy"));
     g_rccl.allReduce = reinterpret_cast<decltype(g_rccl.allReduce)>(dlsym(g_rccl.lib, "ncclAllReduce"));
+    g_rccl.allGather = reinterpret_cast<decltype(g_rccl.allGather)>(dlsym(g_rccl.lib, "ncclAllGather"));
     g_rccl.getErrorString = reinterpret_cast<decltype(g_rccl.getErrorString)>(dlsym(g_rccl.lib, "ncclGetErrorString"));
-    if (!g_rccl.getUniqueId || !g_rccl.commInitRank || !g_rccl.commDestroy || !g_rccl.allReduce) {
-        why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce";
+    if (!g_rccl.getUniqueId || !g_rccl.commInitRank || !g_rccl.commDestroy || !g_rccl.allReduce || !g_rccl.allGather) {
+        why = "librccl lacks ncclGetUniqueId / ncclCommInitRank / ncclCommDestroy / ncclAllReduce / ncclAllGather";
         dlclose(g_rccl.lib);
         g_rccl = RcclApi{};
         return false;
@@ -1195,6 +1238,8 @@ struct thx_comm {
     thx_ctx* ctx = nullptr;
     void* nccl = nullptr;
     int rank = 0, world = 1;
+    float* gathered = nullptr; // [world][n] staging of thx_hist_gather_reduce
+    size_t gatheredFloats = 0;
 };
 
 extern "C" {
@@ -1231,6 +1276,7 @@ int thx_comm_destroy(thx_comm* comm) {
     if (!comm) return THX_OK;
     (void)hipSetDevice(comm->ctx->device);
     if (comm->nccl) g_rccl.commDestroy(comm->nccl);
+    if (comm->gathered) (void)hipFree(comm->gathered);
     delete comm;
     return THX_OK;
 }
@@ -1244,6 +1290,39 @@ int thx_hist_allreduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, void* s
     // ncclFloat32 = 7, ncclSum = 0 (rccl.h); in place
     int rc = g_rccl.allReduce(p, p, n_floats, 7, 0, comm->nccl, s);
     return rc == 0 ? THX_OK : rcclFail(rc, "ncclAllReduce");
+}
+
+int thx_stats_allreduce(thx_comm* comm, uint64_t d_counters, size_t n, void* stream) {
+    if (!comm || (d_counters == 0 && n)) return fail(THX_ERR_INVALID, "null argument");
+    if (n == 0) return THX_OK;
+    THX_HIP(hipSetDevice(comm->ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : comm->ctx->stream;
+    void* p = (void*)(uintptr_t)d_counters;
+    // ncclUint64 = 5, ncclSum = 0 (rccl.h); in place
+    int rc = g_rccl.allReduce(p, p, n, 5, 0, comm->nccl, s);
+    return rc == 0 ? THX_OK : rcclFail(rc, "ncclAllReduce (u64)");
+}
+
+int thx_hist_gather_reduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, void* stream) {
+    if (!comm || (d_hist == 0 && n_floats)) return fail(THX_ERR_INVALID, "null argument");
+    if (n_floats == 0) return THX_OK;
+    if (n_floats > 0xFFFFFFFFull) return fail(THX_ERR_INVALID, "histogram too large");
+    THX_HIP(hipSetDevice(comm->ctx->device));
+    hipStream_t s = stream ? (hipStream_t)stream : comm->ctx->stream;
+    const size_t need = n_floats * (size_t)comm->world;
+    if (need > comm->gatheredFloats) {
+        THX_HIP(hipStreamSynchronize(s));
+        if (comm->gathered) (void)hipFree(comm->gathered);
+        comm->gathered = nullptr; comm->gatheredFloats = 0;
+        THX_HIP(hipMalloc((void**)&comm->gathered, sizeof(float) * need));
+        comm->gatheredFloats = need;
+    }
+    // every rank's curve, in rank order, on every rank ...
+    int rc = g_rccl.allGather((const void*)(uintptr_t)d_hist, comm->gathered, n_floats, 7, comm->nccl, s);
+    if (rc != 0) return rcclFail(rc, "ncclAllGather");
+    // ... summed by the slab reducer: Kahan partials per lane, fixed butterfly -- the same bits on every rank and in every run
+    THX_HIP(launchReduce(comm->gathered, (float*)(uintptr_t)d_hist, (uint32_t)n_floats, (uint32_t)comm->world, 1.0f, nullptr, s));
+    return THX_OK;
 }
 
 } // extern "C"

@@ -8,7 +8,7 @@ namespace thx {
 
 // compile-time specialisation of one kernel variant (the reference specialises
 // through GLSL macros, trace.py:660-666 / :1226-1235)
-template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, int STACK_ = 0>
+template <bool POL_, bool MIS_, bool STATS_, bool TRACK_, int STACK_ = 0, int QRNG_ = -1>
 struct Variant {
     static constexpr bool POL = POL_;       // POLARIZATION
     static constexpr bool MIS = MIS_;       // !DISABLE_MIS
@@ -16,10 +16,13 @@ struct Variant {
     static constexpr bool TRACK = TRACK_;   // per-event dump
     // The scrambled Sobol sampler (THX_FLAG_RNG_SOBOL) is compiled into the instrumented variants only, which the host picks for
     // it: inlined behind a run-time flag at each of the ~50 places a kernel draws a number it made the production kernels a
-    // quarter larger than the 64 KB of instruction cache two CUs share (round 3: 72 KB -> 55 KB).
-    static constexpr bool QRNG = STATS_;
+    // quarter larger than the 64 KB of instruction cache two CUs share (round 3: 72 KB -> 55 KB). QRNG_ = 1 compiles it into
+    // a variant regardless: the small streaming kernels around the path (light sampler, hit replay, probes) have one
+    // variant each and take whatever generator the host stage was given.
+    static constexpr bool QRNG = QRNG_ < 0 ? STATS_ : QRNG_ != 0;
     // What is known about the traversal stack at compile time. 0: nothing (entry width and the split between LDS and global
-    // memory are decided at run time); 1: 16-bit entries (scenes below 8 190 nodes / triangles / instances); 2: 16-bit
+    // memory are decided at run time); 1: 16-bit entries (scenes below 4 096 pair records / triangles / instances: every ref = index << 3 | count stays below 0x8000, which the
+    // sign-extending pops of Walker<V, true> rely on -- the host checks the scene's largest ref before it picks such a variant); 2: 16-bit
     // entries and the whole stack in LDS (such scenes no deeper than the LDS share). Every push and pop loses a
     // wave-uniform branch with 1 and a lane-divergent one with 2: -1 % and -2 %. 3: as 2, and the walk reads the pair
     // records from a copy in LDS (scenes whose whole node array fits next to the photon pool): an LDS read returns in
@@ -53,7 +56,7 @@ struct LaunchArgs {
     uint32_t stack_depth;      // traversal stack entries per lane
     uint32_t stack_lds;        // the first stack_lds of them live in LDS, deeper ones in `spill` (== stack_depth: all in LDS)
     uint32_t stack_wave_words; // LDS words of one wavefront's stack block (stack_lds*64, or stack_lds*32 for 16-bit entries)
-    uint32_t stack16;          // 1: stack entries are 16 bit (scene has < 8190 nodes/triangles)
+    uint32_t stack16;          // 1: stack entries are 16 bit (every ref of the scene < 0x8000: fewer than 4096 pair records / triangles / instances)
     uint32_t lds_node_word;    // staged kernel, Variant::LDSN: LDS word index of the copy of the pair records ...
     uint32_t lds_node_pairs;   // ... and how many records it holds (all of the scene's)
     uint32_t refill_below;     // refill dead lanes when <= this many lanes are still active

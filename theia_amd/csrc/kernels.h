@@ -50,6 +50,7 @@ constexpr uint32_t kLdsNodeMinPool = 1056;
 // config 2 read through the vector cache (THX_LDS_NODES=0) runs 2.58 / 2.48 / 2.48 ms at 1344 / 1472 / 1600; config 5 and the
 // large meshes are flat from 1344 on (gpurun_out/r03/sweep20-22.txt)
 constexpr uint32_t kPoolBest = 1472;
+constexpr uint32_t kPoolMax = 2048; // == THX_POOL_MAX of dev_staged.hpp: the largest pool any sizing (or THX_POOL) can pick
 
 // one function pair per compiled variant (trace_variant.hip, built once per
 // KIND x POL x MIS); mode bit 0 selects the instrumented (statistics + track) kernel,

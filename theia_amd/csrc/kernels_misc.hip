@@ -37,6 +37,7 @@ uint32_t stagedPoolFor(bool polarized, uint32_t n_bins, uint32_t stackBytesPerTh
 uint32_t stagedRingCap(uint32_t pool, bool exactRings) { return StagedLayout<false>::qcap(pool, exactRings); }
 size_t stagedColdBytes(bool polarized, uint32_t pool) { return polarized ? StagedLayout<true>::coldBytes(pool) : StagedLayout<false>::coldBytes(pool); }
 static_assert(kStagedBlock == kSchedThreads && kStagedBlockDebug == kSchedThreadsDebug, "staged block sizes");
+static_assert(kPoolMax == THX_POOL_MAX, "pool bound");
 
 // estimator.reduce.glsl:17-35: out[b] = norm * sum_h slab[h][b] with compensated
 // (Kahan) summation. The reference walks the slabs with one thread per bin; with
@@ -86,7 +87,7 @@ hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_
 // and writes 256 contiguous bytes per column.
 __global__ void __launch_bounds__(kReplayBlock) replayKernel(const LaunchArgs args, const uint32_t* __restrict__ in,
                                                              uint32_t in_capacity, uint32_t in_polarized) {
-    using V = Variant<false, true, false, false>;
+    using V = Variant<false, true, false, false, 0, 1>;
     const uint32_t tid = threadIdx.x;
     const uint32_t n_bins = args.n_bins;
     float* hist = ldsHist();
@@ -145,7 +146,7 @@ hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32
 template <bool POL>
 __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs args, uint32_t* __restrict__ light_out,
                                                               uint32_t* __restrict__ lam_out, uint32_t capacity) {
-    using V = Variant<POL, true, false, false>;
+    using V = Variant<POL, true, false, false, 0, 1>;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t count = args.p.dispatch.batchSize;
     if (idx >= count) return;
@@ -215,7 +216,7 @@ THX_DEV void putTargetSample(float* o, f3 observer, const TargetSample& ts, bool
 }
 struct ProbeBox { float lo[3], hi[3]; };
 __global__ void probeTargetKernel(const LaunchArgs args, ProbeBox box, uint32_t n, float* out) {
-    using V = Variant<false, true, false, false>;
+    using V = Variant<false, true, false, false, 0, 1>;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Lane<V> L;
@@ -233,7 +234,7 @@ __global__ void probeTargetKernel(const LaunchArgs args, ProbeBox box, uint32_t 
     o[24] = __uint_as_float(isOccludedByTarget(args.p.target, observer, args.flags) ? 1u : 0u);
 }
 __global__ void probeGuideKernel(const LaunchArgs args, ProbeBox box, uint32_t n, float* out) {
-    using V = Variant<false, true, false, false>;
+    using V = Variant<false, true, false, false, 0, 1>;
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= n) return;
     Lane<V> L;

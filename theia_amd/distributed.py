@@ -10,7 +10,7 @@ from __future__ import annotations
 
 import os
 
-__all__ = ["init_from_env", "shard_range", "reduce_histograms", "world", "rank"]
+__all__ = ["init_from_env", "shard_range", "reduce_histograms", "gather_reduce_histograms", "reduce_counters", "world", "rank"]
 
 
 def world() -> int:
@@ -61,3 +61,41 @@ def reduce_histograms(hist, dist=None):
         torch.cuda.synchronize(hist.device)
     dist.all_reduce(hist, op=dist.ReduceOp.SUM)
     return hist
+
+
+def gather_reduce_histograms(hist, dist=None):
+    """The deterministic form of `reduce_histograms` ("gather + fixed-order Kahan"): every rank gathers
+    all ranks' histograms in rank order and sums them with the slab reducer (`HistogramReducer`: Kahan partials, fixed
+    order) -- the same bits on every rank and in every run, whatever order a ring all-reduce would have added them in.
+    The torch.distributed counterpart of the C ABI's `thx_hist_gather_reduce`. In place; no-op for one process."""
+    if dist is None:
+        return hist
+    import torch
+
+    from . import _backend
+
+    if getattr(hist, "is_cuda", False):
+        torch.cuda.synchronize(hist.device)
+    flat = hist.reshape(-1)
+    parts = [torch.empty_like(flat) for _ in range(dist.get_world_size())]
+    dist.all_gather(parts, flat)
+    stacked = torch.stack(parts).cpu().numpy()
+    flat.copy_(torch.from_numpy(_backend.get().reduce_histograms(stacked, 1.0)).to(flat.device))
+    return hist
+
+
+def reduce_counters(counters, dist=None):
+    """Sum of the u64 event / traversal counters (`EventStatisticCallback`, 12 + 8 of them) over all ranks: numpy uint64
+    array in, numpy uint64 array out. The torch.distributed counterpart of `thx_stats_allreduce`."""
+    import numpy as np
+
+    c = np.asarray(counters, dtype=np.uint64)
+    if dist is None:
+        return c
+    import torch
+
+    t = torch.from_numpy(c.astype(np.int64))  # (counts stay far below 2^63)
+    if dist.get_backend() == "nccl":
+        t = t.cuda()
+    dist.all_reduce(t, op=dist.ReduceOp.SUM)
+    return t.cpu().numpy().astype(np.uint64)
