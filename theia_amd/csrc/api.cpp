@@ -183,8 +183,17 @@ static int deviceErrorCheck(thx_tracer* t) {
     THX_HIP(hipMemsetAsync(t->devError, 0, 4, t->ctx->stream));
     THX_HIP(hipStreamSynchronize(t->ctx->stream));
     std::string msg = "device error:";
-    if (bits & THX_DEVERR_WATCHDOG) msg += " the staged kernel's scheduler watchdog tripped (results of this batch are incomplete)";
-    if (bits & ~THX_DEVERR_WATCHDOG) msg += " unknown bits " + std::to_string(bits);
+    if (bits & THX_DEVERR_WATCHDOG) {
+        msg += " the staged kernel's scheduler watchdog tripped (results of this batch are incomplete";
+        const uint32_t why = (bits >> 8) & 31u; // dev_staged.hpp: W_*
+        if (why & 1u) msg += "; a wavefront found no work for 2^20 polls while photons were still in flight";
+        if (why & 2u) msg += "; an appended ring cell never became free";
+        if (why & 4u) msg += "; a claimed ring cell never received its entry";
+        if (why & 8u) msg += "; a ring position reached 2^25";
+        if (why & 16u) msg += "; THX_TEST_ABORT";
+        msg += ")";
+    }
+    if (bits & ~(THX_DEVERR_WATCHDOG | (31u << 8))) msg += " unknown bits " + std::to_string(bits);
     return fail(THX_ERR_DEVICE, msg);
 }
 

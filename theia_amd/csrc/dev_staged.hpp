@@ -35,7 +35,10 @@ constexpr uint32_t kSchedThreads = 1024; // upper bound of the workgroup size
 // registers instead of 128. At 128 they kept 25-30 values in scratch memory, and three times in round 3 a harmless change elsewhere
 // made ONE of them misbehave (photons traced differently, a tripped watchdog, a wild address) while the production variants, which
 // never spill, and the other instrumented ones stayed exact (profiles/r03_inner_loop.txt items 10, 16, 22): no spills any more.
-constexpr uint32_t kSchedThreadsDebug = 768;
+#ifndef THX_DEBUG_THREADS
+#define THX_DEBUG_THREADS 768
+#endif
+constexpr uint32_t kSchedThreadsDebug = THX_DEBUG_THREADS;
 #ifndef THX_POOL_MAX
 #define THX_POOL_MAX 2048 // upper bound of the photon pool of a workgroup (ring entries: 11-bit slot id, bit 11 = a walk taken up again)
 #endif
@@ -61,6 +64,8 @@ enum : int { C_CURSOR = 14, C_ABORT = 15,
 THX_DEV constexpr int cHead(int q) { return 2 * q; }
 THX_DEV constexpr int cTail(int q) { return 2 * q + 1; }
 constexpr uint32_t Q_EMPTY = 0xFFFFu;  // ring cell without an entry (entries: slot < 4096 | which << 12 | lap tag << 14)
+// what the abort flag holds (which of the watchdog's checks tripped; reported in bits 8.. of the device error word)
+enum : uint32_t { W_IDLE = 1u, W_APPEND = 2u, W_CLAIM = 4u, W_RING_LIMIT = 8u, W_TEST = 16u };
 constexpr uint32_t kIdleSpinLimit = 1u << 20; // polls (~150 cycles each): ~70 ms without any work appearing -> abort
 constexpr uint32_t kCellSpinLimit = 1u << 22;
 #ifndef THX_IDLE_SLEEP
@@ -424,7 +429,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     const uint32_t begin = b64 < batch ? (uint32_t)b64 : batch;
     const uint32_t end = (b64 + per) < batch ? (uint32_t)(b64 + per) : batch;
     if (tid < C_NUM) pool.ctr[tid] = tid == (uint32_t)cTail(S_BIRTH) ? P : (tid == C_CURSOR ? begin : 0u);
-    if (tid == 0 && (args.flags & (1u << 31))) pool.ctr[C_ABORT] = 1u; // THX_TEST_ABORT: exercises the watchdog exit
+    if (tid == 0 && (args.flags & (1u << 31))) pool.ctr[C_ABORT] = W_TEST; // THX_TEST_ABORT: exercises the watchdog exit
     __syncthreads();
 
     const thx_propagate_params& prop = args.p.scene.propagation;
@@ -478,7 +483,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         const uint32_t hvx = (uint32_t)hv, hvy = (uint32_t)(hv >> 32);
         // (rings that are not a power of two long: Pool::cell is exact below 2^25 appends; the host sizes them so only for
         // launches that stay far below -- should one get there all the same, it ends like a tripped watchdog, loudly)
-        if (__ballot(qLane < 7u && hvy >= (1u << 25)) != 0ull && (pool.cap & (pool.cap - 1u)) != 0u) ldsWrite32(pool.ctrWord + C_ABORT, 1u);
+        if (__ballot(qLane < 7u && hvy >= (1u << 25)) != 0ull && (pool.cap & (pool.cap - 1u)) != 0u) ldsWrite32(pool.ctrWord + C_ABORT, W_RING_LIMIT);
 
         // ring cells of this lane's entries
         uint32_t cellA = kNoCell, cellB = kNoCell; // LDS half-word indices
@@ -557,14 +562,14 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
 #endif
         if (cellA != kNoCell) {
             for (uint32_t spin = 0; chkA != Q_EMPTY; ++spin) {
-                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); break; }
+                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, W_APPEND); break; }
                 chkA = ldsRead16(cellA);
             }
             ldsWrite16(cellA, entA);
         }
         if (cellB != kNoCell) {
             for (uint32_t spin = 0; chkB != Q_EMPTY; ++spin) {
-                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); break; }
+                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, W_APPEND); break; }
                 chkB = ldsRead16(cellB);
             }
             ldsWrite16(cellB, entB);
@@ -587,7 +592,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             if (lane == 0) atomicAdd(&profLds[11], 1ull);
 #endif
             if (++idleSpins > kIdleSpinLimit) {
-                if (lane == 0) ldsWrite32(pool.ctrWord + C_ABORT, 1u);
+                if (lane == 0) ldsWrite32(pool.ctrWord + C_ABORT, W_IDLE);
                 break;
             }
             if (best == 0u) __builtin_amdgcn_s_sleep(THX_IDLE_SLEEP);
@@ -602,7 +607,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
             // reserved but not written yet: the cell is empty (or, after a very late claimer of
             // the previous lap, still holds that lap's entry: wrong tag)
             for (uint32_t spin = 0; (entry & 0xC000u) != wantTag; ++spin) {
-                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, 1u); entry = 0; act = false; break; }
+                if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, W_CLAIM); entry = 0; act = false; break; }
                 entry = ldsRead16(claimCell);
             }
             ldsWrite16(claimCell, Q_EMPTY);
@@ -909,10 +914,11 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
     __syncthreads();
     // a tripped scheduler watchdog (a bug, never seen) poisons the light curve instead of
     // returning a plausible partial one
-    const bool aborted = pool.ctr[C_ABORT] != 0u;
+    const uint32_t abortCode = pool.ctr[C_ABORT];
+    const bool aborted = abortCode != 0u;
     // ... and raises the tracer's device error word: hit queues, tracks, statistics and reductions into
     // external buffers have no slab to poison (the host checks the word on every readback)
-    if (aborted && tid == 0 && args.error != nullptr) atomicOr(args.error, THX_DEVERR_WATCHDOG);
+    if (aborted && tid == 0 && args.error != nullptr) atomicOr(args.error, THX_DEVERR_WATCHDOG | (abortCode << 8)); // bits 8..12: which check tripped
 #ifdef THX_STAGE_PROFILE
     if (tid < 48 && args.prof) atomicAdd(&args.prof[tid], reinterpret_cast<unsigned long long*>(pool.ctr + C_PROF)[tid]);
     if (tid == 0 && args.prof) { // how evenly the workgroups finish: sum and maximum of their run times (100 MHz ticks)

@@ -1377,13 +1377,19 @@ struct Walker {
         typedef uint32_t u4 __attribute__((ext_vector_type(4)));
         *(THX_GLOBAL u4*)(a) = u4{__float_as_uint(h.t), __float_as_uint(h.b1), __float_as_uint(h.b2), h.prim};
         *(THX_GLOBAL u4*)(a + 4) = u4{h.instance | (h.valid ? 0x80000000u : 0u), cur, sp | (inBlas ? 0x10000u : 0u) | (overflow ? 0x20000u : 0u), curInst};
-        for (uint32_t e = 0; e < sp; ++e) {
-            uint32_t v;
-            if (e >= ldsN) v = spill[(e - ldsN) * 64u + (threadIdx.x & 63u)];
-            else if (s16) { v = stack16[e * 64]; v = v == 0xFFFEu ? WALK_SENTINEL : v; } // (refs are below 0xFFFE either way)
-            else v = stack32[e * 64];
-            a[8 + e] = v;
-        }
+        auto entry = [&](uint32_t e) -> uint32_t {
+            if (e >= sp) return 0u;
+            if (e >= ldsN) return spill[(e - ldsN) * 64u + (threadIdx.x & 63u)];
+            if (s16) { const uint32_t v = stack16[e * 64]; return v == 0xFFFEu ? WALK_SENTINEL : v; } // (refs are below 0xFFFE either way)
+            return stack32[e * 64];
+        };
+        // at least eight entries (zeros beyond the saved depth): start() reads the first eight back with two 16-B loads whatever the
+        // depth, and must not be handed words nobody wrote (until round 4 it was: harmless -- it never looks at entries beyond the
+        // saved depth -- but an uninitialised read all the same). One entry at a time: eight live values more cost one instrumented
+        // variant its last free registers (tests/test_capi.py::test_no_kernel_spills_vector_registers).
+        const uint32_t n = sp > 8u ? sp : 8u;
+#pragma unroll 1
+        for (uint32_t e = 0; e < n; ++e) a[8 + e] = entry(e);
     }
     // A batch of the staged kernel's walk stage holds fresh rays (what begin() does for one ray) and rays taken up again (what save() wrote). Their
     // expensive parts are the same -- the world-space slab ray, and the object-space frames of the instance a ray is

@@ -40,7 +40,10 @@ uint32_t stagedRingCap(uint32_t pool, bool exactRings);
 // global memory (bytes) of one workgroup's cold photon state (dev_staged.hpp: StagedLayout::coldBytes)
 size_t stagedColdBytes(bool polarized, uint32_t pool);
 constexpr uint32_t kStagedBlock = 1024;
-constexpr uint32_t kStagedBlockDebug = 768; // instrumented variants: 12 wavefronts, 168 registers per lane (dev_staged.hpp: kSchedThreadsDebug)
+#ifndef THX_DEBUG_THREADS
+#define THX_DEBUG_THREADS 768
+#endif
+constexpr uint32_t kStagedBlockDebug = THX_DEBUG_THREADS; // instrumented variants: 12 wavefronts, 168 registers per lane (dev_staged.hpp: kSchedThreadsDebug)
 // staged kernel: the pair records of a scene go into LDS when they are at most kLdsNodeMaxBytes and still leave a pool of
 // kLdsNodeMinPool photons (measured: profiles/r03_lds_nodes.txt)
 constexpr size_t kLdsNodeMaxBytes = 48 * 1024;
