@@ -76,8 +76,6 @@ THX_DEV float comp(f3 v, int i) { return i == 0 ? v.x : (i == 1 ? v.y : v.z); }
 // polynomials, a selection by quadrant); sincosf does that once and returns the same two values
 #ifdef THX_NATIVE_MATH
 THX_DEV void thx_sincos(float x, float& s, float& c) { s = __sinf(x); c = __cosf(x); }
-#elif defined(THX_SEPARATE_SINCOS)
-THX_DEV void thx_sincos(float x, float& s, float& c) { s = sinf(x); c = cosf(x); }
 #else
 THX_DEV void thx_sincos(float x, float& s, float& c) { sincosf(x, &s, &c); }
 #endif

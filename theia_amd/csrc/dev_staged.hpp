@@ -105,13 +105,8 @@ struct StagedLayout {
     // reads it once before it starts. 64 B of LDS per photon; what that frees holds the walk's pair records on small
     // scenes (Variant::LDSN) and a larger pool on the others (profiles/r03_lds_nodes.txt).
     static constexpr uint32_t NHOT = 3u;
-#ifdef THX_SHADOW2_LDS // the round-2 layout (A/B builds)
-    static constexpr uint32_t NCOLD = POL ? 4u : 2u;
-    static constexpr uint32_t NSC = 2u;                                 // scratch chunks per photon
-#else
     static constexpr uint32_t NCOLD = POL ? 5u : 3u;                    // the last one: direction + weight of the second shadow ray
     static constexpr uint32_t NSC = 1u;                                 // scratch chunks per photon in LDS
-#endif
     static constexpr uint32_t C_SHADOW2 = NCOLD - 1u;
     static constexpr uint32_t NCH = NHOT; // state chunks per photon in LDS
     // Ring capacity of a queue (the TS ring takes two of them): at least the pool. Round 3: the next multiple of 64 instead of
@@ -472,9 +467,6 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         const bool pushA = dstA >= 0;
         uint32_t posA = 0, posB = 0;
         if (__ballot(pushA) != 0ull) {
-#ifdef THX_EARLY_RELEASE // round 2: the release fence in front of the reservation
-            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup"); // stage data before the entries
-#endif
             if (pushA) posA = atomicAdd(&pool.ctr[cTail(dstA)], 1u);
             if (__ballot(hasB) != 0ull)
                 if (hasB) posB = atomicAdd(&pool.ctr[cTail(S_TS)], 1u);
@@ -557,9 +549,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         // ---- publish the entries of the finished stage. What the stage stored (cold chunks in global memory, hot chunks in
         // LDS) has to be visible before an entry is: the release fence waits for those stores -- here, behind the two LDS round
         // trips above, which need nothing of it (a reserved cell without its entry makes the claimer wait, not read).
-#ifndef THX_EARLY_RELEASE
         __builtin_amdgcn_fence(__ATOMIC_RELEASE, "workgroup");
-#endif
         if (cellA != kNoCell) {
             for (uint32_t spin = 0; chkA != Q_EMPTY; ++spin) {
                 if (spin > kCellSpinLimit) { ldsWrite32(pool.ctrWord + C_ABORT, W_APPEND); break; }
@@ -624,11 +614,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
         }
         __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "workgroup");
 #ifdef THX_SCHED_PRIO
-#ifdef THX_SHADE_PRIO
-        __builtin_amdgcn_s_setprio(THX_SHADE_PRIO);
-#else
         __builtin_amdgcn_s_setprio(0);
-#endif
 #endif
 #ifdef THX_STAGE_PROFILE
         const unsigned long long profT0 = __builtin_amdgcn_s_memtime();
@@ -694,11 +680,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                     dir = normalize(f3{c1.x, c1.y, c1.z});
                     tmax = pool.sc[0 * P + slot].x;
                 } else {
-#ifdef THX_SHADOW2_LDS
-                    float4 d = pool.sc[(which - 1u) * P + slot];
-#else
                     float4 d = which == 1u ? pool.sc[slot] : pool.ldCold(Lay::C_SHADOW2, slot);
-#endif
                     dir = f3{d.x, d.y, d.z};
                     weight = d.w;
                     tmax = pool.st[2 * P + slot].w;
@@ -762,9 +744,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 if ((tid & 63u) == 0u) atomicAdd(&profLds[9], __builtin_amdgcn_s_memtime() - wt1);
 #endif
             }
-#if defined(THX_WALK_PRIO) && defined(THX_SHADE_PRIO)
-            __builtin_amdgcn_s_setprio(THX_SHADE_PRIO);
-#elif defined(THX_WALK_PRIO)
+#if defined(THX_WALK_PRIO)
             __builtin_amdgcn_s_setprio(0);
 #endif
             entA = slot;
@@ -880,11 +860,7 @@ __device__ void sceneStagedBody(const LaunchArgs& args) {
                 float wTarget = pTT * pPT / (pTT * pTT + pPT * pPT);
                 float wPhase = pPP * pPP / (pPP * pPP + pTP * pTP);
                 pool.sc[0 * P + slot] = make_float4(dirPhase.x, dirPhase.y, dirPhase.z, wPhase);
-#ifdef THX_SHADOW2_LDS
-                pool.sc[1 * P + slot] = make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget);
-#else
                 pool.stCold(Lay::C_SHADOW2, slot, make_float4(ts.dir.x, ts.dir.y, ts.dir.z, wTarget));
-#endif
                 t1 = rootHit(L, ray.position, dirPhase, ps.dist);
                 t2 = rootHit(L, ray.position, ts.dir, ts.dist);
                 m.distShadow = ps.dist; // == ts.dist: both are |center - observer| + radius

@@ -231,9 +231,7 @@ THX_DEV void response(Lane<V>& L, const HitItem& item) {
     // `uint bin = int(floor(..))`: negative values wrap and fail bin < N_BINS
     if (f >= 0.0f && f < (float)L.a->n_bins) {
         [[maybe_unused]] uint32_t bin = (uint32_t)f;
-#ifndef THX_NO_HIST_ATOMIC // (attribution of LDS bank conflicts only: profiles/r02_lds_conflicts.txt)
         if (bin < L.a->n_bins) atomicAdd(&ldsHist()[bin], item.contrib);
-#endif
     }
 }
 
@@ -1057,11 +1055,7 @@ struct SlabRay {
 // reciprocal scales all plane distances of an axis by the same 1 +- 1.2e-7, which the relative slack of the interval test
 // (kSlabSlack, raised from 4e-7 to 1e-6 with this) covers whatever the distance; the ray/triangle test -- what decides a
 // hit and its coordinates -- keeps its exact divisions (woopSetup), so hits stay bitwise those of the oracle's brute force.
-#ifdef THX_SLAB_EXACT_DIV
-THX_DEV float slabInv(float d) { return fminf(fmaxf(1.0f / d, -1.0e24f), 1.0e24f); }
-#else
 THX_DEV float slabInv(float d) { return fminf(fmaxf(__builtin_amdgcn_rcpf(d), -1.0e24f), 1.0e24f); }
-#endif
 constexpr float kSlabSlack = 1.000001f;
 THX_DEV SlabRay slabRay(f3 o, f3 d) {
     SlabRay r;
@@ -1090,11 +1084,9 @@ THX_DEV float slabNode(const float4 a, const float4 b, const SlabRay& r, float t
 struct QRay {
     v2f a_xy, b_xy;
     float a_z, b_z;
-#ifndef THX_SLAB_MINMAX
     // byte selectors (v_perm_b32) that turn a box's near / far plane of an axis -- picked by the sign of the ray from the
     // axis' lo | hi << 16 word -- straight into the float 2^23 + q (see qPlane)
     uint32_t snx, sny, snz, sfx, sfy, sfz;
-#endif
 };
 // A 16-bit plane index as a float without a conversion: the bytes of q under the exponent of 2^23 ARE the float 2^23 + q
 // (one v_perm_b32 from the record's word and the constant; a v_cvt_f32_u32 with a 16-bit source selector issues no faster
@@ -1112,7 +1104,6 @@ THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origi
     r.b_xy = v2f{__builtin_fmaf(f0.x, ix, -(o.x * ix)), __builtin_fmaf(f0.y, iy, -(o.y * iy))};
     r.a_z = f1.z * iz;
     r.b_z = __builtin_fmaf(f0.z, iz, -(o.z * iz));
-#ifndef THX_SLAB_MINMAX
     r.b_xy = v2f{__builtin_fmaf(-kPlaneBase, r.a_xy.x, r.b_xy.x), __builtin_fmaf(-kPlaneBase, r.a_xy.y, r.b_xy.y)};
     r.b_z = __builtin_fmaf(-kPlaneBase, r.a_z, r.b_z);
     // v_perm_b32 D, word, magic, sel: selector bytes 4..7 = bytes of the word, 0..3 = bytes of the magic (2: 0x00, 3: 0x4B)
@@ -1120,14 +1111,12 @@ THX_DEV QRay qRay(const float4 f0, const float4 f1, f3 o, f3 d) { // f0 = {origi
     r.snx = r.a_xy.x < 0.0f ? HI : LO; r.sfx = r.a_xy.x < 0.0f ? LO : HI;
     r.sny = r.a_xy.y < 0.0f ? HI : LO; r.sfy = r.a_xy.y < 0.0f ? LO : HI;
     r.snz = r.a_z < 0.0f ? HI : LO;    r.sfz = r.a_z < 0.0f ? LO : HI;
-#endif
     return r;
 }
 THX_DEV float qPlane(uint32_t word, uint32_t sel) { return __uint_as_float(__builtin_amdgcn_perm(word, kPlaneMagic, sel)); }
 // one child of a pair record: c.x = lo.x | hi.x << 16, c.y = lo.y | hi.y << 16, c.z = lo.z | hi.z << 16
 THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     const uint32_t wx = __float_as_uint(c.x), wy = __float_as_uint(c.y), wz = __float_as_uint(c.z);
-#ifndef THX_SLAB_MINMAX
     // Near and far plane of every axis picked by the sign of the ray instead of computing both distances and taking
     // min / max: t = q a + b is monotonic in q, so the values are the same ones.
     const v2f tn_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.snx), qPlane(wy, r.sny)}, r.a_xy, r.b_xy);
@@ -1136,14 +1125,6 @@ THX_DEV float slabChild(const float4 c, const QRay& r, float tmax) {
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
     const float tf = fminf(fminf(tf_xy.x, tf_xy.y), fminf(tf_z, tmax));
     return tn <= tf * kSlabSlack ? tn : -1.0f;
-#else
-    const v2f t0 = __builtin_elementwise_fma(v2f{(float)(wx & 0xFFFFu), (float)(wy & 0xFFFFu)}, r.a_xy, r.b_xy);
-    const v2f t1 = __builtin_elementwise_fma(v2f{(float)(wx >> 16), (float)(wy >> 16)}, r.a_xy, r.b_xy);
-    const float tz0 = __builtin_fmaf((float)(wz & 0xFFFFu), r.a_z, r.b_z), tz1 = __builtin_fmaf((float)(wz >> 16), r.a_z, r.b_z);
-    float tn = fmaxf(fmaxf(fminf(t0.x, t1.x), fminf(t0.y, t1.y)), fmaxf(fminf(tz0, tz1), 0.0f));
-    float tf = fminf(fminf(fmaxf(t0.x, t1.x), fmaxf(t0.y, t1.y)), fminf(fmaxf(tz0, tz1), tmax));
-    return tn <= tf * kSlabSlack ? tn : -1.0f;
-#endif
 }
 // the same with a miss at infinity (what the 4-wide visit sorts by)
 THX_DEV float slabChildFar(const float4 c, const QRay& r, float tmax) {
@@ -1166,10 +1147,6 @@ THX_DEV float maxRaw(float a, float b) {
     return r;
 }
 THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax, float inf) {
-#ifdef THX_SLAB_MINMAX
-    const float t = slabChildFar(c, r, tmax);
-    return t < INFINITY ? t : inf;
-#else
     const uint32_t wx = __float_as_uint(c.x), wy = __float_as_uint(c.y), wz = __float_as_uint(c.z);
     const v2f tn_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.snx), qPlane(wy, r.sny)}, r.a_xy, r.b_xy);
     const v2f tf_xy = __builtin_elementwise_fma(v2f{qPlane(wx, r.sfx), qPlane(wy, r.sfy)}, r.a_xy, r.b_xy);
@@ -1177,15 +1154,10 @@ THX_DEV float slabChildInf(const float4 c, const QRay& r, float tmax, float inf)
     const float tn = fmaxf(fmaxf(tn_xy.x, tn_xy.y), fmaxf(tn_z, 0.0f));
     const float tf = fminf(fminf(tf_xy.x, tf_xy.y), minRaw(tf_z, tmax));
     return tn <= tf * kSlabSlack ? tn : inf;
-#endif
 }
 // the root box of a tree = its whole frame, q = 0 .. 65535
 THX_DEV bool slabRoot(const QRay& r, float tmax) {
-#ifndef THX_SLAB_MINMAX
     constexpr float q0 = kPlaneBase, q1 = kPlaneBase + 65535.0f;
-#else
-    constexpr float q0 = 0.0f, q1 = 65535.0f;
-#endif
     const v2f t0 = __builtin_elementwise_fma(v2f{q0, q0}, r.a_xy, r.b_xy);
     const v2f t1 = __builtin_elementwise_fma(v2f{q1, q1}, r.a_xy, r.b_xy);
     const float tz0 = __builtin_fmaf(q0, r.a_z, r.b_z), tz1 = __builtin_fmaf(q1, r.a_z, r.b_z);
@@ -1263,13 +1235,9 @@ struct Walker {
         // fetches but +45 % walk time from the extra LDS traffic and the cull loop.)
         s16 = FAST ? V::S16 : (V::S16 || L.a->stack16 != 0u);
         stack32 = ldsWords() + L.stackBase + (threadIdx.x & 63u);
-#ifdef THX_STACK16_LINEAR // the first layout: lanes 2k and 2k+1 share an LDS bank (profiles/r02_lds_conflicts.txt)
-        stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (threadIdx.x & 63u);
-#else
         // 16-bit entries: lanes l and l + 32 share a 32-bit word, so the 32 lanes the LDS serves per cycle
         // touch 32 different banks whatever their stack pointers are
         stack16 = reinterpret_cast<uint16_t*>(ldsWords() + L.stackBase) + (((threadIdx.x & 31u) << 1) | ((threadIdx.x >> 5) & 1u));
-#endif
         if constexpr (FAST) { // the sentinel slot below entry 0: "what a pop would return" can be read without asking for an empty stack
             if (V::S16) {
                 stack16 += 64;
@@ -1346,27 +1314,14 @@ struct Walker {
         const uint32_t root = instanceFrame();
         L.cnt.add(ST_NODES);
         // (A ray that misses the mesh's own box -- the instance's world-space box is looser -- takes the sentinel straight
-        // off again and leaves through the ordinary exit in the next round. Staying in world space right here
-        // (-DTHX_EXP_NEW_MISS) is equivalent and was measured no faster; compiled with the SDWA peephole of hipcc 7.2
-        // the production variant of that form traced ~1 % of the photons of the two-shell scene differently from launch to
-        // launch -- the Makefile turns the peephole off, test_production_kernel_equals_instrumented keeps watch.)
-#ifdef THX_EXP_NEW_MISS
-        if (slabRoot(sr, h.t)) {
-            inBlas = true;
-            push(WALK_SENTINEL);
-            cur = root;
-        } else {
-            sr = wsr;
-            cur = pop();
-        }
-#else
+        // off again and leaves through the ordinary exit in the next round. Staying in world space right here is equivalent
+        // and was measured no faster: profiles/r02_park.txt.)
         inBlas = true;
         push(WALK_SENTINEL);
         if (slabRoot(sr, h.t))
             cur = root;
         else
             cur = pop(); // pops the sentinel
-#endif
     }
 
     // A walk set aside between two rounds and taken up again later, by any lane of any wavefront of the workgroup
@@ -1464,33 +1419,8 @@ struct Walker {
         const uint32_t pair = cur >> 3;
         const float4 lc = nodes[2 * pair], rc = nodes[2 * pair + 1];
         L.cnt.add(ST_NODES, 2);
-#ifdef THX_EXTRA_LOADS // experiment: what do two more 16-B gathers per visit cost?
-        {
-            float4 x0 = nodes[2 * pair + 0 + THX_EXTRA_LOADS], x1 = nodes[2 * pair + 1 + THX_EXTRA_LOADS];
-            if (x0.x == 12345.678f || x1.x == 12345.678f) h.t = 0.0f;
-        }
-#endif
         float tl = slabChild(lc, sr, h.t);
         float tr = slabChild(rc, sr, h.t);
-#ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
-        {
-            float sink;
-#pragma unroll
-            for (int e = 0; e < THX_EXTRA_ISSUE; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(tl));
-        }
-#endif
-#ifdef THX_EXTRA_NOP // experiment: N x 16 cycles in which this wavefront issues nothing (latency, no issue slots)
-#pragma unroll
-        for (int e = 0; e < THX_EXTRA_NOP; ++e) asm volatile("s_nop 15");
-#endif
-#ifdef THX_EXTRA_VALU // experiment: is the walk bound by VALU issue? N dependent FMAs per visit that cannot be removed
-        {
-            float acc = tl;
-#pragma unroll
-            for (int e = 0; e < THX_EXTRA_VALU; ++e) acc = __builtin_fmaf(acc, 1.0000001f, tr);
-            if (acc == 12345.678f) h.t = 0.0f;
-        }
-#endif
         const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
         if (tl >= 0.0f && tr >= 0.0f) {
             bool leftFirst = tl <= tr;
@@ -1519,17 +1449,6 @@ struct Walker {
         const uint32_t below = V::S16 ? (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64] : stack32[(int32_t)(sp << 6) - 64];
         L.cnt.add(ST_NODES, 2);
         const float tl = slabChildInf(lc, sr, h.t, infReg), tr = slabChildInf(rc, sr, h.t, infReg);
-#ifdef THX_EXTRA_ISSUE // experiment: N independent vector instructions per visit (issue slots, no latency)
-        {
-            float sink;
-#pragma unroll
-            for (int e = 0; e < THX_EXTRA_ISSUE; ++e) asm volatile("v_mov_b32 %0, %1" : "=v"(sink) : "v"(tl));
-        }
-#endif
-#ifdef THX_EXTRA_NOP // experiment: N x 16 cycles in which this wavefront issues nothing (latency, no issue slots)
-#pragma unroll
-        for (int e = 0; e < THX_EXTRA_NOP; ++e) asm volatile("s_nop 15");
-#endif
         const uint32_t ml = __float_as_uint(lc.w), mr = __float_as_uint(rc.w);
         const bool leftFirst = tl <= tr;
         const uint32_t nearRef = leftFirst ? ml : mr, farRef = leftFirst ? mr : ml;
@@ -1551,7 +1470,6 @@ struct Walker {
         // nodes (fewer than THX_INNER_KEEP / 8 of those that started the loop) that the others should not wait any
         // longer: everybody leaves then, lanes holding a leaf process it, the rest go on in the next round
         const uint32_t innerKeep = ((uint32_t)__popcll(__ballot((cur & 7u) == 0u)) * (uint32_t)THX_INNER_KEEP) >> 3;
-#if !defined(THX_BVH4) && !defined(THX_BRANCHY_INNER)
         // Staged kernel: straight-line visits (visitStraight) while a lane's stack top is inside the LDS part. Variants with
         // the whole stack in LDS run nothing else and do not look at the stack pointer at all: the host picks them only
         // when the stack holds the hierarchy's depth + 2 entries, which a walk cannot exceed (a stack made shallower by the
@@ -1585,7 +1503,6 @@ struct Walker {
             if (cur == WALK_DONE) sp = 0; // (popping the sentinel slot took the stack pointer below zero)
             goto innerDone; // (lanes still at an inner node -- early exit -- go on in the next round)
         }
-#endif
         while ((cur & 7u) == 0u) {
 #ifdef THX_STAGE_PROFILE
             pLane += 1;
@@ -1598,36 +1515,10 @@ struct Walker {
                 }
             }
 #endif
-#ifdef THX_BVH4
-            // 4-wide record: four children (box + ref each), hit ones visited nearest first
-            const uint32_t quad = cur >> 3;
-            const float4 c0 = nodes[4 * quad], c1 = nodes[4 * quad + 1], c2 = nodes[4 * quad + 2], c3 = nodes[4 * quad + 3];
-            uint32_t r0 = __float_as_uint(c0.w), r1 = __float_as_uint(c1.w), r2 = __float_as_uint(c2.w), r3 = __float_as_uint(c3.w);
-            L.cnt.add(ST_NODES, 2u + (r2 != WALK_DONE ? 1u : 0u) + (r3 != WALK_DONE ? 1u : 0u));
-            float t0 = slabChildFar(c0, sr, h.t), t1 = slabChildFar(c1, sr, h.t);
-            float t2 = r2 != WALK_DONE ? slabChildFar(c2, sr, h.t) : INFINITY;
-            float t3 = r3 != WALK_DONE ? slabChildFar(c3, sr, h.t) : INFINITY;
-            // sorting network on (distance, ref); a miss is at infinity
-#define THX_CSWAP(ta, ra, tb, rb) { const bool sw = tb < ta; const float tt = sw ? tb : ta; tb = sw ? ta : tb; ta = tt; \
-                                    const uint32_t rr = sw ? rb : ra; rb = sw ? ra : rb; ra = rr; }
-#ifdef THX_BVH4_NEAREST_ONLY // the nearest child first, the others in storage order
-            THX_CSWAP(t0, r0, t1, r1) THX_CSWAP(t2, r2, t3, r3) THX_CSWAP(t0, r0, t2, r2)
-#else
-            THX_CSWAP(t0, r0, t1, r1) THX_CSWAP(t2, r2, t3, r3) THX_CSWAP(t0, r0, t2, r2) THX_CSWAP(t1, r1, t3, r3) THX_CSWAP(t1, r1, t2, r2)
-#endif
-#undef THX_CSWAP
-            if (t3 < INFINITY) push(r3);
-            if (t2 < INFINITY) push(r2);
-            if (t1 < INFINITY) push(r1);
-            cur = t0 < INFINITY ? r0 : pop();
-#else
             visitBranchy();
-#endif
             if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
         }
-#if !defined(THX_BVH4) && !defined(THX_BRANCHY_INNER)
     innerDone:
-#endif
 #ifdef THX_STAGE_PROFILE
         const unsigned long long pt1 = __builtin_amdgcn_s_memtime();
         pInner += pt1 - pt0;
@@ -1669,14 +1560,12 @@ struct Walker {
                 }
             }
             cur = pop();
-#ifndef THX_NO_LEAF_EXIT
             // the last leaf of an instance visit: leave the instance here instead of spending the next round on it
             if (cur == WALK_SENTINEL) {
                 inBlas = false;
                 sr = wsr;
                 cur = pop();
             }
-#endif
         }
     }
 };

@@ -8,13 +8,8 @@ namespace thx {
 
 constexpr uint32_t kTraceBlock = 256;  // threads per tracing workgroup (4 wavefronts)
 constexpr uint32_t kTreeDepth = 48;    // depth bound of the binary trees the builder makes (TLAS + deepest BLAS + 2)
-#ifdef THX_BVH4
-constexpr uint32_t kStackDepth = 2 * kTreeDepth; // a 4-wide visit pushes up to three entries per level
-constexpr uint32_t kRecordSlots = 2;             // NodePair slots per record of the walk
-#else
 constexpr uint32_t kStackDepth = kTreeDepth;     // traversal stack entries per lane
 constexpr uint32_t kRecordSlots = 1;
-#endif
 constexpr uint32_t kStackLds16 = 16;   // staged kernel: entries of them kept in LDS (16-bit / 32-bit entries), the rest in global memory;
 // staged kernel: a walk batch sets its last rays aside once fewer lanes than kParkBelow still walk (kParkBelowDeep for
 // hierarchies deeper than kParkDeepFrom, whose walks are long and spread more) after at least kParkRounds rounds
