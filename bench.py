@@ -80,6 +80,8 @@ def parse():
     ap.add_argument("--polarized", type=int, default=-1, help="override the workload's polarization (0/1)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-secondary", action="store_true", help="skip the config 3 / config 5 / big mesh / scheduler flow lines")
+    ap.add_argument("--no-flow", action="store_true", help="skip the scheduler-flow lines (their quarter-chip launches are launches of the headline's kernel: a "
+                                                          "rocprofv3 --stats average over that kernel name would mix them with the whole-chip ones)")
     ap.add_argument("--cpu-seconds", type=float, default=10.0, help="target duration of each CPU-oracle sample")
     return ap.parse_args()
 
@@ -460,8 +462,9 @@ def main() -> None:
             secondary.append(entry)
             del s
         kernel_rate = m.steps_local / (K * m.kernel_ms * 1e-3)  # photon-steps per second of the headline's kernel alone
-        for fb in (1 << 19, 1_000_000):
-            secondary.append(scheduler_flow(S, fb, 20, kernel_rate))
+        for fb, nb in ((1 << 19, 20), (1_000_000, 20), (B, 8)):
+            if not args.no_flow:
+                secondary.append(scheduler_flow(S, fb, nb, kernel_rate))
         result["secondary"] = secondary
 
     if rank == 0 and world == 1 and not args.no_cpu_baseline:

@@ -20,7 +20,7 @@ for w in ("config2", "config3", "config5", "bigmesh"):
     out[w] = {"hbm_bytes_per_launch": d["hbm_bytes_per_launch"], "FETCH_SIZE_KB": round(d["FETCH_SIZE_KB"], 1), "WRITE_SIZE_KB": round(d["WRITE_SIZE_KB"], 1), "source": note}
 json.dump(out, open(os.path.join(dst, "traffic.json"), "w"), indent=1)
 with open(os.path.join(dst, f"{rnd}_pmc_staged.txt"), "w") as fh:
-    fh.write("rocprofv3 --pmc (three passes, kernel-trace only) over `python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 [--workload W]`, MI355X,\n"
+    fh.write("rocprofv3 --pmc (five passes, kernel-trace only) over `python3 bench.py --no-cpu-baseline --no-secondary --steps 3 --warmup 1 [--workload W]`, MI355X,\n"
              f"10^7 photons per launch; per-launch means, tools/prof_pmc_quick.sh (tools/prof_round.sh {tag}). \"staged\" = production kernel, \"staged_debug\" = instrumented.\n"
              "Derived: lane utilisation = SQ_THREAD_CYCLES_VALU / (64 SQ_INSTS_VALU); vector instructions per SIMD and cycle = SQ_INSTS_VALU / (1024 SIMDs x kernel time x 2.4 GHz),\n"
              "to be held against the 1.8-2.95 cycles per instruction a SIMD needs with four wavefronts resident (profiles/r03_valu_rates.txt).\n\n")
@@ -33,20 +33,30 @@ import re
 b = json.load(open(os.path.join(src, "bench.json")))
 kernel_ms = {"config2": b["roofline"]["kernel_ms"]}
 for sec in b.get("secondary", []):
-    kernel_ms["config3" if "config 3" in sec["workload"] else "config5"] = sec["kernel_ms"]
+    for w in ("config 3", "config 5"):
+        if w in sec["workload"] and "kernel_ms" in sec:
+            kernel_ms[w.replace(" ", "")] = sec["kernel_ms"]
 issue = {}
+CLASSES = {"add_f32": "SQ_INSTS_VALU_ADD_F32", "mul_f32": "SQ_INSTS_VALU_MUL_F32", "fma_f32": "SQ_INSTS_VALU_FMA_F32", "trans_f32": "SQ_INSTS_VALU_TRANS_F32",
+           "int32": "SQ_INSTS_VALU_INT32", "int64": "SQ_INSTS_VALU_INT64", "cvt": "SQ_INSTS_VALU_CVT"}
 for w in ("config2", "config3", "config5"):
     f = os.path.join(src, f"pmc_{w}.txt")
     if not os.path.exists(f) or w not in kernel_ms:
         continue
     t = open(f).read()
     st = t[t.index("== staged\n"):]
-    g = lambda n: float(re.search(n + r"\s+n=\s*\d+ mean=([0-9.e+]+)", st).group(1))
+    def g(n, default=None):
+        m = re.search(n + r"\s+n=\s*\d+ mean=([0-9.e+]+)", st)
+        return float(m.group(1)) if m else default
     valu, thr = g("SQ_INSTS_VALU"), g("SQ_THREAD_CYCLES_VALU")
-    cycles = kernel_ms[w] * 1e-3 * 2.4e9 * 1024  # SIMD cycles of the launch at the 2.4 GHz peak clock
-    issue[w] = {"vector_instructions": valu, "scalar_instructions": g("SQ_INSTS_SALU"), "vector_memory_reads": g("SQ_INSTS_VMEM_RD"),
-                "lds_instructions": g("SQ_INSTS_LDS"), "lane_utilisation": thr / (64.0 * valu), "simd_cycles_per_vector_instruction": cycles / valu,
-                "source": f"profiles/{rnd}_pmc_staged.txt (rocprofv3 --pmc, production kernel, per launch of 10^7 photons); a SIMD with four wavefronts "
-                          "resident issues a vector instruction every 1.8-2.95 cycles depending on its encoding (profiles/r03_valu_rates.txt)"}
+    classes = {k: g(c, 0.0) for k, c in CLASSES.items()}
+    classes["f64"] = g("SQ_INSTS_VALU_ADD_F64", 0.0) + g("SQ_INSTS_VALU_MUL_F64", 0.0) + g("SQ_INSTS_VALU_FMA_F64", 0.0)
+    gui = g("GRBM_GUI_ACTIVE")
+    issue[w] = {"vector_instructions": valu, "classes": classes, "scalar_instructions": g("SQ_INSTS_SALU"), "branch_instructions": g("SQ_INSTS_BRANCH"),
+                "vector_memory_reads": g("SQ_INSTS_VMEM_RD"), "lds_instructions": g("SQ_INSTS_LDS"), "lane_utilisation": thr / (64.0 * valu),
+                "gpu_cycles_per_launch": gui, "kernel_ms_profiled": kernel_ms[w],
+                "source": f"profiles/{rnd}_pmc_staged.txt (rocprofv3 --pmc, five passes, production kernel, per launch of 10^7 photons: SQ_INSTS_VALU and its "
+                          "class counters SQ_INSTS_VALU_{ADD,MUL,FMA,TRANS}_F32 / _INT32 / _INT64 / _CVT / _*_F64, SQ_THREAD_CYCLES_VALU); issue cost per class: "
+                          "profiles/r03_valu_rates.txt (four wavefronts per SIMD)"}
 json.dump(issue, open(os.path.join(dst, "issue.json"), "w"), indent=1)
 print("bench:", round(b["value"], 1), "Mphoton-steps/s, kernel", round(b["roofline"]["kernel_ms"], 3), "ms; traffic", {k: v["hbm_bytes_per_launch"] for k, v in out.items()})
