@@ -187,3 +187,59 @@ def test_recording_tracers_stay_on_two_configs(oracle_backend):
     sched.wait()
     sched.destroy()
     assert not pl.Pipeline(S.config2_sphere(500, track=True).stages()).asynchronous
+
+
+class _CountingTask(pl.DynamicTask):
+    """asks for `extra` more batches each time all issued ones are in, `rounds` times"""
+
+    def __init__(self, stage, initial, extra, rounds):
+        super().__init__({"rec__value": 7}, "rec", initialBatchCount=initial)
+        self.stage, self.extra, self.rounds = stage, extra, rounds
+        self.seen, self.remaining_at_call, self.finished_calls = [], [], 0
+
+    def processBatch(self, config):
+        self.seen.append((config, self.stage.results[config]))
+        self.remaining_at_call.append(self.batchesRemaining)
+        if self.batchesRemaining == 0 and self.rounds > 0:
+            self.rounds -= 1
+            return self.extra
+        return 0
+
+    def onTaskFinished(self):
+        self.finished_calls += 1
+
+
+@pytest.mark.parametrize("asynchronous", [True, False])
+def test_dynamic_task_scheduler_keeps_a_tasks_batches_in_flight(asynchronous):
+    """`DynamicTaskScheduler`: the batches a task has asked for go to the device ahead of the one being processed (asynchronous
+    pipelines), `processBatch` sees them in issue order with `batchesRemaining` = asked for and not yet processed"""
+    stage = _Recorder(asynchronous, collect_delay=0.002)
+    sched = pl.DynamicTaskScheduler({"rec": pl.Pipeline([stage])}, inFlight=5)
+    assert sched.batchesInFlight == (8 if asynchronous else 1)  # at least one slot per lane
+    sched.destroy()
+    stage = _Recorder(asynchronous, collect_delay=0.002)
+    sched = pl.DynamicTaskScheduler({"rec": pl.Pipeline([stage])}, lanes=3, gridDivisor=2, inFlight=5)
+    task = _CountingTask(stage, initial=9, extra=4, rounds=2)
+    sched.scheduleTask(task)
+    sched.waitAll()
+    sched.destroy()
+    n = 9 + 4 + 4
+    assert task.isFinished and task.finished_calls == 1 and len(task.seen) == n
+    assert [c for c, _ in task.seen] == [k % 2 for k in range(n)] and all(v == 7 for _, v in task.seen)
+    assert task.remaining_at_call == list(range(8, -1, -1)) + [3, 2, 1, 0] * 2
+    ahead, submitted, collected = 0, 0, 0
+    for what, *_ in stage.log:
+        submitted += what == "submit"
+        collected += what == "collect"
+        ahead = max(ahead, submitted - collected)
+    assert ahead == (5 if asynchronous else 1)
+    assert stage.concurrency == ((1, 1) if asynchronous else None)
+    # errors of processBatch surface in waitAll
+    class Boom(pl.DynamicTask):
+        def processBatch(self, config):
+            raise RuntimeError("boom")
+    sched = pl.DynamicTaskScheduler({"rec": pl.Pipeline([_Recorder(asynchronous)])})
+    sched.scheduleTask(Boom({}, "rec", initialBatchCount=3))
+    with pytest.raises(RuntimeError, match="boom"):
+        sched.waitAll()
+    sched.destroy()

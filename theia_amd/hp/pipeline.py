@@ -518,11 +518,26 @@ class DynamicTask:
 
 
 class DynamicTaskScheduler:
-    """Runs `DynamicTask`s on one or several pipelines (background thread, configs alternate 0/1):
-    `scheduleTask(task)`, `waitAll()`, `destroy()`."""
+    """Runs `DynamicTask`s on one or several pipelines (configs alternate 0/1): `scheduleTask(task)`, `waitAll()`, `destroy()`.
+    One background thread; the batches a task has asked for are queued on the device ahead of the one being processed -- up to
+    `inFlight` of them for a pipeline made of `DeviceCommand`s (slots, lanes and the share of the chip per launch as in
+    `PipelineScheduler`), one at a time for any other -- so the device works while `processBatch` runs and the tail of one launch
+    is covered by the next. `processBatch(config)` is called in the order the batches were issued, with `result(config)` holding
+    that batch."""
 
-    def __init__(self, pipeline, *, queueSize: int = 0) -> None:
+    def __init__(self, pipeline, *, queueSize: int = 0, lanes: int | None = None, gridDivisor: int | None = None,
+                 inFlight: int | None = None) -> None:
         self._pipelines = pipeline if isinstance(pipeline, dict) else {None: pipeline}
+        lanes = _env_int("THEIA_AMD_LANES", 8) if lanes is None else int(lanes)
+        gridDivisor = _env_int("THEIA_AMD_GRID_DIVISOR", 4) if gridDivisor is None else int(gridDivisor)
+        self._lanes = max(1, min(lanes, PipelineScheduler.MAX_SLOTS))
+        self._divisor = max(1, min(gridDivisor, self._lanes))
+        self._deep = self._lanes > 1 and all(p.asynchronous for p in self._pipelines.values())
+        inFlight = _env_int("THEIA_AMD_IN_FLIGHT", PipelineScheduler.MAX_SLOTS) if inFlight is None else int(inFlight)
+        self._depth = max(self._lanes, min(inFlight, PipelineScheduler.MAX_SLOTS)) if self._deep else 1
+        if self._deep:
+            for p in self._pipelines.values():
+                p.setConcurrency(self._lanes, self._divisor)
         self._queue: Queue = Queue(queueSize)
         self._cv = threading.Condition()
         self._open = 0  # tasks scheduled and not finished
@@ -530,6 +545,8 @@ class DynamicTaskScheduler:
         self._alive = True
         self._thread = threading.Thread(target=self._worker, name="theia-task-scheduler", daemon=True)
         self._thread.start()
+
+    batchesInFlight = property(lambda self: self._depth, doc="batches of a task this scheduler keeps on the device at once")
 
     def scheduleTask(self, task: DynamicTask) -> None:
         with self._cv:
@@ -552,6 +569,12 @@ class DynamicTaskScheduler:
             self._alive = False
             self._queue.put(None)
             self._thread.join(timeout=5.0)
+            if self._deep:
+                for p in self._pipelines.values():
+                    try:
+                        p.setConcurrency(1, 1)
+                    except Exception:
+                        pass
 
     def __del__(self) -> None:
         try:
@@ -565,6 +588,8 @@ class DynamicTaskScheduler:
             task = self._queue.get()
             if task is None:
                 return
+            flying: list[tuple[int, int]] = []  # (config, slot) of the batches on the device, oldest first
+            pipe = None
             try:
                 name = task.pipeline
                 if name not in self._pipelines:
@@ -575,13 +600,21 @@ class DynamicTaskScheduler:
                 pipe = self._pipelines[name]
                 if task.parameters:
                     pipe.setParams(**task.parameters)
-                todo = task.initialBatchCount
+                todo = task.initialBatchCount  # asked for and not yet on the device
                 task._remaining = todo
-                while todo > 0:
-                    cfg = batch % 2
-                    pipe.run(cfg)
-                    batch += 1
-                    todo -= 1
+                while todo > 0 or flying:
+                    # a config's result array is written when its batch is collected, so two batches of one config may be in
+                    # flight; its parameter block is consumed by the launch itself
+                    while todo > 0 and len(flying) < self._depth:
+                        cfg = batch % 2
+                        slot = batch % self._depth if self._deep else cfg
+                        pipe.update(cfg)
+                        pipe.submit(cfg, slot)
+                        flying.append((cfg, slot))
+                        batch += 1
+                        todo -= 1
+                    cfg, slot = flying.pop(0)
+                    pipe.collect(cfg, slot)
                     task._remaining -= 1
                     more = int(task.processBatch(cfg) or 0)
                     if more > 0:
@@ -591,6 +624,11 @@ class DynamicTaskScheduler:
                 task.onTaskFinished()
             except BaseException as exc:  # surfaced by waitAll()
                 self._error = exc
+                for cfg, slot in flying:  # leave no readback behind
+                    try:
+                        pipe.collect(cfg, slot)
+                    except BaseException:
+                        pass
             finally:
                 with self._cv:
                     self._open -= 1
