@@ -263,9 +263,11 @@ typedef struct {
 typedef struct {
     uint32_t n_nodes, n_triangles, n_instances, max_depth;
     uint64_t bytes_nodes, bytes_triangles, bytes_instances, bytes_total;
-    /* bytes the traversal's OWN records move per counted unit (the counters of the instrumented kernels):
-     * per child box tested, per triangle tested, per instance entered, per hit reconstructed. (SURVEY.md 8(d)
-     * fixes contract figures of 32 / 48 / 112 / 132 B for the roofline; these are what this build fetches.) */
+    /* bytes the traversal's own LOADS REQUEST per counted unit (the counters of the instrumented kernels): per child box tested
+     * (half a 32-B pair record), per triangle tested (three 12-B vertex loads out of a 64-B record -- the cache moves the lines they
+     * touch, and the walk also requests the record behind a leaf's first triangle whether or not it belongs to the leaf, which the
+     * triangle counter does not see), per instance entered, per hit reconstructed. Requested, not moved. (SURVEY.md 8(d) fixes
+     * contract figures of 32 / 48 / 112 / 132 B for the north star's roofline; bench.py reports both.) */
     uint32_t layout_box_bytes, layout_triangle_bytes, layout_instance_bytes, layout_hit_bytes;
 } thx_scene_info;
 

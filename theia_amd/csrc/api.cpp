@@ -104,6 +104,8 @@ struct thx_tracer {
     float* slabs[THX_MAX_SLOTS] = {};
     float* out[THX_MAX_SLOTS] = {};
     float* pinned[THX_MAX_SLOTS] = {};
+    float* pinnedDev[THX_MAX_SLOTS] = {}; // the same buffers as the device addresses them (the reducer writes them directly)
+    bool mirrored[THX_MAX_SLOTS] = {};    // the slot's last reduction went into its pinned buffer as well
     hipEvent_t evFetch[THX_MAX_SLOTS] = {};
     bool fetched[THX_MAX_SLOTS] = {};
     uint32_t lastGrid[THX_MAX_SLOTS] = {};
@@ -166,8 +168,9 @@ static int ensureSlot(thx_tracer* t, uint32_t slot) {
     THX_HIP(hipMemset(t->slabs[slot], 0, slabBytes));
     THX_HIP(hipMalloc((void**)&t->out[slot], outBytes));
     THX_HIP(hipMemset(t->out[slot], 0, outBytes));
-    THX_HIP(hipHostMalloc((void**)&t->pinned[slot], outBytes + 16, hipHostMallocDefault));
+    THX_HIP(hipHostMalloc((void**)&t->pinned[slot], outBytes + 16, hipHostMallocMapped));
     std::memset(t->pinned[slot], 0, outBytes + 16);
+    THX_HIP(hipHostGetDevicePointer((void**)&t->pinnedDev[slot], t->pinned[slot], 0));
     THX_HIP(hipEventCreateWithFlags(&t->evFetch[slot], hipEventDisableTiming));
     THX_HIP(hipDeviceSynchronize());
     return THX_OK;
@@ -844,7 +847,9 @@ int thx_tracer_reduce(thx_tracer* t, uint32_t cfg, float norm, uint64_t d_out, v
     hipStream_t s = (hipStream_t)stream;
     if (!s) THX_HIP(laneStream(ctx, cfg % t->conc, &s));
     float* out = d_out ? (float*)(uintptr_t)d_out : t->out[cfg];
-    THX_HIP(launchReduce(t->slabs[cfg], out, t->desc.n_bins, t->lastGrid[cfg], norm, d_out ? nullptr : t->devError, s));
+    // into the tracer's own buffer: also into the slot's pinned host buffer, so that thx_tracer_fetch_hist needs no copy command
+    THX_HIP(launchReduce(t->slabs[cfg], out, t->desc.n_bins, t->lastGrid[cfg], norm, d_out ? nullptr : t->devError, d_out ? nullptr : t->pinnedDev[cfg], s));
+    t->mirrored[cfg] = d_out == 0;
     return THX_OK;
 }
 
@@ -867,8 +872,9 @@ int thx_tracer_fetch_hist(thx_tracer* t, uint32_t cfg, void* stream) {
     THX_HIP(hipSetDevice(ctx->device));
     hipStream_t s = (hipStream_t)stream;
     if (!s) THX_HIP(laneStream(ctx, cfg % t->conc, &s));
-    // (the reduction left the device error word behind the curve: one copy)
-    THX_HIP(hipMemcpyAsync(t->pinned[cfg], t->out[cfg], sizeof(float) * (t->desc.n_bins + 1u), hipMemcpyDeviceToHost, s));
+    // (the reduction wrote curve + device error word into the pinned buffer itself; after a reduction into an external buffer the
+    // slot's own curve is copied)
+    if (!t->mirrored[cfg]) THX_HIP(hipMemcpyAsync(t->pinned[cfg], t->out[cfg], sizeof(float) * (t->desc.n_bins + 1u), hipMemcpyDeviceToHost, s));
     THX_HIP(hipEventRecord(t->evFetch[cfg], s));
     t->fetched[cfg] = true;
     return THX_OK;
@@ -1183,7 +1189,7 @@ int thx_reduce_histograms(thx_ctx* ctx, const float* hists, uint32_t n_hist, uin
     THX_HIP(hipMalloc((void**)&d_in, nb ? nb : 16));
     hipError_t e = hipMalloc((void**)&d_out, sizeof(float) * n_bins);
     if (e == hipSuccess && nb) e = hipMemcpyAsync(d_in, hists, nb, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = launchReduce(d_in, d_out, n_bins, n_hist, norm, nullptr, ctx->stream);
+    if (e == hipSuccess) e = launchReduce(d_in, d_out, n_bins, n_hist, norm, nullptr, nullptr, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync(out, d_out, sizeof(float) * n_bins, hipMemcpyDeviceToHost, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     (void)hipFree(d_in);
@@ -1330,7 +1336,7 @@ int thx_hist_gather_reduce(thx_comm* comm, uint64_t d_hist, size_t n_floats, voi
     int rc = g_rccl.allGather((const void*)(uintptr_t)d_hist, comm->gathered, n_floats, 7, comm->nccl, s);
     if (rc != 0) return rcclFail(rc, "ncclAllGather");
     // ... summed by the slab reducer: Kahan partials per lane, fixed butterfly -- the same bits on every rank and in every run
-    THX_HIP(launchReduce(comm->gathered, (float*)(uintptr_t)d_hist, (uint32_t)n_floats, (uint32_t)comm->world, 1.0f, nullptr, s));
+    THX_HIP(launchReduce(comm->gathered, (float*)(uintptr_t)d_hist, (uint32_t)n_floats, (uint32_t)comm->world, 1.0f, nullptr, nullptr, s));
     return THX_OK;
 }
 

@@ -64,9 +64,9 @@ struct TraceVariant {
 // index = kind * 4 + pol * 2 + mis
 const TraceVariant& traceVariant(uint32_t kind, bool pol, bool mis);
 
-// `error` (may be null): device error word copied to out[n_bins]
+// `error` (may be null): device error word copied to out[n_bins]; `mirror` (may be null): second destination of curve + error word
 hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
-                        float norm, const uint32_t* error, hipStream_t stream);
+                        float norm, const uint32_t* error, float* mirror, hipStream_t stream);
 // response.replay.glsl: one response() call per item of the input queue
 hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32_t in_capacity, bool in_polarized,
                         uint32_t grid, hipStream_t stream);

@@ -48,8 +48,11 @@ static_assert(kPoolMax == THX_POOL_MAX, "pool bound");
 // (-ffp-contract=off keeps the compensation from being folded away.)
 // `error` (optional): the tracer's device error word; its value lands behind the curve, out[n_bins], so that ONE copy brings the
 // host both (thx_tracer_fetch_hist).
+// `mirror` (optional): a second destination, the tracer's pinned host buffer (mapped into the device's address space): the curve and
+// the error word land there without a copy command behind the kernel.
 __global__ void __launch_bounds__(64) reduceKernel(const float* __restrict__ slabs, float* __restrict__ out,
-                                                   uint32_t n_bins, uint32_t n_hist, float norm, const uint32_t* __restrict__ error) {
+                                                   uint32_t n_bins, uint32_t n_hist, float norm, const uint32_t* __restrict__ error,
+                                                   float* __restrict__ mirror) {
     const uint32_t bin = blockIdx.x;
     const uint32_t lane = threadIdx.x;
     float result = 0.0f, c = 0.0f;
@@ -69,14 +72,21 @@ __global__ void __launch_bounds__(64) reduceKernel(const float* __restrict__ sla
         c = (t - result) - y;
         result = t;
     }
-    if (lane == 0) out[bin] = result * norm;
-    if (error != nullptr && bin == 0 && lane == 0) out[n_bins] = __uint_as_float(*error);
+    if (lane == 0) {
+        out[bin] = result * norm;
+        if (mirror != nullptr) mirror[bin] = result * norm;
+        if (error != nullptr && bin == 0) {
+            const float e = __uint_as_float(*error);
+            out[n_bins] = e;
+            if (mirror != nullptr) mirror[n_bins] = e;
+        }
+    }
 }
 
 hipError_t launchReduce(const float* slabs, float* out, uint32_t n_bins, uint32_t n_hist,
-                        float norm, const uint32_t* error, hipStream_t stream) {
+                        float norm, const uint32_t* error, float* mirror, hipStream_t stream) {
     if (n_bins == 0) return hipSuccess;
-    hipLaunchKernelGGL(reduceKernel, dim3(n_bins), dim3(64), 0, stream, slabs, out, n_bins, n_hist, norm, error);
+    hipLaunchKernelGGL(reduceKernel, dim3(n_bins), dim3(64), 0, stream, slabs, out, n_bins, n_hist, norm, error, mirror);
     return hipGetLastError();
 }
 
