@@ -403,7 +403,7 @@ def test_parked_walks_change_nothing(hip_backend, scene, monkeypatch):
 
 @pytest.mark.parametrize("scene", ["config2", "config3", "suzanne-grid"])
 def test_walk_variants_change_nothing(hip_backend, scene, monkeypatch):
-    """The walk exists in several compiled forms the host picks by the scene (dev_trace.hpp: Variant, Walker<V, FAST>): pair
+    """The walk exists in several compiled forms the host picks by the scene (dev_trace.hpp: Variant, dev_walk.hpp: Walker<V, FAST>): pair
     records read from a copy in LDS or through the vector cache, 16- or 32-bit stack entries, the whole stack in LDS or its
     deep part in global memory (where a lane takes the branchy visit instead of the straight-line one); the scheduler's rings are
     as long as the pool or the next power of two. All of them trace the same photons through the same tree in the same order:

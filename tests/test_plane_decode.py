@@ -1,4 +1,4 @@
-"""The walk reads a child box's 16-bit plane indices as floats without a conversion (theia_amd/csrc/dev_trace.hpp: QRay,
+"""The walk reads a child box's 16-bit plane indices as floats without a conversion (theia_amd/csrc/dev_walk.hpp: QRay,
 qPlane): one v_perm_b32 puts the index under the exponent byte of 2^23, which IS the float 2^23 + q, and the ray's offset takes
 the 2^23 back out, b' = b - 2^23 a. b' is rounded at the size of 2^23 a, so the planes a ray sees lie up to half a quantisation
 step off -- inside the one whole step the builder moves every plane outwards (bvh_build.cpp: qlo / qhi; the tree's own box spans
@@ -106,7 +106,7 @@ def test_decoded_planes_and_box_test_are_conservative():
     assert coarse.mean() > 0.5
     assert (plo <= plo_box.astype(np.float64) - 0.9 * step)[coarse].all() and (phi >= phi_box.astype(np.float64) + 0.9 * step)[coarse].all()
 
-    # dev_trace.hpp: slabInv (v_rcp_f32: 1 ulp, emulated by a random last bit) and qRay
+    # dev_walk.hpp: slabInv (v_rcp_f32: 1 ulp, emulated by a random last bit) and qRay
     with np.errstate(divide="ignore"):
         inv = (F(1.0) / d).astype(F)
     wob = rng.integers(-1, 2, inv.shape)

@@ -88,7 +88,7 @@ struct thx_tracer {
     uint32_t stackLds = kStackDepth; // entries of the traversal stack kept in LDS; the rest of stackDepth spills to `spill`
     uint32_t stackSlots = kStackDepth; // staged kernel: LDS slots per lane (stackLds, + 1 for the variants with the whole stack in LDS)
     uint32_t* spill = nullptr;
-    uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_trace.hpp: Walker::save)
+    uint32_t* park = nullptr;     // staged kernel: state of walks set aside half way (dev_walk.hpp: Walker::save)
     bool stack16 = false;         // 16-bit stack entries (small scenes)
     uint32_t pool = 0;            // staged kernel: photons per workgroup pool
     bool exactRings = false;      // staged kernel: ring capacity = pool rounded up to 64 (else: to a power of two)
@@ -341,7 +341,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     if (!s) return fail(THX_ERR_INVALID, "out of host memory");
     s->ctx = ctx;
     // one record of padding behind the last triangle: the walk asks for a leaf's triangles two at a time, whether or not
-    // the second one belongs to the leaf (dev_trace.hpp: Walker::advance)
+    // the second one belongs to the leaf (dev_walk.hpp: Walker::advance)
     const size_t nTriangles = built.tris.size();
     built.tris.emplace_back();
     std::memset(&built.tris.back(), 0, sizeof(TriRecord));
@@ -394,7 +394,7 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     for (uint32_t m = 0; m < n_meshes; ++m)
         total += 24ull * meshes[m].n_vertices + 12ull * meshes[m].n_triangles;
     s->info.bytes_total = total;
-    // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_trace.hpp: Walker,
+    // what the walk and the hit reconstruction load per counted unit (thx_layout.h; dev_walk.hpp: Walker,
     // processRayQuery): half a NodePair per child box; the three 12-B vertex loads of a triangle test (its TriRecord is 64 B: every
     // vertex is stored as x y z x y and read from byte 0 / 4 / 8); a WalkInstance (80) per instance entry; per reconstructed hit the
     // triangle's three vertices (36) + NormalRecord (48) + Geometry (24) + Material (24) + the instance record (112)
@@ -519,10 +519,10 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         size_t budget = (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor - 2048; // whole CU, one workgroup
         if (const char* env = std::getenv("THX_POOL_LDS_KB")) budget = (size_t)std::max(16, std::atoi(env)) * 1024;
         // Deep hierarchies: rays use the worst-case depth rarely, so only the first kStackLds entries (THX_STACK_LDS)
-        // come out of LDS and the rest lives in global memory (dev_trace.hpp: Walker::push)
+        // come out of LDS and the rest lives in global memory (dev_walk.hpp: Walker::push)
         t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
         if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
-        // one more slot per lane below entry 0 (dev_trace.hpp: Walker<V, FAST>)
+        // one more slot per lane below entry 0 (dev_walk.hpp: Walker<V, FAST>)
         // (the variants compiled for a stack that is all in LDS do not check for a full stack: only where it cannot fill up)
         const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth && t->stackDepth >= scene->info.max_depth + 2;
         t->stackSlots = t->stackLds + 1u;

@@ -45,7 +45,7 @@ static_assert(sizeof(TreeFrame) == 32, "tree frame must be 32 B");
 // Triangle record in BVH leaf order, 64 B (half a cache line, never across two). Every vertex is stored as x y z x y:
 // the ray/triangle test wants the coordinates in the order (kx, ky, kz) with kz the ray's dominant axis -- a rotation of
 // (x, y, z) -- and reads it as three consecutive floats from byte 0, 4 or 8 of the vertex (one 12-B load) instead of
-// picking nine values with two selects each (dev_trace.hpp: woopSetup / woopTri).
+// picking nine values with two selects each (dev_walk.hpp: woopSetup / woopTri).
 struct alignas(16) TriRecord {
     float v[3][5]; // vertex k: x y z x y
     uint32_t prim; // index into the mesh's Index buffer
