@@ -283,6 +283,12 @@ int thx_ctx_destroy(thx_ctx* ctx);
 int thx_ctx_device_name(thx_ctx* ctx, char* buf, size_t n);
 int thx_ctx_device_info(thx_ctx* ctx, uint32_t* n_cus, uint32_t* lds_per_cu, uint64_t* hbm_bytes);
 int thx_ctx_sync(thx_ctx* ctx);
+/* How many of the context's lane streams (thx_tracer_set_concurrency) really run side by side, measured once and remembered: the
+ * largest L of 8, 6, 4, 3, 2 for which L idle 200-us kernels, one per lane stream, were all running at the same moment (device
+ * timestamps; ~1-3 ms), else 1. Streams that share one of the runtime's hardware queues (GPU_MAX_HW_QUEUES, default 4, read when
+ * HIP initialises) run one after the other, and more lanes than run side by side make batches queue up behind each other on a
+ * fraction of the chip -- slower than whole-chip launches. The scheduler of theia_amd.hp.pipeline asks before it sets its lanes. */
+int thx_ctx_concurrent_kernels(thx_ctx* ctx, uint32_t* out);
 
 /* ---- raw device memory (replaces hp.Tensor/hp.Buffer + hp.updateTensor for the
  * MaterialStore blob; addresses stay plain integers, material.py:1005-1018) ---- */
@@ -322,8 +328,8 @@ int thx_tracer_run(thx_tracer* tracer, uint32_t cfg, const thx_run_params* param
  * workgroups of the next batch start wherever one of an earlier batch ends. (1, 1) (default): every launch takes the
  * whole chip, all slots share the context's stream. Waits for the tracer's work in flight. lanes in [1, THX_MAX_SLOTS],
  * grid_divisor in [1, lanes]; tracers with ONE output queue or track buffer (record / store-time responses, light
- * sampler, hit replay, THX_FLAG_TRACK) accept (1, 1) only. The HIP runtime runs as many kernels side by side as it has
- * hardware queues for (GPU_MAX_HW_QUEUES, read when HIP initialises; measured on MI355X: half that number). */
+ * sampler, hit replay, THX_FLAG_TRACK) accept (1, 1) only. Lanes only run side by side while they have hardware queues of their own
+ * (GPU_MAX_HW_QUEUES, read when HIP initialises): see thx_ctx_concurrent_kernels. */
 int thx_tracer_set_concurrency(thx_tracer* tracer, uint32_t lanes, uint32_t grid_divisor);
 /* HistogramReducer.run (response.py:1188-1197; shader/estimator.reduce.glsl):
  * out[b] = norm * KahanSum_h slab[h][b]; d_out == 0 -> internal buffer of cfg */

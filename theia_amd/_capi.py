@@ -177,6 +177,7 @@ _PROTOS = {
     "thx_ctx_device_name": (c_int, [c_void_p, c_char_p, c_size_t]),
     "thx_ctx_device_info": (c_int, [c_void_p, POINTER(c_uint32), POINTER(c_uint32), POINTER(c_uint64)]),
     "thx_ctx_sync": (c_int, [c_void_p]),
+    "thx_ctx_concurrent_kernels": (c_int, [c_void_p, POINTER(c_uint32)]),
     "thx_mem_alloc": (c_int, [c_void_p, c_size_t, POINTER(c_uint64)]),
     "thx_mem_free": (c_int, [c_void_p, c_uint64]),
     "thx_mem_upload": (c_int, [c_void_p, c_uint64, c_void_p, c_size_t]),

@@ -19,6 +19,7 @@ class _Program:
         self._handle = None
         self._be = None
         self.last_batch = 0
+        self.lanes, self.grid_divisor = 1, 1  # what set_concurrency last asked the library for
 
     @property
     def created(self) -> bool:
@@ -56,6 +57,14 @@ class _Program:
         cannot cut its launches that small (the library bounds the ring positions of a workgroup): the divisor is halved
         until it fits -- such batches hide the tail of a launch by their size anyway."""
         div = int(grid_divisor or lanes)
+        # no more lanes than the runtime runs kernels side by side (half of GPU_MAX_HW_QUEUES: 8 when this package could set the
+        # variable before HIP initialised, 2 with the runtime's default) -- more would queue batches up behind each other on a
+        # fraction of the chip, slower than whole-chip launches
+        probe = getattr(self.backend, "concurrent_kernels", None)
+        if lanes > 1 and probe is not None:
+            lanes = max(1, min(int(lanes), int(probe())))
+            div = max(1, min(div, lanes))
+        self.lanes, self.grid_divisor = lanes, div
         while True:
             try:
                 return self.backend.tracer_set_concurrency(self.handle, lanes, div)

@@ -6,6 +6,7 @@
 #include <dlfcn.h>
 
 #include <algorithm>
+#include <chrono>
 #include <cmath>
 #include <cstdio>
 #include <cstdlib>
@@ -25,9 +26,10 @@ namespace {
 thread_local std::string g_error;
 
 // Batches side by side (thx_tracer_set_concurrency) need hardware queues: the HIP runtime multiplexes its streams onto
-// GPU_MAX_HW_QUEUES of them (default 4) and, measured on MI355X, runs half that many kernels at once (gpurun_out/r04/overlap*:
-// 4 queues: 2 kernels, 8: 4, 16: 8). The variable is read when HIP initialises, so it is set -- unless the user has set it --
-// when the library is loaded, which is before its first HIP call. A process that initialised HIP earlier keeps its setting.
+// GPU_MAX_HW_QUEUES of them (default 4), and streams that share a queue run one after the other (profiles/r04_batches_side_by_side.txt:
+// 20 batches of 10^6 photons take 0.31-0.32 ms each with 2 or 4 queues, 0.28 with 8, 0.26 with 16, 0.43 one at a time). The variable is
+// read when HIP initialises, so it is set -- unless the user has set it -- when the library is loaded, which is before its first HIP
+// call. A process that initialised HIP earlier keeps its setting; thx_ctx_concurrent_kernels measures what it got.
 struct HwQueues {
     HwQueues() { setenv("GPU_MAX_HW_QUEUES", "16", 0); }
 } g_hwQueues;
@@ -51,6 +53,7 @@ struct thx_ctx {
     hipStream_t stream = nullptr;          // lane 0
     hipStream_t lanes[THX_MAX_SLOTS] = {}; // lanes[0] == stream; the others are created on first use (laneStream)
     uint32_t nLanes = 1;
+    uint32_t concurrentKernels = 0; // kernels of different streams the runtime runs side by side (0: not measured yet)
     hipDeviceProp_t prop{};
     std::mutex lock; // serialises calls on this context's tracers / scenes (launch bookkeeping, event ring)
 };
@@ -274,6 +277,59 @@ int thx_ctx_sync(thx_ctx* ctx) {
     THX_HIP(hipSetDevice(ctx->device));
     for (uint32_t l = 0; l < ctx->nLanes; ++l)
         if (ctx->lanes[l]) THX_HIP(hipStreamSynchronize(ctx->lanes[l]));
+    return THX_OK;
+}
+
+int thx_ctx_concurrent_kernels(thx_ctx* ctx, uint32_t* out) {
+    if (!ctx || !out) return fail(THX_ERR_INVALID, "null argument");
+    std::lock_guard<std::mutex> guard(ctx->lock);
+    if (ctx->concurrentKernels == 0) {
+        THX_HIP(hipSetDevice(ctx->device));
+        // eight idle wavefronts of 200 us each, one per lane stream, each noting its start and end on the device's own clock:
+        // how many of them were running at the same moment?
+        constexpr uint32_t kProbe = 8;
+        constexpr unsigned long long kTicks = 20000; // x 10 ns
+        hipStream_t st[kProbe];
+        for (uint32_t l = 0; l < kProbe; ++l) THX_HIP(laneStream(ctx, l, &st[l]));
+        unsigned long long* d_when = nullptr;
+        THX_HIP(hipMalloc((void**)&d_when, sizeof(unsigned long long) * 2 * kProbe));
+        hipEvent_t ev[kProbe] = {};
+        for (uint32_t l = 0; l < kProbe; ++l) THX_HIP(hipEventCreateWithFlags(&ev[l], hipEventDisableTiming));
+        hipError_t e = hipDeviceSynchronize();
+        for (uint32_t l = 0; l < kProbe && e == hipSuccess; ++l) e = launchSpin(100, d_when + 2 * l, st[l]); // code object loaded, queues created
+        if (e == hipSuccess) e = hipDeviceSynchronize();
+        // The question the scheduler asks is "how many LANES can I use": the largest L (8, 6, 4, 3, 2) whose first L lane streams all
+        // run at the same moment -- streams that share a hardware queue run one after the other, and which streams share depends on
+        // the order in which the process created its streams.
+        uint32_t best = 1;
+        for (uint32_t lanes : {8u, 6u, 4u, 3u, 2u}) {
+            if (e != hipSuccess || best > 1) break;
+            bool all = true;
+            for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
+                // (every stream gets what a batch puts on a lane: a long kernel, a short one behind it, an event)
+                for (uint32_t l = 0; l < lanes && e == hipSuccess; ++l) {
+                    e = launchSpin(kTicks, d_when + 2 * l, st[l]);
+                    if (e == hipSuccess) e = launchSpin(1, nullptr, st[l]);
+                    if (e == hipSuccess) e = hipEventRecord(ev[l], st[l]);
+                }
+                if (e == hipSuccess) e = hipDeviceSynchronize();
+                unsigned long long when[2 * kProbe];
+                if (e == hipSuccess) e = hipMemcpy(when, d_when, sizeof(when), hipMemcpyDeviceToHost);
+                if (e != hipSuccess) break;
+                // all of them running when the last one starts?
+                unsigned long long lastStart = 0, firstEnd = ~0ull;
+                for (uint32_t l = 0; l < lanes; ++l) { lastStart = std::max(lastStart, when[2 * l]); firstEnd = std::min(firstEnd, when[2 * l + 1]); }
+                all = all && lastStart < firstEnd;
+            }
+            if (e == hipSuccess && all) best = lanes;
+        }
+        (void)hipFree(d_when);
+        for (uint32_t l = 0; l < kProbe; ++l) (void)hipEventDestroy(ev[l]);
+        if (e != hipSuccess) return hipFail(e, "thx_ctx_concurrent_kernels");
+        ctx->concurrentKernels = std::max(1u, std::min(kProbe, best));
+        if (std::getenv("THX_VERBOSE")) std::fprintf(stderr, "[thx] lane streams that run side by side: %u\n", ctx->concurrentKernels);
+    }
+    *out = ctx->concurrentKernels;
     return THX_OK;
 }
 

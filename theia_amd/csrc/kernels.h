@@ -85,6 +85,8 @@ hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint3
                          float* out_f32, hipStream_t stream);
 hipError_t launchSobolFill(uint32_t seed, uint32_t base_stream, uint32_t n_streams, uint32_t first_dim, uint32_t n_samples,
                            uint32_t sample_dim, float* out, hipStream_t stream);
+// one idle wavefront for `ticks` x 10 ns; when[0..1] = its start / end on the device's realtime counter (thx_ctx_concurrent_kernels)
+hipError_t launchSpin(unsigned long long ticks, unsigned long long* when, hipStream_t stream);
 hipError_t launchQuery(const SceneView& scene, const float* rays7, uint32_t n, float* out6,
                        hipStream_t stream);
 

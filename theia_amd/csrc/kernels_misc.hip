@@ -389,6 +389,22 @@ hipError_t launchRngFill(const thx_philox_params& p, uint32_t base_stream, uint3
     return hipGetLastError();
 }
 
+// One wavefront that does nothing for `ticks` of the 100-MHz realtime counter and notes when it started and ended: the unit of
+// thx_ctx_concurrent_kernels, which launches one on each of several streams and counts how many of them were running at once.
+__global__ void __launch_bounds__(64) spinKernel(unsigned long long ticks, unsigned long long* when) {
+    const unsigned long long t0 = __builtin_amdgcn_s_memrealtime();
+    unsigned long long t1 = t0;
+    for (unsigned int polls = 0; t1 - t0 < ticks && polls < (1u << 22); ++polls) { // (a counter that does not tick must not hang the queue)
+        __builtin_amdgcn_s_sleep(32);
+        t1 = __builtin_amdgcn_s_memrealtime();
+    }
+    if (when != nullptr && threadIdx.x == 0) { when[0] = t0; when[1] = t1; }
+}
+hipError_t launchSpin(unsigned long long ticks, unsigned long long* when, hipStream_t stream) {
+    hipLaunchKernelGGL(spinKernel, dim3(1), dim3(64), 0, stream, ticks, when);
+    return hipGetLastError();
+}
+
 // closest-hit probe for BVH parity tests
 __global__ void __launch_bounds__(kTraceBlock) queryKernel(LaunchArgs args, const float* rays7,
                                                            uint32_t n, float* out6) {
