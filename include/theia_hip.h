@@ -284,7 +284,7 @@ int thx_ctx_device_name(thx_ctx* ctx, char* buf, size_t n);
 int thx_ctx_device_info(thx_ctx* ctx, uint32_t* n_cus, uint32_t* lds_per_cu, uint64_t* hbm_bytes);
 int thx_ctx_sync(thx_ctx* ctx);
 /* How many of the context's lane streams (thx_tracer_set_concurrency) really run side by side, measured once and remembered: the
- * largest L of 8, 6, 4, 3, 2 for which L idle 200-us kernels, one per lane stream, were all running at the same moment (device
+ * largest L of 16, 12, 8, 6, 4, 3, 2 for which L idle 200-us kernels, one per lane stream, were all running at the same moment (device
  * timestamps; ~1-3 ms), else 1. Streams that share one of the runtime's hardware queues (GPU_MAX_HW_QUEUES, default 4, read when
  * HIP initialises) run one after the other, and more lanes than run side by side make batches queue up behind each other on a
  * fraction of the chip -- slower than whole-chip launches. The scheduler of theia_amd.hp.pipeline asks before it sets its lanes. */

@@ -342,7 +342,7 @@ def test_slots_lanes_and_asynchronous_readback_through_the_c_abi(hip_backend, mo
         hip_backend.tracer_run(h, capi.MAX_SLOTS, tr._assemble(0))
     # lanes the runtime really runs side by side: measured once per context; the host layer takes no more than that
     side = hip_backend.concurrent_kernels()
-    assert side in (1, 2, 3, 4, 6, 8) and hip_backend.concurrent_kernels() == side
+    assert side in (1, 2, 3, 4, 6, 8, 12, 16) and hip_backend.concurrent_kernels() == side
     prog.set_concurrency(16, 4)
     assert prog.lanes == min(16, side) and prog.grid_divisor == min(4, prog.lanes)
     # one batch per slot, all in flight before the first one is read: same photons as batch k of a serial loop

@@ -287,7 +287,7 @@ int thx_ctx_concurrent_kernels(thx_ctx* ctx, uint32_t* out) {
         THX_HIP(hipSetDevice(ctx->device));
         // eight idle wavefronts of 200 us each, one per lane stream, each noting its start and end on the device's own clock:
         // how many of them were running at the same moment?
-        constexpr uint32_t kProbe = 8;
+        constexpr uint32_t kProbe = THX_MAX_SLOTS;
         constexpr unsigned long long kTicks = 20000; // x 10 ns
         hipStream_t st[kProbe];
         for (uint32_t l = 0; l < kProbe; ++l) THX_HIP(laneStream(ctx, l, &st[l]));
@@ -298,11 +298,11 @@ int thx_ctx_concurrent_kernels(thx_ctx* ctx, uint32_t* out) {
         hipError_t e = hipDeviceSynchronize();
         for (uint32_t l = 0; l < kProbe && e == hipSuccess; ++l) e = launchSpin(100, d_when + 2 * l, st[l]); // code object loaded, queues created
         if (e == hipSuccess) e = hipDeviceSynchronize();
-        // The question the scheduler asks is "how many LANES can I use": the largest L (8, 6, 4, 3, 2) whose first L lane streams all
+        // The question the scheduler asks is "how many LANES can I use": the largest L (16, 12, 8, 6, 4, 3, 2) whose first L lane streams all
         // run at the same moment -- streams that share a hardware queue run one after the other, and which streams share depends on
         // the order in which the process created its streams.
         uint32_t best = 1;
-        for (uint32_t lanes : {8u, 6u, 4u, 3u, 2u}) {
+        for (uint32_t lanes : {16u, 12u, 8u, 6u, 4u, 3u, 2u}) {
             if (e != hipSuccess || best > 1) break;
             bool all = true;
             for (int rep = 0; rep < 2 && e == hipSuccess; ++rep) {
