@@ -277,7 +277,7 @@ def test_config3_batches_through_the_scheduler(hip_backend):
     assert np.abs(alone - curves["hip"][2]).max() <= 1e-5 * alone.sum()
 
 
-@pytest.mark.parametrize("config", ["config2", "config3"])
+@pytest.mark.parametrize("config", ["config2", "config3", "config2 at 10^7"])
 def test_batches_in_flight_equal_the_serial_scheduler(hip_backend, config):
     """The scheduler keeps 16 batches in flight on 8 lanes, each launch on a quarter of the chip
     (thx_tracer_set_concurrency): every batch's curve equals what the two-config scheduler (one lane, whole-chip
@@ -286,8 +286,9 @@ def test_batches_in_flight_equal_the_serial_scheduler(hip_backend, config):
     parameter change of task 7 lands in batch 7 and nowhere else."""
     from theia_amd.hp import pipeline as pl
 
-    make = {"config2": lambda: S.config2_sphere(batch=150_000), "config3": lambda: S.config3_cube_torus(batch=60_000, polarized=True)}[config]
-    tasks = [{}] * 7 + [{"lightSource__budget": 3.0e5 if config == "config3" else 3.0e9}] + [{}] * 12
+    make = {"config2": lambda: S.config2_sphere(batch=150_000), "config3": lambda: S.config3_cube_torus(batch=60_000, polarized=True),
+            "config2 at 10^7": lambda: S.config2_sphere(batch=10_000_000)}[config]  # (the last: BASELINE's full batch size)
+    tasks = [{}] * 7 + [{"lightSource__budget": 3.0e5 if config == "config3" else 3.0e9}] + [{}] * (12 if "10^7" not in config else 2)
     curves = {}
     for mode, kw in (("in flight", {}), ("two configs", {"lanes": 1}), ("three lanes", {"lanes": 3, "gridDivisor": 2, "inFlight": 5})):
         sc = make()
@@ -301,7 +302,7 @@ def test_batches_in_flight_equal_the_serial_scheduler(hip_backend, config):
         curves[mode] = np.array([h for _, _, h in got])
         assert sc.rng.offset == len(tasks) * sc.tracer.nRNGSamples
         # the scheduler handed the chip back: a plain run afterwards takes whole-chip launches again
-        assert hip_backend.tracer_launch_info(sc.tracer.program.handle, 10_000_000)["grid"] == 256
+        assert hip_backend.tracer_launch_info(sc.tracer.program.handle, 10_000_000)["grid"] == hip_backend.device_info()["compute_units"]
     sc = make()
     pipe = pl.Pipeline(sc.stages())
     serial = []
