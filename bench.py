@@ -291,7 +291,8 @@ def scheduler_flow(S, B: int, N: int, kernel_rate: float, reps: int = 3) -> dict
         dt = time.perf_counter() - t0
         if rep:
             best = min(best, dt)
-    lanes, div, depth = sched._lanes, sched._divisor, sched.batchesInFlight
+    prog = sc.tracer.program  # (what the library was asked for: the scheduler's lanes, clamped to what the runtime runs side by side)
+    lanes, div, depth = prog.lanes, prog.grid_divisor, sched.batchesInFlight
     sched.destroy()
     if len(curves) != N or not all(np.isfinite(c).all() and c.sum() > 0 for c in curves):
         raise RuntimeError("scheduler flow: invalid light curves")
