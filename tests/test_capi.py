@@ -154,3 +154,48 @@ def test_no_kernel_spills_vector_registers(tmp_path):
     assert not found, "\n".join(found[:3])
 
 
+
+
+def test_exec_restore_checker_sees_the_pattern():
+    """tools/exec_restore_check.py on a hand-written disassembly: the miscompilation of DESIGN.md section 4 -- a spill store at the top of
+    a join block, in front of the instruction that gives the region's lanes back -- is flagged; the same block with the store behind
+    the restore, a run-time-indexed stack array in front of it (legitimate: the lanes of the branch update their own counters) and a
+    spill in straight-line code are not."""
+    import sys
+
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    import exec_restore_check as X
+
+    def listing(block_top: str) -> str:
+        return f"""
+0000000000001000 <kernel>:
+\ts_and_saveexec_b64 s[18:19], vcc                          // 000000001000: BE92206A
+\ts_cbranch_execz 6                                          // 000000001004: BF880006 <kernel+0x20>
+\tv_add_u32_e32 v4, 1, v4                                    // 000000001008: 68080881
+\tscratch_store_dword off, v9, off offset:8                  // 00000000100C: DC708008 007F0900
+\tv_mov_b32_e32 v5, v4                                       // 000000001014: 7E0A0304
+\ts_nop 0                                                    // 000000001018: BF800000
+\ts_nop 0                                                    // 00000000101C: BF800000
+{block_top}
+\ts_endpgm                                                   // 000000001030: BF810000
+"""
+    bad = listing("\tscratch_store_dword off, v67, off offset:160              // 000000001020: DC7080A0 007F4300\n"
+                  "\ts_or_b64 exec, exec, s[18:19]                             // 000000001028: 87FE127E")
+    good = listing("\ts_or_b64 exec, exec, s[18:19]                             // 000000001020: 87FE127E\n"
+                   "\tscratch_store_dword off, v67, off offset:160              // 000000001024: DC7080A0 007F4300")
+    indexed = listing("\tscratch_store_dword v4, v11, off                          // 000000001020: DC708000 007F0B04\n"
+                      "\ts_or_b64 exec, exec, s[18:19]                             // 000000001028: 87FE127E")
+    found = X.check_text(bad)
+    assert len(found) == 1 and "0x1020" in found[0] and "kernel" in found[0]
+    assert X.check_text(good) == [] and X.check_text(indexed) == []
+
+
+def test_the_package_asks_for_hardware_queues():
+    """batches side by side need hardware queues: importing the package sets GPU_MAX_HW_QUEUES unless the user has (it is read when HIP
+    initialises, so it has to be in place before that)"""
+    import importlib
+
+    import theia_amd
+
+    importlib.reload(theia_amd)
+    assert int(os.environ["GPU_MAX_HW_QUEUES"]) >= 4

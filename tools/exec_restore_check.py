@@ -79,7 +79,11 @@ def _writes_exec(op: str, args: str) -> bool:
 
 def check(elf: str) -> list[str]:
     """violations found in one code object, as readable excerpts"""
-    text = subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf]).decode()
+    return check_text(subprocess.check_output([os.path.join(LLVM, "llvm-objdump"), "-d", "--no-show-raw-insn", elf]).decode())
+
+
+def check_text(text: str) -> list[str]:
+    """... in the text of `llvm-objdump -d --no-show-raw-insn`"""
     findings = []
     kernel, base, insns = None, 0, []  # insns: (address, op, args)
 
