@@ -296,6 +296,12 @@ int thx_mem_alloc(thx_ctx* ctx, size_t nbytes, uint64_t* dev_addr);
 int thx_mem_free(thx_ctx* ctx, uint64_t dev_addr);
 int thx_mem_upload(thx_ctx* ctx, uint64_t dev_addr, const void* src, size_t nbytes);
 int thx_mem_download(thx_ctx* ctx, void* dst, uint64_t dev_addr, size_t nbytes);
+/* Page-locks a host buffer of the caller's (the two host buffers of an IOQueue, hephaistos' mapped hp.Buffer): copies between it and the
+ * device then run on the DMA engines, beside a kernel that occupies every CU -- a copy to pageable memory is done by a copy KERNEL,
+ * which gets no CU while the staged tracing kernel runs (measured: 157 MB of hits per batch read 60 % slower overlapped than one after
+ * the other). Registering twice / unregistering what is not registered is not an error. Unregister before freeing the memory. */
+int thx_host_register(thx_ctx* ctx, void* ptr, size_t nbytes);
+int thx_host_unregister(thx_ctx* ctx, void* ptr);
 
 /* ---- scene (replaces hp.GeometryStore + hp.AccelerationStructure + the
  * Geometries tensor, scene.py:550, 637-668): builds BLAS/TLAS (own BVH2) ---- */
@@ -369,7 +375,11 @@ int thx_tracer_read_stage_profile(thx_tracer* tracer, uint64_t* out48);
 size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized);
 size_t thx_time_queue_bytes(uint32_t hit_capacity, uint32_t store_object_id); /* THX_RESPONSE_STORE_TIME queue */
 int thx_tracer_read_hits(thx_tracer* tracer, void* out, size_t nbytes, int clear);
-int thx_tracer_hits_device_ptr(thx_tracer* tracer, uint64_t* dev_addr);
+/* The tracing kinds keep one hit queue per pipeline config (slots 0 / 1; IOQueue's two tensors, response.py:219): _read_hits_cfg waits
+ * for the last launch of config `cfg` only and copies ITS queue on a stream of its own, so that the batch of the other config runs while
+ * this one is read (thx_tracer_read_hits waits for the device and reads the queue of the most recent launch). */
+int thx_tracer_read_hits_cfg(thx_tracer* tracer, uint32_t cfg, void* out, size_t nbytes, int clear);
+int thx_tracer_hits_device_ptr(thx_tracer* tracer, uint64_t* dev_addr); /* (the queue of config 0) */
 /* HostLightSource / HostWavelengthSource input (replace hephaistos IOQueue(mode="update",
  * skipCounter=True) of light.py:120, 735): copy a host queue without counter -- columns of
  * light_queue_capacity floats posX posY posZ dirX dirY dirZ [stokesI Q U V polX polY polZ]

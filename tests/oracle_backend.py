@@ -34,7 +34,9 @@ class _Tracer:
         self.fetched = {}
         self.stats = np.zeros(orc.N_STATS, np.uint64)
         self.track = None
-        self.hits = None  # HitRecorder queue: uint32 count + columns
+        self.hits = None  # HitRecorder queue of the batch being traced: uint32 count + columns
+        self.hit_queues = {}  # ... by pipeline config (the tracing kinds keep one per config)
+        self.last_cfg = 0
 
 
 class OracleBackend:
@@ -134,9 +136,12 @@ class OracleBackend:
         kind = getattr(spec, "response_kind", 0)
         record = kind in (capi.RESPONSE_RECORD, capi.RESPONSE_STORE_TIME)
         if record:
-            if t.hits is None:
+            key = cfg & 1 if spec.kind in (capi.TRACER_VOLUME_FORWARD, capi.TRACER_SCENE_FORWARD) else 0
+            if key not in t.hit_queues:
                 ncol = (2 if spec.hit_polarized else 1) if kind == capi.RESPONSE_STORE_TIME else (20 if spec.hit_polarized else 13)
-                t.hits = np.zeros(1 + ncol * spec.hit_capacity, dtype=np.uint32)
+                t.hit_queues[key] = np.zeros(1 + ncol * spec.hit_capacity, dtype=np.uint32)
+            t.hits = t.hit_queues[key]
+            t.last_cfg = key
             if kind == capi.RESPONSE_STORE_TIME:
                 orc.set_time_queue(t.hits, spec.hit_capacity, spec.hit_polarized)
             else:
@@ -253,13 +258,14 @@ class OracleBackend:
             hist, stats, track = orc.trace_scene(c, tp, guide, t.scene, threads=self.threads, track=want_track)
         return hist, stats, track
 
-    def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True) -> None:
+    def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True, cfg=None) -> None:
         t = self._tracers[tracer]
-        raw = t.hits.view(np.uint8)
+        queue = t.hit_queues.get(t.last_cfg if cfg is None else cfg & 1, t.hits)
+        raw = queue.view(np.uint8)
         n = min(out.nbytes, raw.nbytes)
         out.reshape(-1).view(np.uint8)[:n] = raw[:n]
         if clear:
-            t.hits[0] = 0
+            queue[0] = 0
 
     def tracer_reduce(self, tracer: int, cfg: int, norm: float, d_out: int = 0, stream: int = 0) -> None:
         t = self._tracers[tracer]

@@ -321,6 +321,49 @@ def test_batches_in_flight_equal_the_serial_scheduler(hip_backend, config):
     assert np.abs(serial[0] - serial[1]).max() > 100 * np.abs(curves["in flight"][0] - serial[0]).max()
 
 
+@pytest.mark.parametrize("kind", ["scene", "volume-photon"])
+def test_recorded_hits_through_the_scheduler(hip_backend, kind):
+    """Recording tracers keep one hit queue per pipeline config: the scheduler runs the batch of one config while the queue of the
+    other is read (thx_tracer_read_hits_cfg). Every batch's hits are exactly those of a serial loop over the same tasks -- the same
+    photons, in whatever order the kernel appended them."""
+    import theia.response
+    import theia.trace
+    from theia_amd.hp import pipeline as pl
+
+    def build():
+        rec = theia.response.HitRecorder()
+        if kind == "scene":
+            sc = S.config2_sphere(batch=120_000, response=rec)
+            return rec, sc, sc.tracer
+        base = S.config1_volume(batch=1000)
+        tracer = theia.trace.VolumePhotonTracer(200_000, base.light, base.target, base.wavelength, rec, base.rng, medium=base.store.media["homogenous"],
+                                                nRuns=2, nScatteringPerRun=5)
+        base.rng.autoAdvance = tracer.nRNGSamples
+        return rec, base, tracer
+
+    def table(view):
+        n = view.count
+        t = np.column_stack([np.asarray(view[k][:n], dtype=np.float64).reshape(n, -1) for k in ("time", "contrib", "position", "direction")])
+        return t[np.lexsort(t.T[::-1])]
+
+    rec, keep, tracer = build()
+    pipe = pl.Pipeline(tracer.collectStages())
+    assert pipe.asynchronous and pipe.maxInFlight == 2
+    got = []
+    sched = pl.PipelineScheduler(pipe, processFn=lambda c, b, a: got.append(table(rec.queue.view(c))))
+    assert sched.batchesInFlight == 2
+    sched.schedule([{}] * 6)
+    sched.wait()
+    sched.destroy()
+    rec2, keep2, tracer2 = build()
+    pipe2 = pl.Pipeline(tracer2.collectStages())
+    for k in range(6):
+        pipe2.run(k % 2)
+        want = table(rec2.queue.view(k % 2))
+        assert len(want) > 1000 and got[k].shape == want.shape and np.array_equal(got[k], want), (k, got[k].shape, want.shape)
+    assert got[0].shape != got[1].shape or not np.array_equal(got[0], got[1])
+
+
 def test_slots_lanes_and_asynchronous_readback_through_the_c_abi(hip_backend, monkeypatch):
     """thx_tracer_set_concurrency / _fetch_hist / _collect_hist: argument checks, a batch per slot, the watchdog through
     the asynchronous readback"""

@@ -174,19 +174,36 @@ def test_pipelined_equals_serial_on_the_real_stages(oracle_backend):
     assert curves["deep"][5].sum() > 2 * curves["deep"][0].sum()
 
 
-def test_recording_tracers_stay_on_two_configs(oracle_backend):
-    """a hit queue / track buffer exists once per tracer: such pipelines are not asynchronous"""
+def test_recording_tracers_run_two_batches_one_queue_per_config(oracle_backend):
+    """a hit queue exists once per pipeline config: a recording tracer's pipeline keeps exactly two batches in flight (one runs
+    while the other's queue is read), on whole-chip launches; a track buffer exists once per tracer: one batch at a time. The hits
+    of every batch are those of a serial loop."""
     from theia_amd.response import HitRecorder
 
-    sc = S.config2_sphere(500, response=HitRecorder())
+    def hits_of(view):
+        n = view.count
+        return np.column_stack([np.asarray(view["time"][:n]), np.asarray(view["contrib"][:n])])
+
+    rec = HitRecorder()
+    sc = S.config2_sphere(700, response=rec)
     pipe = pl.Pipeline(sc.stages())
-    assert not pipe.asynchronous
-    sched = pl.PipelineScheduler(pipe)
+    assert pipe.asynchronous and pipe.maxInFlight == 2
+    got = []
+    sched = pl.PipelineScheduler(pipe, processFn=lambda c, b, a: got.append(hits_of(rec.queue.view(c))))
     assert sched.batchesInFlight == 2
-    sched.schedule([{}] * 3)
+    sched.schedule([{}] * 5)
     sched.wait()
     sched.destroy()
-    assert not pl.Pipeline(S.config2_sphere(500, track=True).stages()).asynchronous
+    rec2 = HitRecorder()
+    sc2 = S.config2_sphere(700, response=rec2)
+    pipe2 = pl.Pipeline(sc2.stages())
+    for k in range(5):
+        pipe2.run(k % 2)
+        want = hits_of(rec2.queue.view(k % 2))
+        assert len(want) > 50 and np.array_equal(np.sort(got[k], axis=0), np.sort(want, axis=0)), k
+    assert not np.array_equal(np.sort(got[0], axis=0), np.sort(got[1], axis=0))  # different photons per batch
+    tracked = pl.Pipeline(S.config2_sphere(500, track=True).stages())
+    assert tracked.maxInFlight == 1
 
 
 class _CountingTask(pl.DynamicTask):

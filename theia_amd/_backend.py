@@ -91,6 +91,13 @@ class HipBackend:
         capi.check(self._lib.thx_mem_download(self._ctx, out.ctypes.data_as(C.c_void_p), int(addr), int(nbytes)))
         return out.tobytes()
 
+    def host_register(self, array: np.ndarray) -> None:
+        """page-locks a host array (device copies to / from it then run on the DMA engines, beside any kernel); idempotent"""
+        capi.check(self._lib.thx_host_register(self._ctx, array.ctypes.data_as(C.c_void_p), array.nbytes))
+
+    def host_unregister(self, array: np.ndarray) -> None:
+        capi.check(self._lib.thx_host_unregister(self._ctx, array.ctypes.data_as(C.c_void_p)))
+
     # -- scene -------------------------------------------------------------
     def scene_create(self, meshes, instances) -> int:
         """meshes: [(vertices (N,6) f32, faces (M,3) u32)], instances:
@@ -242,9 +249,13 @@ class HipBackend:
         capi.check(self._lib.thx_tracer_read_track(C.c_void_p(tracer), out.ctypes.data_as(C.POINTER(C.c_float)), out.size))
         return out
 
-    def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True) -> None:
-        """copies the HitRecorder queue into `out` (uint8) and resets its counter"""
-        capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
+    def tracer_read_hits(self, tracer: int, out: np.ndarray, clear: bool = True, cfg: int | None = None) -> None:
+        """copies the HitRecorder queue into `out` (uint8) and resets its counter; `cfg`: the queue of that pipeline config, waiting
+        for its last launch only (thx_tracer_read_hits_cfg) -- else the queue of the most recent launch, after everything"""
+        if cfg is None:
+            capi.check(self._lib.thx_tracer_read_hits(C.c_void_p(tracer), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
+        else:
+            capi.check(self._lib.thx_tracer_read_hits_cfg(C.c_void_p(tracer), int(cfg), out.ctypes.data_as(C.c_void_p), out.nbytes, int(clear)))
 
     def rng_fill_sobol(self, seed: int, base_stream: int, n_streams: int, first_dim: int, n_samples: int, sample_dim: int = 1) -> np.ndarray:
         """RNGBufferSink over a SobolQRNG: float32 [streams][samples] (or [...][2] for 2-D samples)"""

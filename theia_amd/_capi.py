@@ -182,6 +182,8 @@ _PROTOS = {
     "thx_mem_free": (c_int, [c_void_p, c_uint64]),
     "thx_mem_upload": (c_int, [c_void_p, c_uint64, c_void_p, c_size_t]),
     "thx_mem_download": (c_int, [c_void_p, c_void_p, c_uint64, c_size_t]),
+    "thx_host_register": (c_int, [c_void_p, c_void_p, c_size_t]),
+    "thx_host_unregister": (c_int, [c_void_p, c_void_p]),
     "thx_scene_create": (c_int, [c_void_p, POINTER(MeshDesc), c_uint32, POINTER(InstanceDesc), c_uint32, POINTER(c_void_p)]),
     "thx_scene_destroy": (c_int, [c_void_p]),
     "thx_scene_get_info": (c_int, [c_void_p, POINTER(SceneInfo)]),
@@ -206,6 +208,7 @@ _PROTOS = {
     "thx_hit_queue_bytes": (c_size_t, [c_uint32, c_uint32]),
     "thx_time_queue_bytes": (c_size_t, [c_uint32, c_uint32]),
     "thx_tracer_read_hits": (c_int, [c_void_p, c_void_p, c_size_t, c_int]),
+    "thx_tracer_read_hits_cfg": (c_int, [c_void_p, c_uint32, c_void_p, c_size_t, c_int]),
     "thx_tracer_hits_device_ptr": (c_int, [c_void_p, POINTER(c_uint64)]),
     "thx_tracer_write_hits": (c_int, [c_void_p, c_void_p, c_size_t]),
     "thx_tracer_write_light": (c_int, [c_void_p, c_uint32, c_void_p, c_size_t]),

@@ -41,6 +41,22 @@ class _Program:
                 and not spec.flags & capi.FLAG_TRACK)
 
     @property
+    def queue_per_config(self) -> bool:
+        """a tracing program with a record / store-time response has one hit queue per pipeline config: the batch of one config runs
+        while the other config's queue is read"""
+        spec = self._spec
+        return (spec.kind in (capi.TRACER_VOLUME_FORWARD, capi.TRACER_SCENE_FORWARD)
+                and spec.response_kind in (capi.RESPONSE_RECORD, capi.RESPONSE_STORE_TIME))
+
+    @property
+    def max_in_flight(self) -> int:
+        """batches of this program that can be on the device at once: one result slot each (histogram), one queue per config (hit
+        queues), one (a track buffer, the samplers)"""
+        if self.concurrent:
+            return capi.MAX_SLOTS
+        return 2 if self.queue_per_config and not self._spec.flags & capi.FLAG_TRACK else 1
+
+    @property
     def backend(self):
         self.handle
         return self._be
@@ -85,8 +101,8 @@ class _Program:
     def hist_ptr(self, cfg: int) -> int:
         return self.backend.tracer_hist_ptr(self.handle, cfg)
 
-    def read_hits(self, out: np.ndarray, clear: bool = True) -> None:
-        self.backend.tracer_read_hits(self.handle, out, clear)
+    def read_hits(self, out: np.ndarray, clear: bool = True, cfg: int | None = None) -> None:
+        self.backend.tracer_read_hits(self.handle, out, clear, cfg if self.queue_per_config else None)
 
     def write_hits(self, data: np.ndarray) -> None:
         self.backend.tracer_write_hits(self.handle, data)

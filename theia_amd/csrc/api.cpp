@@ -52,6 +52,7 @@ struct thx_ctx {
     int device = 0;
     hipStream_t stream = nullptr;          // lane 0
     hipStream_t lanes[THX_MAX_SLOTS] = {}; // lanes[0] == stream; the others are created on first use (laneStream)
+    hipStream_t copyStream = nullptr; // readback of one config's hit queue while the other config's batch runs (thx_tracer_read_hits_cfg)
     uint32_t nLanes = 1;
     uint32_t concurrentKernels = 0; // kernels of different streams the runtime runs side by side (0: not measured yet)
     hipDeviceProp_t prop{};
@@ -122,7 +123,11 @@ struct thx_tracer {
     uint32_t* devError = nullptr; // device error word (THX_DEVERR_* bits), set by the kernels' exit paths
     unsigned long long* prof = nullptr;
     float* track = nullptr;
-    uint32_t* hits = nullptr;     // HitRecorder queue (count + SoA columns) or null
+    uint32_t* hits = nullptr;     // HitRecorder queue (count + SoA columns) or null; of pipeline config 0 for the tracing kinds
+    uint32_t* hits1 = nullptr;    // ... of pipeline config 1 (tracing kinds with a record / store-time response: a batch of one config
+                                  // runs while the other config's queue is read, thx_tracer_read_hits_cfg)
+    hipEvent_t evHits[2] = {};    // behind the last launch of either config
+    uint32_t lastHitCfg = 0;      // config of the most recent launch (what thx_tracer_read_hits reads)
     uint32_t* replayIn = nullptr; // THX_TRACER_HIT_REPLAY: the input hit queue
     uint32_t* lamOut = nullptr;   // THX_TRACER_LIGHT_SAMPLER: wavelength output queue (light output: `hits`)
     float* lightIn[2] = {nullptr, nullptr}; // HostLightSource queue per pipeline config
@@ -254,6 +259,7 @@ int thx_ctx_destroy(thx_ctx* ctx) {
     (void)hipDeviceSynchronize();
     for (uint32_t l = 0; l < THX_MAX_SLOTS; ++l)
         if (ctx->lanes[l]) (void)hipStreamDestroy(ctx->lanes[l]);
+    if (ctx->copyStream) (void)hipStreamDestroy(ctx->copyStream);
     delete ctx;
     return THX_OK;
 }
@@ -347,6 +353,24 @@ int thx_mem_free(thx_ctx* ctx, uint64_t dev_addr) {
     if (dev_addr == 0) return THX_OK;
     THX_HIP(hipSetDevice(ctx->device));
     THX_HIP(hipFree((void*)(uintptr_t)dev_addr));
+    return THX_OK;
+}
+
+int thx_host_register(thx_ctx* ctx, void* ptr, size_t nbytes) {
+    if (!ctx || !ptr || nbytes == 0) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostRegister(ptr, nbytes, hipHostRegisterDefault);
+    if (e == hipErrorHostMemoryAlreadyRegistered) { (void)hipGetLastError(); return THX_OK; }
+    if (e != hipSuccess) return hipFail(e, "hipHostRegister");
+    return THX_OK;
+}
+
+int thx_host_unregister(thx_ctx* ctx, void* ptr) {
+    if (!ctx || !ptr) return fail(THX_ERR_INVALID, "null argument");
+    THX_HIP(hipSetDevice(ctx->device));
+    hipError_t e = hipHostUnregister(ptr);
+    if (e == hipErrorHostMemoryNotRegistered) { (void)hipGetLastError(); return THX_OK; }
+    if (e != hipSuccess) return hipFail(e, "hipHostUnregister");
     return THX_OK;
 }
 
@@ -673,6 +697,11 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         const size_t nb = 4 + hitColumns(*desc) * 4 * (size_t)desc->hit_capacity;
         e = hipMalloc((void**)&t->hits, nb);
         if (e == hipSuccess) e = hipMemset(t->hits, 0, nb);
+        if (e == hipSuccess && !replay) { // one queue per pipeline config
+            e = hipMalloc((void**)&t->hits1, nb);
+            if (e == hipSuccess) e = hipMemset(t->hits1, 0, nb);
+            for (int i = 0; i < 2 && e == hipSuccess; ++i) e = hipEventCreateWithFlags(&t->evHits[i], hipEventDisableTiming);
+        }
     }
     if (e == hipSuccess && sampler) {
         const size_t nb = 4 + hitColumns(*desc) * 4 * (size_t)desc->capacity, nl = 4 + 2 * 4 * (size_t)desc->capacity;
@@ -728,6 +757,9 @@ int thx_tracer_destroy(thx_tracer* t) {
     if (t->devError) (void)hipFree(t->devError);
     if (t->track) (void)hipFree(t->track);
     if (t->hits) (void)hipFree(t->hits);
+    if (t->hits1) (void)hipFree(t->hits1);
+    for (int i = 0; i < 2; ++i)
+        if (t->evHits[i]) (void)hipEventDestroy(t->evHits[i]);
     if (t->replayIn) (void)hipFree(t->replayIn);
     if (t->lamOut) (void)hipFree(t->lamOut);
     for (int i = 0; i < 2; ++i) {
@@ -854,7 +886,8 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.stats = t->stats;
     a.error = t->devError;
     a.prof = t->prof;
-    a.hits = t->hits;
+    if (t->hits1 && cfg > 1) return fail(THX_ERR_INVALID, "tracers with a hit queue run in slots 0 and 1 only (one queue per pipeline config)");
+    a.hits = (t->hits1 && cfg == 1) ? t->hits1 : t->hits;
     a.hit_capacity = t->desc.hit_capacity;
     a.hit_polarized = t->desc.hit_polarized;
     a.hit_kind = t->desc.response_kind;
@@ -886,6 +919,10 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
         THX_HIP(launchReplay(a, t->replayIn, t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) != 0, grid, s));
     else
         THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
+    if (t->hits1) {
+        THX_HIP(hipEventRecord(t->evHits[cfg], s));
+        t->lastHitCfg = cfg;
+    }
     if (timed) {
         THX_HIP(hipEventRecord(t->evStop[slot], s));
         t->lastSlot[cfg] = (int)slot;
@@ -1018,6 +1055,27 @@ size_t thx_hit_queue_bytes(uint32_t hit_capacity, uint32_t hit_polarized) {
     return 4 + columns * 4 * (size_t)hit_capacity;
 }
 
+// the counter first, then of every column only the entries that were appended (a queue is sized for the worst case,
+// maxHitsPerThread * batch: reading it whole would move ~10x more); `s`: the stream the copies run on (its earlier work is done)
+static int copyHitQueue(thx_tracer* t, uint32_t* queue, void* out, size_t nbytes, int clear, hipStream_t s) {
+    const size_t cap = t->desc.hit_capacity, columns = hitColumns(t->desc);
+    if (nbytes < 4) return fail(THX_ERR_INVALID, "output buffer too small");
+    uint32_t count = 0;
+    THX_HIP(hipMemcpyAsync(&count, queue, 4, hipMemcpyDeviceToHost, s));
+    THX_HIP(hipStreamSynchronize(s));
+    std::memcpy(out, &count, 4);
+    const size_t n = std::min<size_t>(count, cap);
+    for (size_t c = 0; c < columns && n > 0; ++c) {
+        const size_t off = 4 + c * cap * 4;
+        if (off >= nbytes) break;
+        const size_t bytes = std::min(n * 4, nbytes - off);
+        THX_HIP(hipMemcpyAsync((char*)out + off, (const char*)queue + off, bytes, hipMemcpyDeviceToHost, s));
+    }
+    if (clear) THX_HIP(hipMemsetAsync(queue, 0, 4, s)); // (completed before returning: the next launch into this queue must not race it)
+    THX_HIP(hipStreamSynchronize(s));
+    return THX_OK;
+}
+
 int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
     if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
     std::lock_guard<std::mutex> guard(t->ctx->lock);
@@ -1025,29 +1083,34 @@ int thx_tracer_read_hits(thx_tracer* t, void* out, size_t nbytes, int clear) {
     THX_HIP(hipSetDevice(t->ctx->device));
     THX_HIP(hipDeviceSynchronize());
     if (int rc = deviceErrorCheck(t)) return rc;
-    // the counter first, then of every column only the entries that were appended (a queue is
-    // sized for the worst case, maxHitsPerThread * batch: reading it whole would move ~10x more)
-    const size_t cap = t->desc.hit_capacity, columns = hitColumns(t->desc);
-    if (nbytes < 4) return fail(THX_ERR_INVALID, "output buffer too small");
-    uint32_t count = 0;
-    THX_HIP(hipMemcpy(&count, t->hits, 4, hipMemcpyDeviceToHost));
-    std::memcpy(out, &count, 4);
-    const size_t n = std::min<size_t>(count, cap);
-    for (size_t c = 0; c < columns && n > 0; ++c) {
-        const size_t off = 4 + c * cap * 4;
-        if (off >= nbytes) break;
-        const size_t bytes = std::min(n * 4, nbytes - off);
-        THX_HIP(hipMemcpyAsync((char*)out + off, (const char*)t->hits + off, bytes, hipMemcpyDeviceToHost, t->ctx->stream));
+    return copyHitQueue(t, (t->hits1 && t->lastHitCfg == 1) ? t->hits1 : t->hits, out, nbytes, clear, t->ctx->stream);
+}
+
+int thx_tracer_read_hits_cfg(thx_tracer* t, uint32_t cfg, void* out, size_t nbytes, int clear) {
+    if (!t || !out) return fail(THX_ERR_INVALID, "null argument");
+    hipEvent_t ev = nullptr;
+    {
+        std::lock_guard<std::mutex> guard(t->ctx->lock);
+        if (!t->hits1) return fail(THX_ERR_INVALID, "tracer has no hit queue per pipeline config (record / store-time response of a tracing kind)");
+        if (cfg > 1) return fail(THX_ERR_INVALID, "config index must be 0 or 1");
+        ev = t->evHits[cfg];
+        if (!t->ctx->copyStream) {
+            THX_HIP(hipSetDevice(t->ctx->device));
+            THX_HIP(hipStreamCreateWithFlags(&t->ctx->copyStream, hipStreamNonBlocking));
+        }
     }
-    THX_HIP(hipStreamSynchronize(t->ctx->stream));
-    if (clear) {
-        // on the context's stream and completed before returning: a memset on the null stream
-        // is not ordered with the next launch on the (non-blocking) stream and would wipe the
-        // counter in the middle of the next batch
-        THX_HIP(hipMemsetAsync(t->hits, 0, 4, t->ctx->stream));
-        THX_HIP(hipStreamSynchronize(t->ctx->stream));
+    // waits for THIS config's launch only -- outside the context's lock: the other config's batch is launched and runs meanwhile
+    THX_HIP(hipSetDevice(t->ctx->device));
+    THX_HIP(hipEventSynchronize(ev));
+    std::lock_guard<std::mutex> guard(t->ctx->lock);
+    uint32_t bits = 0; // (the error word as of now: an error of the batch still running is reported by that batch's read)
+    THX_HIP(hipMemcpyAsync(&bits, t->devError, 4, hipMemcpyDeviceToHost, t->ctx->copyStream));
+    THX_HIP(hipStreamSynchronize(t->ctx->copyStream));
+    if (bits != 0) {
+        THX_HIP(hipDeviceSynchronize());
+        return deviceErrorCheck(t) == THX_OK ? fail(THX_ERR_DEVICE, "device error (already reported)") : THX_ERR_DEVICE;
     }
-    return THX_OK;
+    return copyHitQueue(t, cfg == 1 ? t->hits1 : t->hits, out, nbytes, clear, t->ctx->copyStream);
 }
 
 static int writeQueue(thx_tracer* t, float* dst, size_t have, const void* src, size_t nbytes, const char* what) {

@@ -18,8 +18,10 @@ scheduler does (docs/pipeline/pipeline.md:74-92).
 """
 from __future__ import annotations
 
+import atexit
 import ctypes
 import threading
+import weakref
 from ctypes import Array, Structure
 from queue import Queue
 from typing import Any, Callable, Iterable
@@ -28,6 +30,19 @@ __all__ = ["Command", "DeviceCommand", "PipelineStage", "SourceCodeMixin", "Pipe
            "DynamicTaskScheduler"]
 
 Command = Callable[[], None]
+
+# schedulers whose threads still run: stopped before the interpreter shuts down, so that no thread of ours is inside a device
+# call (or about to make one) while the HIP runtime and the interpreter are being taken apart
+_liveSchedulers: "weakref.WeakSet" = weakref.WeakSet()
+
+
+@atexit.register
+def _stopSchedulers() -> None:
+    for s in list(_liveSchedulers):
+        try:
+            s.destroy()
+        except Exception:
+            pass
 
 
 class DeviceCommand:
@@ -247,6 +262,12 @@ class Pipeline:
         ahead of the one being processed, each in a slot of its own"""
         return all(isinstance(c, DeviceCommand) for cmds in self._commands for c in cmds)
 
+    @property
+    def maxInFlight(self) -> int:
+        """batches of this pipeline that can be on the device at once: the smallest limit any stage states (`maxInFlight`: a tracer with a
+        hit queue has one queue per config), 16 if none does"""
+        return min([int(getattr(st, "maxInFlight")) for _, st in self._stages if getattr(st, "maxInFlight", None) is not None] + [16])
+
     def setConcurrency(self, lanes: int, gridDivisor: int | None = None) -> None:
         """tells the stages that launch kernels how many batches will be in flight (`Tracer.setConcurrency`)"""
         for _, st in self._stages:
@@ -321,11 +342,15 @@ class PipelineScheduler:
         self._lanes = max(1, min(lanes, self.MAX_SLOTS))
         self._divisor = max(1, min(gridDivisor, self._lanes))
         deep = self._lanes > 1 and all(p.asynchronous for p in self._pipelines.values())
+        limit = min([p.maxInFlight for p in self._pipelines.values()] + [self.MAX_SLOTS])  # (hit queues: one per config, i.e. 2)
+        if deep and limit < self._lanes:
+            self._lanes = self._divisor = 1  # whole-chip launches, two batches in flight: one runs while the other's queue is read
         # (more slots than lanes: the submit thread then never waits for processFn of the batch whose slot it needs next)
         inFlight = _env_int("THEIA_AMD_IN_FLIGHT", self.MAX_SLOTS) if inFlight is None else int(inFlight)
-        self._depth = max(self._lanes, min(inFlight, self.MAX_SLOTS)) if deep else 2
+        self._depth = min(limit, max(self._lanes, min(inFlight, self.MAX_SLOTS))) if deep else 2
         self._deep = deep
-        if deep:
+        self._sliced = deep and self._lanes > 1
+        if self._sliced:
             for p in self._pipelines.values():
                 p.setConcurrency(self._lanes, self._divisor)
         self._tasks: Queue = Queue(queueSize)   # schedule() -> update thread
@@ -338,6 +363,7 @@ class PipelineScheduler:
         self._finished = 0    # tasks done with, processed or dropped after an error (what wait() counts)
         self._error: BaseException | None = None
         self._alive = True
+        _liveSchedulers.add(self)
         self._threads = [threading.Thread(target=fn, name=f"theia-scheduler-{name}", daemon=True)
                          for name, fn in (("update", self._updateLoop), ("submit", self._submitLoop), ("process", self._processLoop))]
         for t in self._threads:
@@ -367,7 +393,7 @@ class PipelineScheduler:
             self._tasks.put(None)
             for t in self._threads:
                 t.join(timeout=5.0)
-            if self._deep:
+            if self._sliced:
                 for p in self._pipelines.values():
                     try:
                         p.setConcurrency(1, 1)
@@ -533,9 +559,13 @@ class DynamicTaskScheduler:
         self._lanes = max(1, min(lanes, PipelineScheduler.MAX_SLOTS))
         self._divisor = max(1, min(gridDivisor, self._lanes))
         self._deep = self._lanes > 1 and all(p.asynchronous for p in self._pipelines.values())
+        limit = min([p.maxInFlight for p in self._pipelines.values()] + [PipelineScheduler.MAX_SLOTS])
+        if self._deep and limit < self._lanes:
+            self._lanes = self._divisor = 1  # (hit queues: one per config -- whole-chip launches, two batches in flight)
         inFlight = _env_int("THEIA_AMD_IN_FLIGHT", PipelineScheduler.MAX_SLOTS) if inFlight is None else int(inFlight)
-        self._depth = max(self._lanes, min(inFlight, PipelineScheduler.MAX_SLOTS)) if self._deep else 1
-        if self._deep:
+        self._depth = min(limit, max(self._lanes, min(inFlight, PipelineScheduler.MAX_SLOTS))) if self._deep else 1
+        self._sliced = self._deep and self._lanes > 1
+        if self._sliced:
             for p in self._pipelines.values():
                 p.setConcurrency(self._lanes, self._divisor)
         self._queue: Queue = Queue(queueSize)
@@ -543,6 +573,7 @@ class DynamicTaskScheduler:
         self._open = 0  # tasks scheduled and not finished
         self._error: BaseException | None = None
         self._alive = True
+        _liveSchedulers.add(self)
         self._thread = threading.Thread(target=self._worker, name="theia-task-scheduler", daemon=True)
         self._thread.start()
 
@@ -569,7 +600,7 @@ class DynamicTaskScheduler:
             self._alive = False
             self._queue.put(None)
             self._thread.join(timeout=5.0)
-            if self._deep:
+            if self._sliced:
                 for p in self._pipelines.values():
                     try:
                         p.setConcurrency(1, 1)

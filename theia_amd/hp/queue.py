@@ -14,6 +14,8 @@ the tracer / replay the stage is bound to.
 from __future__ import annotations
 
 import ctypes
+import mmap
+import sys
 from ctypes import Structure
 
 import numpy as np
@@ -145,6 +147,13 @@ def dumpQueue(view: QueueView) -> dict[str, np.ndarray]:
     return {name: np.array(view[name][:n]) for name in view.fields}
 
 
+def _hostBuffer(nbytes: int) -> np.ndarray:
+    """zeroed host bytes in an anonymous mapping of their own (whole pages, page aligned): what `IOQueue.pin` page-locks is then
+    exactly this memory -- page-locking marks pages as not inherited by a forked child, which must not happen to pages of the
+    allocator's heap that a small numpy array shares with everything else. Unmapped when the last view onto it goes away."""
+    return np.frombuffer(mmap.mmap(-1, max(int(nbytes), 1)), dtype=np.uint8, count=int(nbytes))
+
+
 class IOQueue:
     """Host side of a queue that is filled on the device and retrieved after each batch."""
 
@@ -186,12 +195,31 @@ class IOQueue:
         if capacity <= 0:
             raise ValueError("capacity must be positive")
         self._capacity = int(capacity)
-        self._buffers = [np.zeros(self.nbytes, dtype=np.uint8) for _ in range(2)]
+        self._buffers = [_hostBuffer(self.nbytes) for _ in range(2)]
         if self._mode == "update" and not self._skipCounter:
             # a queue the user fills starts out full: the reference's tests write all `capacity`
             # items and never touch the counter (tests/test_response.py:24-37)
             for b in self._buffers:
                 b[:4].view(np.uint32)[0] = self._capacity
+
+    def pin(self, backend) -> None:
+        """page-locks the two host buffers once (`thx_host_register`): the copies of a retrieve / update then run on the DMA engines;
+        a backend without page-locking (the CPU stand-in of the tests) is skipped. Unpinned again when the queue goes away."""
+        reg = getattr(backend, "host_register", None)
+        if reg is None or self._buffers is None or getattr(self, "_pinned", None) is not None:
+            return
+        for b in self._buffers:
+            reg(b)
+        self._pinned = backend
+
+    def __del__(self) -> None:
+        backend = getattr(self, "_pinned", None)
+        if backend is not None and self._buffers is not None and not sys.is_finalizing():
+            for b in self._buffers:
+                try:
+                    backend.host_unregister(b)
+                except Exception:
+                    pass
 
     def buffer(self, i: int) -> np.ndarray:
         if self._buffers is None:

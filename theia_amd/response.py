@@ -130,12 +130,15 @@ class HitRecorder(HitResponse):
         self._program = program
 
     def run(self, i):
-        def retrieve() -> None:
+        # the tracer keeps one queue per pipeline config: this config's is read (and reset) once ITS batch is through, while the
+        # other config's batch runs. (A program with one queue only -- a hit replay -- is read behind everything.)
+        def retrieve(slot: int = i) -> None:
             if self._program is None:
                 raise RuntimeError("HitRecorder is not bound to a tracer")
-            self._program.read_hits(self._queue.buffer(i), clear=True)
+            self._queue.pin(self._program.backend)
+            self._program.read_hits(self._queue.buffer(i), clear=True, cfg=i)
 
-        return [retrieve]
+        return [DeviceCommand(i, lambda slot: None, retrieve)]
 
 
 class ValueResponse(SourceCodeMixin):
@@ -229,12 +232,13 @@ class StoreTimeHitResponse(HitResponse):
             self._response.update(i)
 
     def run(self, i):
-        def retrieve() -> None:
+        def retrieve(slot: int = i) -> None:
             if self._program is None:
                 raise RuntimeError("StoreTimeHitResponse is not bound to a tracer")
-            self._program.read_hits(self._queue.buffer(i), clear=True)
+            self._queue.pin(self._program.backend)
+            self._program.read_hits(self._queue.buffer(i), clear=True, cfg=i)
 
-        return [retrieve] if self._retrieve else []
+        return [DeviceCommand(i, lambda slot: None, retrieve)] if self._retrieve else []
 
 
 class HistogramHitResponse(HitResponse):

@@ -255,9 +255,12 @@ class Tracer(PipelineStage):
         # A launch only queues the kernel (its parameter block is copied into the kernel arguments). Sources fed from host
         # queues upload into the device queue of config i, and a track recorder / hit queue has ONE buffer on the device:
         # those batches cannot be told apart in flight, their launch stays a plain (serialising) command.
-        if isinstance(self._source, HostLightSource) or isinstance(self._wavelengthSource, HostWavelengthSource) or not self._program.concurrent:
+        # With a hit queue the program keeps one queue per config: two batches, no more.
+        if isinstance(self._source, HostLightSource) or isinstance(self._wavelengthSource, HostWavelengthSource) or self._program.max_in_flight < 2:
             return [launch]
         return [DeviceCommand(i, launch)]
+
+    maxInFlight = property(lambda self: self._program.max_in_flight, doc="batches of this tracer a scheduler may keep on the device at once")
 
     def setConcurrency(self, lanes: int, gridDivisor: int | None = None) -> None:
         """`lanes` batches of this tracer in flight at once, each launch on 1 / gridDivisor of the chip
