@@ -56,19 +56,62 @@ typedef struct {
     uint32_t offset[4];
 } thx_philox_params;
 
-/* SphericalLightSource: src/theia/light.py:1132-1139; shader/lightsource.spherical.glsl:7-14.
+/* The Cherenkov family of light sources (THX_FLAG_LIGHT_KIND_* below; forward mode: the `sampleLight(wavelength, medium, idx, dim)`
+ * of each shader). Their parameter blocks are the reference's uniform blocks, field by field: */
+/* CherenkovLightSource: src/theia/light.py:1219-1228; shader/lightsource.cherenkov.simple.glsl:8-18 */
+typedef struct {
+    float trackStart[3];
+    float startTime;
+    float trackEnd[3];
+    float endTime;
+    float trackDir[3]; /* unit, end - start (light.py:1262-1268 _finishParams) */
+    float trackDist;
+} thx_cherenkov_params;
+/* CherenkovTrackLightSource: light.py:1376-1377; shader/lightsource.cherenkov.track.glsl:9-21. `track` = device address (lo, hi)
+ * of a ParticleTrack: uint32 trackLength (number of SEGMENTS), then trackLength + 1 vertices {x, y, z, t} (light.py:1285-1297) */
+typedef struct {
+    uint32_t track[2];
+} thx_cherenkov_track_params;
+/* MuonTrackLightSource: light.py:1456-1465; shader/lightsource.particles.muon.glsl:13-27 */
+typedef struct {
+    float startPosition[3];
+    float startTime;
+    float endPosition[3];
+    float endTime;
+    float energyScale;
+    float a_angular, b_angular;
+} thx_muon_track_params;
+/* ParticleCascadeLightSource: light.py:1591-1601; shader/lightsource.particles.cascade.glsl:14-39 */
+typedef struct {
+    float startPosition[3];
+    float startTime;
+    float direction[3];
+    float effectiveLength;
+    float a_angular, b_angular;
+    float a_long, b_long;
+} thx_cascade_params;
+
+/* One block for whichever light source the tracer was created with.
+ * SphericalLightSource: src/theia/light.py:1132-1139; shader/lightsource.spherical.glsl:7-14.
  * PencilLightSource (THX_FLAG_LIGHT_PENCIL): light.py:1065-1073; shader/lightsource.pencil.glsl:4-16
  * -- contribFwd carries its budget, direction / stokes / polRef are read by it and the cone only.
- * ConeLightSource (THX_FLAG_LIGHT_CONE): light.py:935-945; shader/lightsource.cone.glsl:6-20 */
-typedef struct {
-    float position[3];
-    float contribFwd;
-    float contribBwd;
-    float t_min, t_max;
-    float direction[3];
-    float stokes[4];
-    float polRef[3];
-    float cosOpeningAngle;
+ * ConeLightSource (THX_FLAG_LIGHT_CONE): light.py:935-945; shader/lightsource.cone.glsl:6-20.
+ * Cherenkov family: the member named after the source. */
+typedef union {
+    struct {
+        float position[3];
+        float contribFwd;
+        float contribBwd;
+        float t_min, t_max;
+        float direction[3];
+        float stokes[4];
+        float polRef[3];
+        float cosOpeningAngle;
+    };
+    thx_cherenkov_params cherenkov;
+    thx_cherenkov_track_params cherenkovTrack;
+    thx_muon_track_params muonTrack;
+    thx_cascade_params cascade;
 } thx_light_params;
 
 /* src/theia/light.py:272-273 (const) / :308-312 (uniform) / :393-394 (function) */
@@ -200,6 +243,19 @@ enum {
     THX_FLAG_TARGET_MISS_INFINITE  = 1u << 25, /* DiskTarget / FlatTarget: report a missed outline (or a plane behind the ray) as infinitely
                                                 far. Default (flag clear) = the reference: target.disk.glsl:60 / target.flat.glsl:66 return the
                                                 distance to the plane regardless, and tracer.volume.forward.glsl:167 stops the ray there */
+    /* bits 26-28: light sources of the Cherenkov family (0: none of them -- the LIGHT_* bits above decide) */
+    THX_FLAG_LIGHT_KIND_SHIFT      = 26,
+    THX_FLAG_LIGHT_KIND_MASK       = 7u << 26,
+    THX_FLAG_LIGHT_CHERENKOV       = 1u << 26, /* CherenkovLightSource (lightsource.cherenkov.simple.glsl) */
+    THX_FLAG_LIGHT_CHERENKOV_TRACK = 2u << 26, /* CherenkovTrackLightSource (lightsource.cherenkov.track.glsl) */
+    THX_FLAG_LIGHT_MUON_TRACK      = 3u << 26, /* MuonTrackLightSource (lightsource.particles.muon.glsl) */
+    THX_FLAG_LIGHT_CASCADE         = 4u << 26, /* ParticleCascadeLightSource (lightsource.particles.cascade.glsl) */
+    THX_FLAG_FRANK_TAMM_PHOTONS    = 1u << 29, /* FRANK_TAMM_USE_PHOTON_COUNT of the two Cherenkov sources: radiance in photons, else eV */
+    THX_FLAG_FRANK_TAMM_IS         = 1u << 30, /* FRANK_TAMM_IS of the muon track / cascade sources: the Frank-Tamm factor is NOT applied
+                                                  (the wavelength source is taken to have importance sampled it) */
+    THX_FLAG_SOURCES_PRESAMPLED    = 1u << 7,  /* set by the library, never by the caller: a tracer with a Cherenkov-family source reads
+                                                  light and wavelength samples (and the RNG dimension behind them) from queues its
+                                                  sampler kernel filled right before the launch */
     THX_FLAG_PHOTON                = 1u << 12, /* ScenePhotonTracer (trace.py:2370-2665): contribution = survival chance,
                                                   absorption roulette after every step, RNG dimension restarted per run */
     THX_FLAG_TARGET_INNER          = 1u << 11  /* volume tracer: InnerSphereTarget (target.py:142-199), else SphereTarget;
@@ -444,7 +500,12 @@ int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flag
  *   SIGN_BIT       in x                                 out +-1 */
 enum { THX_UNIT_LOOKUP = 0, THX_UNIT_LOOKUP_MEDIUM, THX_UNIT_SCATTER_DIR, THX_UNIT_FRESNEL, THX_UNIT_SCATTER_PROB,
        THX_UNIT_SCATTER_SAMPLE, THX_UNIT_ROTATE_POLREF, THX_UNIT_ALIGN_POLREF, THX_UNIT_PHASE_MATRIX, THX_UNIT_POLARIZER,
-       THX_UNIT_SIGN_BIT, THX_UNIT_COUNT };
+       THX_UNIT_SIGN_BIT,
+       /* the Cherenkov family (tests/test_light.py:725-836 drive the first two through their own test shaders):
+        * (n, a, b, u) -> cos_theta;  (n, a, b, u, cos_min, cos_max) -> (cos_theta, contrib);  (n, a, b, cos_theta) -> pdf;
+        * (n, lambda) -> Frank-Tamm in eV, in photons (both per azimuth), in photons over all azimuths */
+       THX_UNIT_EMISSION_ANGLE, THX_UNIT_EMISSION_ANGLE_RANGE, THX_UNIT_EMISSION_PDF, THX_UNIT_FRANK_TAMM,
+       THX_UNIT_COUNT };
 int thx_probe_unit(thx_ctx* ctx, uint32_t which, uint64_t addr, const float* in, uint32_t n_in, uint32_t n, float* out, uint32_t n_out);
 
 /* RNGBufferSink over a SobolQRNG (random.sink.glsl with random.sobol.glsl): out[stream][sample] =

@@ -156,6 +156,8 @@ def lib() -> C.CDLL:
         L.orc_phase_matrix_apply.restype = None
         L.orc_sign_bit.argtypes = [C.c_float]
         L.orc_sign_bit.restype = C.c_float
+        L.orc_cherenkov_units.argtypes = [C.c_uint32, fp, C.c_uint32, fp]
+        L.orc_cherenkov_units.restype = None
         _LIB = L
     return _LIB
 

@@ -893,10 +893,185 @@ static SourceRay polarizedSourceRay(Ctx* x, vec3 position, vec3 direction, vec4 
     return r;
 }
 
+/* ---- the Cherenkov family of light sources ---- */
+static float f_sign(float v);
+#define INV_SPEED_OF_LIGHT_F 3.335640951981521f /* material.glsl:7 */
+
+/* lightsource.cherenkov.common.glsl:6-46: radiance per track length and wavelength, in eV or in photons (d/dphi form) */
+static float frankTammCherenkov(float n, float lambda, int photons) {
+    lambda *= 1e-3f; /* nm -> um */
+    float result = photons ? 7.2973525693f / (lambda * lambda) * (1.0f - (1.0f / (n * n)))
+                           : 9.04756408986352f / (lambda * lambda * lambda) * (1.0f - (1.0f / (n * n)));
+    return fmaxf(result, 0.0f);
+}
+/* lightsource.particles.common.glsl:53-62: photons per track length and wavelength, all azimuths */
+static float frankTammParticle(float lambda, float n) {
+    lambda *= 1e-3f;
+    float sin2_theta = 1.0f - 1.0f / (n * n);
+    float result = TWO_PI_F * 7.2973525693f / (lambda * lambda) * sin2_theta;
+    return fmaxf(result, 0.0f);
+}
+/* lightsource.particles.common.glsl:69-97 */
+static float particleSampleEmissionAngle(float n, float a, float b, float u) {
+    float cos_chev = 1.0f / n;
+    float int_lower = 1.0f - expf(-b * powf(1.0f - cos_chev, a));
+    float int_upper = 1.0f - expf(-b * powf(1.0f + cos_chev, a));
+    u = u * (int_upper + int_lower) - int_lower;
+    float xx = powf(-logf(1.0f - fabsf(u)) / b, 1.0f / a);
+    return cos_chev - f_sign(u) * xx;
+}
+/* lightsource.particles.common.glsl:103-136: the same profile on [cos_min, cos_max], with the weight f / p */
+static float particleSampleEmissionAngleRange(float n, float a, float b, float u, float cos_min, float cos_max, float* contrib) {
+    float cos_chev = 1.0f / n;
+    float int_upper = 1.0f - expf(-b * powf(fabsf(cos_max - cos_chev), a));
+    float int_lower = 1.0f - expf(-b * powf(fabsf(cos_min - cos_chev), a));
+    int_upper *= f_sign(cos_max - cos_chev);
+    int_lower *= f_sign(cos_min - cos_chev);
+    *contrib = fabsf(int_upper - int_lower);
+    *contrib /= 2.0f - expf(-b * powf(1.0f - cos_chev, a)) - expf(-b * powf(1.0f + cos_chev, a));
+    u = u * (int_upper - int_lower) + int_lower;
+    float xx = -powf(-logf(1.0f - fabsf(u)) / b, 1.0f / a);
+    return cos_chev - f_sign(u) * xx;
+}
+/* lightsource.particles.common.glsl:138-154 */
+static float particleEvalEmissionAngle(float n, float a, float b, float cos_theta) {
+    float cos_chev = 1.0f / n;
+    float norm = a * b;
+    norm /= 2.0f - expf(-b * powf(1.0f - cos_chev, a)) - expf(-b * powf(1.0f + cos_chev, a));
+    float xx = fabsf(cos_theta - cos_chev);
+    return expf(-b * powf(xx, a)) * powf(xx, a - 1.0f) * norm;
+}
+/* random.gamma.glsl:8-31: Cheng's GA rejection sampler; alpha < 1 through alpha + 1 */
+static float sampleGamma(Ctx* x, float alpha, uint32_t idx, uint32_t* dim) {
+    float scale = 1.0f;
+    if (alpha < 1.0f) {
+        scale = powf(rnd(x, idx, dim), 1.0f / alpha);
+        alpha += 1.0f;
+    }
+    float a = sqrtf(2.0f * alpha - 1.0f);
+    float b = alpha - logf(4.0f);
+    float c = alpha + 1.0f / alpha;
+    for (;;) {
+        float u0, u1;
+        rnd2(x, idx, dim, &u0, &u1);
+        float V = a * logf(u0 / (1.0f - u0));
+        float X = alpha * expf(V);
+        if (b + c * V - X >= logf(u0 * u0 * u1)) return scale * X;
+        if (!(u0 == u0)) return scale * X; /* (a NaN draw cannot happen; no endless loop if it ever did) */
+    }
+}
+/* a Cherenkov photon: on the cone of half angle acos(1 / n) around the particle's direction, linearly polarized in the plane of the
+ * two directions (lightsource.cherenkov.simple.glsl:37-57, lightsource.cherenkov.track.glsl:48-77) */
+static SourceRay cherenkovRay(Ctx* x, vec3 pos, vec3 particleDir, float n, float phiDraw, float time, float contrib) {
+    float cos_theta = 1.0f / n;
+    float sin_theta = sqrtf(fmaxf(1.0f - cos_theta * cos_theta, 0.0f));
+    float phi = TWO_PI_F * phiDraw;
+    vec3 localDir = V3(sin_theta * cosf(phi), sin_theta * sinf(phi), cos_theta);
+    vec3 rayDir = m3_mul(createLocalCOSY(particleDir), localDir);
+    vec3 polRef = v_normalize(v_cross(rayDir, particleDir));
+    vec4 stokes; stokes.x = 1.0f; stokes.y = 1.0f; stokes.z = 0.0f; stokes.w = 0.0f;
+    return polarizedSourceRay(x, pos, rayDir, stokes, polRef, time, contrib);
+}
+static vec3 v_mix(vec3 a, vec3 b, float t) { return V3(f_mix(a.x, b.x, t), f_mix(a.y, b.y, t), f_mix(a.z, b.z, t)); }
+
+/* forward sampleLight of lightsource.cherenkov.simple.glsl:20-58, lightsource.cherenkov.track.glsl:23-78,
+ * lightsource.particles.muon.glsl:29-60, lightsource.particles.cascade.glsl:41-69 */
+static SourceRay sampleCherenkovFamily(Ctx* x, float wavelength, const MediumConstants* medium, uint32_t idx, uint32_t* dim) {
+    const orc_common* c = x->c;
+    const int photons = (c->flags & ORC_FLAG_FRANK_TAMM_PHOTONS) != 0;
+    const int applyFrankTamm = (c->flags & ORC_FLAG_FRANK_TAMM_IS) == 0;
+    switch (c->flags & ORC_FLAG_LIGHT_KIND_MASK) {
+    case ORC_FLAG_LIGHT_CHERENKOV: {
+        const orc_cherenkov_params* p = &c->light.cherenkov;
+        float u = rnd(x, idx, dim);
+        vec3 position = v_mix(V3(p->trackStart[0], p->trackStart[1], p->trackStart[2]), V3(p->trackEnd[0], p->trackEnd[1], p->trackEnd[2]), u);
+        float startTime = f_mix(p->startTime, p->endTime, u);
+        float contrib = TWO_PI_F * frankTammCherenkov(medium->n, wavelength, photons) * p->trackDist;
+        float v = rnd(x, idx, dim);
+        return cherenkovRay(x, position, V3(p->trackDir[0], p->trackDir[1], p->trackDir[2]), medium->n, v, startTime, contrib);
+    }
+    case ORC_FLAG_LIGHT_CHERENKOV_TRACK: {
+        const uint32_t* track = (const uint32_t*)(uintptr_t)((uint64_t)c->light.cherenkovTrack.track[0] | ((uint64_t)c->light.cherenkovTrack.track[1] << 32));
+        const uint32_t trackLength = track[0];
+        const float* vertices = (const float*)(track + 1);
+        float u = rnd(x, idx, dim);
+        u *= (float)trackLength;
+        uint32_t vertexIdx = (uint32_t)floorf(u);
+        if (vertexIdx > trackLength - 1u) vertexIdx = trackLength - 1u;
+        u = u - floorf(u); /* fract */
+        const float* s = vertices + 4 * vertexIdx;
+        const float* e = s + 4;
+        vec3 sp = V3(s[0], s[1], s[2]), ep = V3(e[0], e[1], e[2]);
+        vec3 pos = v_mix(sp, ep, u);
+        float time = f_mix(s[3], e[3], u);
+        float v = rnd(x, idx, dim);
+        vec3 particleDir = v_normalize(v_sub(ep, sp));
+        float segmentLength = v_distance(sp, ep);
+        float contrib = TWO_PI_F * (float)trackLength * segmentLength;
+        contrib *= frankTammCherenkov(medium->n, wavelength, photons);
+        return cherenkovRay(x, pos, particleDir, medium->n, v, time, contrib);
+    }
+    case ORC_FLAG_LIGHT_MUON_TRACK: {
+        const orc_muon_track_params* p = &c->light.muonTrack;
+        vec3 sp = V3(p->startPosition[0], p->startPosition[1], p->startPosition[2]);
+        vec3 ep = V3(p->endPosition[0], p->endPosition[1], p->endPosition[2]);
+        float u = rnd(x, idx, dim);
+        vec3 position = v_mix(sp, ep, u);
+        float startTime = f_mix(p->startTime, p->endTime, u);
+        float contrib = v_distance(sp, ep);
+        contrib *= p->energyScale;
+        float v0, v1;
+        rnd2(x, idx, dim, &v0, &v1);
+        float phi = TWO_PI_F * v0;
+        float cos_theta = particleSampleEmissionAngle(medium->n, p->a_angular, p->b_angular, v1);
+        vec3 trackDir = v_normalize(v_sub(ep, sp));
+        vec3 rayDir = m3_mul(createLocalCOSY(trackDir), sphericalToCartessian(phi, cos_theta));
+        if (applyFrankTamm) contrib *= frankTammParticle(wavelength, medium->n);
+        return unpolarizedSourceRay(x, position, rayDir, startTime, contrib);
+    }
+    default: { /* ORC_FLAG_LIGHT_CASCADE */
+        const orc_cascade_params* p = &c->light.cascade;
+        vec3 dir = V3(p->direction[0], p->direction[1], p->direction[2]);
+        float z = sampleGamma(x, p->a_long, idx, dim) * p->b_long;
+        vec3 rayPos = v_add(V3(p->startPosition[0], p->startPosition[1], p->startPosition[2]), v_scale(dir, z));
+        float time = p->startTime + z * INV_SPEED_OF_LIGHT_F;
+        float u0, u1;
+        rnd2(x, idx, dim, &u0, &u1);
+        float phi = TWO_PI_F * u0;
+        float cos_theta = particleSampleEmissionAngle(medium->n, p->a_angular, p->b_angular, u1);
+        vec3 rayDir = m3_mul(createLocalCOSY(dir), sphericalToCartessian(phi, cos_theta));
+        float contrib = p->effectiveLength;
+        if (applyFrankTamm) contrib *= frankTammParticle(wavelength, medium->n);
+        return unpolarizedSourceRay(x, rayPos, rayDir, time, contrib);
+    }
+    }
+}
+
+void orc_cherenkov_units(uint32_t which, const float* rows, uint32_t count, float* out) {
+    for (uint32_t i = 0; i < count; ++i) {
+        if (which == 0) {
+            const float* r = rows + 4 * (size_t)i;
+            out[i] = particleSampleEmissionAngle(r[0], r[1], r[2], r[3]);
+        } else if (which == 1) {
+            const float* r = rows + 6 * (size_t)i;
+            out[2 * (size_t)i] = particleSampleEmissionAngleRange(r[0], r[1], r[2], r[3], r[4], r[5], &out[2 * (size_t)i + 1]);
+        } else if (which == 2) {
+            const float* r = rows + 4 * (size_t)i;
+            out[i] = particleEvalEmissionAngle(r[0], r[1], r[2], r[3]);
+        } else {
+            const float* r = rows + 2 * (size_t)i;
+            out[3 * (size_t)i] = frankTammCherenkov(r[0], r[1], 0);
+            out[3 * (size_t)i + 1] = frankTammCherenkov(r[0], r[1], 1);
+            out[3 * (size_t)i + 2] = frankTammParticle(r[1], r[0]);
+        }
+    }
+}
+
 /* lightsource.host.glsl:12-19, lightsource.cone.glsl:22-72, lightsource.pencil.glsl:18-35,
  * lightsource.spherical.glsl:16-34 */
-static SourceRay sampleLight(Ctx* x, uint32_t idx, uint32_t item, uint32_t* dim) {
+static SourceRay sampleLight(Ctx* x, float wavelength, const MediumConstants* medium, uint32_t idx, uint32_t item, uint32_t* dim) {
     const orc_common* c = x->c;
+    if (c->flags & ORC_FLAG_LIGHT_KIND_MASK) return sampleCherenkovFamily(x, wavelength, medium, idx, dim);
     vec3 lightPos = V3(c->light.position[0], c->light.position[1], c->light.position[2]);
     if (c->flags & ORC_FLAG_LIGHT_HOST) { /* LOAD_SAMPLE of lightsource.queue.glsl */
         const float* q = g_light_queue + item;
@@ -951,7 +1126,7 @@ static Ray sampleRay(Ctx* x, uint64_t medium, uint32_t idx, uint32_t* dim) {
     const uint32_t item = idx - x->c->photon_offset; /* position in the batch */
     WavelengthSample photon = sampleWavelength(x, idx, item, dim);
     MediumConstants constants = lookUpMedium(medium, photon.wavelength, &x->cnt);
-    SourceRay s = sampleLight(x, idx, item, dim);
+    SourceRay s = sampleLight(x, photon.wavelength, &constants, idx, item, dim);
     Ray r;
     memset(&r, 0, sizeof(r));
     r.position = s.position;
@@ -979,8 +1154,8 @@ int orc_sample_light(const orc_common* c, uint64_t medium, uint32_t count, uint3
     for (uint32_t idx = 0; idx < count; ++idx) {
         uint32_t dim = 0;
         WavelengthSample photon = sampleWavelength(&x, idx + base, idx + base, &dim);
-        (void)lookUpMedium(medium, photon.wavelength, &x.cnt);
-        SourceRay ray = sampleLight(&x, idx + base, idx + base, &dim);
+        MediumConstants constants = lookUpMedium(medium, photon.wavelength, &x.cnt);
+        SourceRay ray = sampleLight(&x, photon.wavelength, &constants, idx + base, idx + base, &dim);
         float* col = (float*)(light_out + 1) + idx;
         const size_t cap = capacity;
 #define PUT(v) do { *col = (v); col += cap; } while (0)

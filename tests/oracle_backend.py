@@ -117,7 +117,8 @@ class OracleBackend:
                                                      capi.FLAG_LIGHT_HOST | capi.FLAG_LIGHT_QUEUE_POLARIZED | capi.FLAG_WAVELENGTH_HOST |
                                                      capi.FLAG_LIGHT_CONE | capi.FLAG_LIGHT_POLARIZED | capi.FLAG_WAVELENGTH_FUNCTION |
                                                      capi.FLAG_TARGET_DISK | capi.FLAG_TARGET_FLAT | capi.FLAG_GUIDE_DISK | capi.FLAG_GUIDE_FLAT |
-                                                     capi.FLAG_RNG_SOBOL | capi.FLAG_TARGET_MISS_INFINITE))
+                                                     capi.FLAG_RNG_SOBOL | capi.FLAG_TARGET_MISS_INFINITE |
+                                                     capi.FLAG_LIGHT_KIND_MASK | capi.FLAG_FRANK_TAMM_PHOTONS | capi.FLAG_FRANK_TAMM_IS))
         photon = bool(spec.flags & capi.FLAG_PHOTON)
         if self.brute_force:
             flags |= orc.FLAG_BRUTE_FORCE
@@ -176,10 +177,15 @@ class OracleBackend:
         L = orc.lib()
         n_in, n_out = {"lookup": (2, 1), "lookup_medium": (1, 4), "scatter_dir": (5, 3), "fresnel": (3, 2), "scatter_prob": (6, 1),
                        "scatter_sample": (5, 4), "rotate_polref": (9, 5), "align_polref": (9, 2), "phase_matrix": (7, 4), "polarizer": (6, 4),
-                       "sign_bit": (1, 1)}[name]
+                       "sign_bit": (1, 1), "emission_angle": (4, 1), "emission_angle_range": (6, 2), "emission_pdf": (4, 1),
+                       "frank_tamm": (2, 3)}[name]
         x = np.ascontiguousarray(np.asarray(inputs, dtype=np.float32).reshape(-1, n_in))
         out = np.zeros((x.shape[0], n_out), dtype=np.float32)
         fp = lambda a: a.ctypes.data_as(C.POINTER(C.c_float))
+        family = {"emission_angle": 0, "emission_angle_range": 1, "emission_pdf": 2, "frank_tamm": 3}
+        if name in family:  # (all rows in one call)
+            L.orc_cherenkov_units(family[name], fp(x), x.shape[0], fp(out))
+            return out
         for r, o in zip(x, out):
             if name == "lookup":
                 o[0] = L.orc_lookup(addr, float(r[0]), float(r[1]))

@@ -1,0 +1,553 @@
+"""
+The Cherenkov family of light sources in forward mode -- `CherenkovLightSource`, `CherenkovTrackLightSource` (+ `ParticleTrack`),
+`MuonTrackLightSource`, `ParticleCascadeLightSource` -- checked the way the reference checks them, restated in this suite's own form
+with the same sizes, seeds, expectations and tolerances (/root/reference/tests/test_light.py: :453-518 test_cherenkov_fwd,
+:599-683 test_cherenkovTrack, :686-716 the emission profile's normalisation, :725-765 / :777-836 the two emission angle samplers
+(there: test shaders of their own; here: `thx_probe_unit`), :839-915 test_muonTrackLightSource_fwd, :991-1066
+test_particleCascadeLightSource_fwd; tests/test_random.py:92-121 test_gamma). Every case runs on the CPU oracle (`-m "not gpu"`)
+and, through the C ABI, on the HIP sampler kernel (`-m gpu`); the last tests drive tracers with these sources on both and compare.
+
+Not restated: the backward-mode cases (backward tracers are out of scope).
+"""
+import numpy as np
+import pytest
+from scipy import integrate, stats
+
+import hephaistos.pipeline as pl
+import theia.cascades
+import theia.light as TL
+import theia.material
+import theia.response
+import theia.trace
+import theia.units as u
+from theia.random import PhiloxRNG
+from theia.target import SphereTarget
+from theia.testing import WaterTestModel
+
+BACKENDS = [pytest.param("oracle", id="oracle"), pytest.param("hip", id="hip", marks=pytest.mark.gpu)]
+ALPHA, E, C0, MU0 = 7.2973525693e-3, 1.602176634e-19, 299792458.0, 1.25663706212e-6  # scipy.constants of the reference's tests
+
+
+@pytest.fixture(params=BACKENDS)
+def backend(request):
+    from theia_amd import _backend
+
+    prev = _backend._backend
+    if request.param == "oracle":
+        from oracle_backend import OracleBackend
+
+        be = OracleBackend(threads=8)
+    else:
+        be = _backend.HipBackend()
+    _backend._backend = be
+    yield request.param
+    _backend._backend = prev
+    if request.param == "oracle":
+        be.close()
+
+
+def water_store(*lam_range):
+    model = WaterTestModel()
+    return model, theia.material.MaterialStore([], media=[model.createMedium(*lam_range)])
+
+
+def sampled(light, photons, n, medium, *, polarized=False, key=0xC0FFEE):
+    sampler = TL.LightSampler(light, photons, n, rng=PhiloxRNG(key=key), medium=medium, polarized=polarized)
+    pl.runPipeline(sampler.collectStages())
+    return sampler.lightQueue.view(0), sampler.wavelengthQueue.view(0)
+
+
+def frank_tamm_per_azimuth(lam, n, photons):
+    """what the two Cherenkov sources multiply the track length with, times 2 pi (test_light.py:496-503)"""
+    sin2 = 1.0 - 1.0 / n**2
+    if photons:
+        return 2.0 * np.pi * ALPHA * 1e9 / lam**2 * sin2
+    return np.pi * E * C0**2 * MU0 * 1e18 / lam**3 * sin2
+
+
+def check_cherenkov_polarization(samples, along):
+    expected = np.cross(along, samples["direction"])
+    expected /= np.sqrt(np.square(expected).sum(-1))[:, None]
+    ref = samples["polarizationRef"]
+    assert np.allclose(samples["stokes"], (1.0, 1.0, 0.0, 0.0))
+    assert np.abs(np.abs((ref * expected).sum(-1)) - 1.0).max() < 1e-6
+    assert np.abs(np.square(ref).sum(-1) - 1.0).max() < 1e-6
+    assert np.abs((ref * samples["direction"]).sum(-1)).max() < 1e-6
+
+
+@pytest.mark.parametrize("usePhotons", [False, True])
+@pytest.mark.parametrize("polarized", [True, False])
+def test_cherenkov_source(backend, usePhotons, polarized):
+    n_samples, along, dist = 32 * 256, np.array([0.36, 0.48, 0.8]), 200.0 * u.m
+    start, t0 = -along * 0.5 * dist, -0.5 * dist / u.c
+    end, t1 = along * 0.5 * dist, 0.5 * dist / u.c
+    model, store = water_store()
+    photons = TL.UniformWavelengthSource(normalize=False)
+    light = TL.CherenkovLightSource(trackStart=start, trackEnd=end, startTime=t0, endTime=t1, usePhotonCount=usePhotons)
+    assert light.usePhotonCount == usePhotons and light.nRNGForward == 2
+    samples, lams = sampled(light, photons, n_samples, store.media["water"], polarized=polarized)
+    fromStart = np.sqrt(np.square(samples["position"] - start).sum(-1))
+    fromEnd = np.sqrt(np.square(samples["position"] - end).sum(-1))
+    assert np.allclose(fromStart + fromEnd, dist)  # on the track
+    t = samples["startTime"].ravel()
+    assert np.all((t >= t0) & (t <= t1))
+    frac = fromStart / dist
+    # (absolute: near the middle of the track the time passes zero, where a relative tolerance asks for more than the fp32
+    # positions -- 1e-5 m on 100 m -- can give; the reference's assertion is the relative one)
+    assert np.allclose(t, (1.0 - frac) * t0 + frac * t1, atol=5e-4)
+    lam = lams["wavelength"]
+    n = model.refractive_index(lam)
+    assert np.allclose(np.multiply(samples["direction"], along[None, :]).sum(-1), 1.0 / n)  # on the Cherenkov cone
+    assert np.allclose(frank_tamm_per_azimuth(lam, n, usePhotons) * dist, samples["contrib"].ravel())
+    lo, hi = photons.lambdaRange
+    assert np.allclose(lams["contrib"], abs(hi - lo))
+    if polarized:
+        check_cherenkov_polarization(samples, along)
+
+
+@pytest.mark.parametrize("usePhotons", [False, True])
+@pytest.mark.parametrize("polarized", [True, False])
+def test_cherenkov_track_source(backend, usePhotons, polarized):
+    vertices = np.array([[0.0, 0.0, 0.0, 0.0], [1.0, 0.0, 0.0, 20.0], [1.0, 1.0, 0.0, 35.0], [1.0, 1.0, 1.0, 60.0]])
+    segmentDir, dt = np.eye(3), np.array([20.0, 15.0, 25.0])
+    model, store = water_store()
+    track = TL.ParticleTrack(4)
+    track.setVertices(vertices)
+    assert track.length == 3 and track.capacity == 4 and np.allclose(track.numpy(True), vertices)
+    photons = TL.UniformWavelengthSource(normalize=False)
+    light = TL.CherenkovTrackLightSource(track, usePhotonCount=usePhotons)
+    samples, lams = sampled(light, photons, 32 * 256, store.media["water"], polarized=polarized)
+    assert np.all((samples["position"] >= 0.0) & (samples["position"] <= 1.0))
+    t = samples["startTime"].ravel()
+    assert np.all((t >= 0.0) & (t <= 60.0))
+    assert np.allclose(t, np.multiply(samples["position"], dt[None, :]).sum(-1))
+    segment = 2 - (samples["position"] == 0.0).sum(-1)
+    assert set(np.unique(segment)) == {0, 1, 2}
+    lam = lams["wavelength"].ravel()
+    n = model.refractive_index(lam)
+    assert np.allclose(np.multiply(samples["direction"], segmentDir[segment]).sum(-1), 1.0 / n)
+    assert np.allclose(frank_tamm_per_azimuth(lam, n, usePhotons) * 3.0, samples["contrib"].ravel())  # 3 segments of 1 m
+    lo, hi = photons.getParam("lambdaRange")
+    assert np.allclose(abs(hi - lo), lams["contrib"].ravel())
+    if polarized:
+        check_cherenkov_polarization(samples, segmentDir[segment])
+
+
+def test_track_source_needs_a_track(backend):
+    light = TL.CherenkovTrackLightSource()
+    assert light.track is None
+    _model, store = water_store()
+    with pytest.raises(RuntimeError, match="ParticleTrack"):
+        sampled(light, TL.ConstWavelengthSource(), 256, store.media["water"])
+    with pytest.raises(ValueError):
+        TL.ParticleTrack(4).length = 4
+    with pytest.raises(TypeError):
+        light.track = 17
+
+
+def emission_pdf(x, n, cos_min=-1, cos_max=1, a=0.39, b=2.61, beta=1.0):
+    """p(x) ~ exp(-b x^a) x^(a-1), x = |cos(theta) - cos(cherenkov)|, normalised on [cos_min, cos_max]"""
+    cos_chev = 1.0 / (beta * n)
+    x = np.abs(x - cos_chev)
+    lower = (1.0 - np.exp(-b * np.abs(cos_chev - cos_min) ** a)) * np.sign(cos_min - cos_chev)
+    upper = (1.0 - np.exp(-b * np.abs(cos_chev - cos_max) ** a)) * np.sign(cos_max - cos_chev)
+    return np.exp(-b * x**a) * x ** (a - 1) * a * b / np.abs(upper - lower)
+
+
+@pytest.mark.parametrize("n,cos_min,cos_max,a,b,beta", [[1.33, -1.0, 1.0, 0.39, 2.61, 1.0], [1.40, -1.0, -0.5, 0.41, 2.39, 0.9],
+                                                        [1.20, 0.8, 0.9, 0.44, 2.78, 1.0], [1.35, 0.1, 0.9, 0.41, 2.78, 0.7],
+                                                        [1.35, -0.1, 0.9, 0.41, 2.78, 1.0]])
+def test_emission_profile_is_a_density(n, cos_min, cos_max, a, b, beta):
+    pole = 1.0 / (beta * n)  # (integrable singularity: the reference lets quad find it and ignores its warning)
+    est, *_ = integrate.quad(emission_pdf, cos_min, cos_max, (n, cos_min, cos_max, a, b, beta), points=[pole] if cos_min < pole < cos_max else None)
+    assert abs(est - 1.0) < 5e-4
+    assert np.all(emission_pdf(np.linspace(cos_min, cos_max, 500), n, cos_min, cos_max, a, b, beta) >= 0.0)
+
+
+def uniforms(n, key):
+    """what `random(idx, dim = 0)` returns for idx = 0 .. n-1 (the reference's test shaders draw exactly that)"""
+    from theia_amd import _backend
+
+    _, f = _backend.get().rng_fill(key, 0, 0, n, 0, 1)
+    return f.reshape(-1)
+
+
+def rows(n_rows, *columns):
+    return np.stack([np.broadcast_to(np.float32(c), (n_rows,)) for c in columns], axis=-1)
+
+
+N_ANGLES, N_BINS = 2 * 1024 * 1024, 100  # (the reference draws 32 M samples)
+
+
+def relative_error(hist, expected, width):
+    """|hist - expected| / expected per bin, less four standard deviations of the bin's counting noise (the reference's 32 M samples
+    need no such allowance; with 2 M the bins far out in the tail hold a few hundred samples)"""
+    sigma = np.sqrt(np.maximum(expected * width * N_ANGLES, 1.0)) / (width * N_ANGLES)
+    return np.maximum(np.abs(hist - expected) - 4.0 * sigma, 0.0) / expected
+
+
+@pytest.mark.parametrize("n,a,b", [[1.33, 0.53, 3.3], [1.2, 0.86, 2.5], [1.45, 1.03, 3.1], [1.35, 1.13, 3.42]])
+def test_emission_angle_sampler(backend, n, a, b):
+    from theia_amd import _backend
+
+    cos_theta = _backend.get().probe_unit("emission_angle", rows(N_ANGLES, n, a, b, uniforms(N_ANGLES, 0x01ABBA10)))[:, 0]
+    hist, edges = np.histogram(cos_theta, N_BINS, (-1.0, 1.0), density=True)
+    pdf = emission_pdf(edges, n, a=a, b=b)
+    expected = 0.5 * (pdf[1:] + pdf[:-1])
+    # the density diverges at 1 / n: its bin and the two next to it are left out
+    peak = int((1.0 / n + 1) / (2.0 / N_BINS))
+    err = relative_error(hist, expected, 2.0 / N_BINS)
+    assert err[: peak - 1].max() < 0.05
+    assert err[peak + 2:].max() < 0.05
+
+
+@pytest.mark.parametrize("n,a,b,cos_min,cos_max", [[1.33, 0.53, 3.3, -1.0, 1.0], [1.45, 0.86, 2.8, -0.5, 0.8],
+                                                   [1.35, 0.72, 3.1, -0.9, -0.2], [1.35, 1.03, 3.1, 0.8, 0.95]])
+def test_emission_angle_sampler_on_a_range(backend, n, a, b, cos_min, cos_max):
+    from theia_amd import _backend
+
+    be = _backend.get()
+    out = be.probe_unit("emission_angle_range", rows(N_ANGLES, n, a, b, uniforms(N_ANGLES, 0x10500501), cos_min, cos_max))
+    cos_theta, contrib = out[:, 0], out[:, 1]
+    hist, edges = np.histogram(cos_theta, N_BINS, (cos_min, cos_max), density=True)
+    pdf = emission_pdf(edges, n, cos_min, cos_max, a, b)
+    expected = 0.5 * (pdf[1:] + pdf[:-1])
+    err = relative_error(hist, expected, (cos_max - cos_min) / N_BINS)
+    if cos_min <= 1.0 / n <= cos_max:
+        peak = int((1.0 / n - cos_min) / (abs(cos_max - cos_min) / N_BINS))
+        assert err[: peak - 1].max() < 0.03
+        assert err[peak + 2:].max() < 0.03
+    else:
+        assert err.max() < 0.01
+    # the weight f / p of a sample: the share of the whole profile that lies inside the range -- the same for every sample.
+    # (The reference leaves the weight to the backward tests of the light sources.)
+    share, *_ = integrate.quad(emission_pdf, cos_min, cos_max, (n, -1.0, 1.0, a, b), points=[1.0 / n] if cos_min < 1.0 / n < cos_max else None)
+    assert np.allclose(contrib, share, rtol=2e-3)
+    # and the density the backward samplers evaluate
+    x = np.linspace(cos_min, cos_max, 64)[1:-1]
+    x = x[np.abs(x - 1.0 / n) > 1e-2]
+    assert np.allclose(be.probe_unit("emission_pdf", rows(len(x), n, a, b, x))[:, 0], emission_pdf(x, n, a=a, b=b), rtol=2e-4)
+
+
+def test_frank_tamm(backend):
+    from theia_amd import _backend
+
+    lam, n = np.linspace(300.0, 700.0, 41), np.linspace(0.9, 1.5, 41)
+    out = _backend.get().probe_unit("frank_tamm", rows(41, n, lam))
+    sin2 = np.maximum(1.0 - 1.0 / n**2, 0.0)  # no radiation below the Cherenkov threshold
+    assert np.allclose(out[:, 0], 0.5 * E * C0**2 * MU0 * 1e18 / lam**3 * sin2, rtol=1e-5)
+    assert np.allclose(out[:, 1], ALPHA * 1e9 / lam**2 * sin2, rtol=1e-5)
+    assert np.allclose(out[:, 2], TL.frankTamm(lam, n).clip(0.0), rtol=1e-5)
+    assert np.all(out[:5] == 0.0)
+
+
+def azimuth_is_uniform(directions, along, up):
+    cos_phi = np.multiply(directions, up).sum(-1)
+    sin_phi = np.multiply(np.cross(directions, up), along).sum(-1)
+    phi = (np.arctan2(sin_phi, cos_phi) + np.pi) / (2.0 * np.pi)
+    return stats.kstest(phi[::100], "uniform").pvalue > 0.05
+
+
+def photons_per_metre(model, lam_range):
+    lam = np.linspace(*lam_range, 1025)
+    return integrate.romb(TL.frankTamm(lam, model.refractive_index(lam)), (lam_range[1] - lam_range[0]) / (len(lam) - 1))
+
+
+@pytest.mark.parametrize("applyFrankTamm", [False, True])
+def test_muon_track_source(backend, applyFrankTamm):
+    n_samples, lam_range, energy = 256 * 1024, (300.0, 500.0) * u.nm, 10.0 * u.TeV
+    start, t0 = np.array([1.0, 5.0, -2.0]) * u.m, 0.5 * u.us
+    along, dist = np.array([0.36, 0.48, 0.8]), 100.0 * u.m
+    end, t1 = start + along * dist, t0 + dist / u.c
+    up = np.array([0.8, -0.6, 0.0])  # unit, orthogonal to the track
+    model, store = water_store(*lam_range)
+    photons = TL.UniformWavelengthSource(lambdaRange=lam_range, normalize=False)
+    light = TL.MuonTrackLightSource(start, t0, end, t1, energy, applyFrankTamm=applyFrankTamm)
+    assert light.isFrankTammApplied == applyFrankTamm and light.muonEnergy == energy and light.nRNGForward == 3
+    result, lams = sampled(light, photons, n_samples, store.media["water"])
+    fromStart = np.sqrt(np.square(start - result["position"]).sum(-1))
+    fromEnd = np.sqrt(np.square(end - result["position"]).sum(-1))
+    assert np.allclose(fromStart + fromEnd, dist)
+    assert np.allclose(result["startTime"], t0 + fromStart / u.c)
+    assert fromStart.min() < 0.05 and fromEnd.min() < 0.05  # the whole track is used
+    assert np.allclose(np.square(result["direction"]).sum(-1), 1.0)
+    cos_theta = np.multiply(result["direction"], along).sum(-1)
+    assert cos_theta.max() > 0.999 and cos_theta.min() < -0.999
+    assert azimuth_is_uniform(result["direction"], along, up)
+    scale = light.getParam("_energyScale")
+    assert np.isclose(scale, 1.1880 + 0.0206 * np.log(energy))
+    if applyFrankTamm:  # the Monte Carlo estimate of the number of Cherenkov photons the track produces
+        expected = photons_per_metre(model, lam_range) * dist * scale
+        assert abs(1.0 - (result["contrib"] * lams["contrib"]).mean() / expected) < 5e-4
+    else:
+        assert np.allclose(result["contrib"], dist * scale)
+
+
+@pytest.mark.parametrize("applyFrankTamm", [False, True])
+@pytest.mark.parametrize("particle", ["e-", "pi+"])
+def test_particle_cascade_source(backend, applyFrankTamm, particle):
+    n_samples, lam_range = 256 * 1024, (300.0, 500.0) * u.nm
+    start, t0 = np.array([1.0, 5.0, -2.0]) * u.m, 0.5 * u.us
+    along, up = np.array([0.36, 0.48, 0.8]), np.array([0.8, -0.6, 0.0])
+    primary = theia.cascades.ParticleType.E_MINUS if particle == "e-" else theia.cascades.ParticleType.PI_PLUS
+    params = theia.cascades.createParamsFromParticle(theia.cascades.Particle(primary, start, along, 1.0 * u.TeV, t0), lightSourceName="")[1]
+    model, store = water_store(*lam_range)
+    photons = TL.UniformWavelengthSource(lambdaRange=lam_range)
+    light = TL.ParticleCascadeLightSource(**params, applyFrankTamm=applyFrankTamm)
+    assert light.nRNGForward == 12
+    result, _lams = sampled(light, photons, n_samples, store.media["water"])
+    offset = result["position"] - start
+    z = np.sqrt(np.square(offset).sum(-1))
+    assert np.allclose((offset / z[:, None])[z > 0.0], along)  # on the axis
+    assert np.allclose(t0 + z / u.c, result["startTime"])
+    mode = (params["a_long"] - 1) * params["b_long"]
+    assert z.min() < 0.1 * mode and z.max() > 4.0 * mode
+    assert np.allclose(np.square(result["direction"]).sum(-1), 1.0)
+    cos_theta = np.multiply(result["direction"], along).sum(-1)
+    assert cos_theta.min() < -0.999 and cos_theta.max() > 0.999
+    assert azimuth_is_uniform(result["direction"], along, up)
+    expected = params["effectiveLength"]
+    if applyFrankTamm:
+        expected *= photons_per_metre(model, lam_range) / (lam_range[1] - lam_range[0])
+    assert abs(1.0 - result["contrib"].mean() / expected) < 5e-4
+
+
+def shader_gamma(alpha, draws):
+    """random.gamma.glsl:8-31 in float64 on given uniforms (one row per sample: the optional scale draw, then pairs); returns the
+    sample and the number of uniforms it took. The shader's constants are not Cheng's (a = sqrt(2 alpha - 1) where GA has its
+    inverse, c = alpha + 1 / alpha where GA has alpha + 1 / a): for alpha != 1 it samples a slightly narrower distribution than
+    the gamma distribution (mean 4.66 for alpha = 4.8), and the reference's own test asserts `pvalue < 0.05` of a KS test against
+    the gamma distribution (tests/test_random.py:120-121). What is checked here is that the library computes what the shader does."""
+    out, used = np.empty(len(draws)), np.zeros(len(draws), dtype=int)
+    for i, row in enumerate(draws):
+        k, scale, al = 0, 1.0, alpha
+        if al < 1.0:
+            scale, al, k = row[0] ** (1.0 / al), al + 1.0, 1
+        a, b, c = np.sqrt(2.0 * al - 1.0), al - np.log(4.0), al + 1.0 / al
+        while True:
+            u0, u1 = row[k], row[k + 1]
+            k += 2
+            v = a * np.log(u0 / (1.0 - u0))
+            x = al * np.exp(v)
+            if b + c * v - x >= np.log(u0 * u0 * u1):
+                break
+        out[i], used[i] = scale * x, k
+    return out, used
+
+
+@pytest.mark.parametrize("alpha,rate", [(1.0, 1.0), (0.5, 2.2), (4.8, 0.6)])
+def test_gamma_sampler(backend, alpha, rate):
+    """random.gamma.glsl through the one caller it has, the depth of a cascade's photons (tests/test_random.py:92-121 drives it
+    with a test shader of its own)"""
+    from theia_amd import _backend
+
+    n = 4096
+    _model, store = water_store()
+    light = TL.ParticleCascadeLightSource(direction=(0.0, 0.0, 1.0), a_angular=0.5, b_angular=3.0, a_long=alpha, b_long=1.0 / rate)
+    result, _ = sampled(light, TL.ConstWavelengthSource(), n, store.media["water"], key=0xABBAABBA)
+    z = result["position"][:, 2].astype(np.float64) * rate
+    _, draws = _backend.get().rng_fill(0xABBAABBA, 0, 0, n, 0, 400)
+    expected, used = shader_gamma(alpha, draws.astype(np.float64))
+    assert used.max() < 400 and used.min() == (3 if alpha < 1.0 else 2) and used.mean() > used.min()  # (rejections happen)
+    # fp32 against float64: a sample whose acceptance test is decided in the last bit may take another pair of draws
+    same = np.isclose(z, expected, rtol=2e-4)
+    assert same.mean() > 0.995
+    assert abs(z.mean() / alpha - 1.0) < (0.05 if alpha == 1.0 else 0.08)
+
+
+# ---- tracers driven by these sources ------------------------------------------------------------------------------------------
+
+def make_light(kind):
+    if kind == "cherenkov":
+        return TL.CherenkovLightSource(trackStart=(-3.0, -9.0, 1.0) * u.m, trackEnd=(1.0, -5.0, -1.0) * u.m, startTime=2.0 * u.ns,
+                                       endTime=2.0 * u.ns + 6.0 * u.m / u.c, usePhotonCount=True)
+    if kind == "track":
+        track = TL.ParticleTrack(8)
+        track.setVertices([[-3.0, -9.0, 1.0, 0.0], [-1.0, -8.0, 0.5, 7.6], [0.0, -6.0, 0.0, 15.3], [1.0, -5.0, -1.0, 21.1]])
+        return TL.CherenkovTrackLightSource(track)
+    if kind == "muon":
+        return TL.MuonTrackLightSource((-3.0, -9.0, 1.0) * u.m, 2.0 * u.ns, (1.0, -5.0, -1.0) * u.m, 22.0 * u.ns, 2.0 * u.TeV)
+    return TL.ParticleCascadeLightSource(startPosition=(-2.0, -8.0, 0.0) * u.m, startTime=1.0 * u.ns, direction=(0.6, 0.8, 0.0),
+                                         effectiveLength=30.0, a_angular=0.39, b_angular=2.61, a_long=3.2, b_long=0.6, applyFrankTamm=False)
+
+
+def volume_tracer(n, light, *, polarized, sobol=False):
+    import theia.random as TRN
+
+    water = WaterTestModel().createMedium()
+    store = theia.material.MaterialStore([], media=[water])
+    photons = TL.UniformWavelengthSource(lambdaRange=(400.0, 600.0) * u.nm)
+    rng = TRN.SobolQRNG(seed=0xBEEF) if sobol else PhiloxRNG(key=0xFEED)
+    response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), nBins=64, binSize=10.0 * u.ns)
+    tracer = theia.trace.VolumeForwardTracer(n, light, SphereTarget(position=(5.0, 2.0, -8.0) * u.m, radius=4.0 * u.m), photons, response,
+                                             rng, medium=store.media["water"], nScattering=6, polarized=polarized)
+    rng.autoAdvance = tracer.nRNGSamples
+    return tracer, response, store
+
+
+@pytest.mark.parametrize("kind", ["cherenkov", "track", "muon", "cascade"])
+def test_volume_tracer_takes_the_source(backend, kind):
+    """a tracer with the source produces a light curve, batch after batch (two configs, RNG advanced in between), and the curve is
+    the one its photons give when a LightSampler draws them first and host queues feed them in: same samples, and -- the
+    tracer goes on at the RNG dimension the sampling stopped at -- not the same random numbers afterwards, so: statistically"""
+    n = 32 * 1024
+    tracer, response, _store = volume_tracer(n, make_light(kind), polarized=True)
+    pipeline = pl.Pipeline(tracer.collectStages())
+    curves = []
+    for k in range(4):
+        pipeline.run(k % 2)
+        curves.append(np.array(response.result(k % 2)))
+    total = np.sum(curves, axis=0)
+    assert total.sum() > 0 and all(c.sum() > 0 for c in curves)
+    assert not np.array_equal(curves[0], curves[1])  # other photons every batch
+    spread = np.std([c.sum() for c in curves]) / np.mean([c.sum() for c in curves])
+    assert spread < 0.5
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind,polarized,sobol", [("cherenkov", True, False), ("track", False, False), ("muon", True, False),
+                                                   ("cascade", False, False), ("cascade", True, True)])
+def test_tracer_with_cherenkov_sources_hip_matches_oracle(kind, polarized, sobol):
+    """The oracle samples the source inside its tracing loop, as the reference's shaders do; the library samples it with the sampler
+    kernel into the tracer's queues and lets the tracing kernel go on at the RNG dimension the sampling stopped at (api.cpp:
+    thx_tracer_run). Same photons, same random numbers behind them: the light curves agree bin by bin."""
+    from oracle_backend import OracleBackend
+    from theia_amd import _backend
+
+    n, out, prev = 32 * 1024, {}, _backend._backend
+    for name in ("oracle", "hip"):
+        be = OracleBackend(threads=8) if name == "oracle" else _backend.HipBackend()
+        _backend._backend = be
+        try:
+            tracer, response, _store = volume_tracer(n, make_light(kind), polarized=polarized, sobol=sobol)
+            pl.runPipeline(tracer.collectStages())
+            out[name] = np.array(response.result(0))
+        finally:
+            _backend._backend = prev
+            if name == "oracle":
+                be.close()
+    assert out["oracle"].sum() > 0
+    assert np.allclose(out["oracle"], out["hip"], rtol=2e-3, atol=1e-5 * out["oracle"].max())
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["cherenkov", "track", "muon", "cascade"])
+def test_sampled_sources_hip_equal_oracle(kind):
+    """the samples themselves, item by item: positions, directions, times and contributions of the HIP sampler kernel against the
+    oracle's (both fp32 with the same operations; they differ in `pow`, `exp`, `log`, `sin`, `cos` of the two math libraries)"""
+    from oracle_backend import OracleBackend
+    from theia_amd import _backend
+
+    out, prev = {}, _backend._backend
+    for name in ("oracle", "hip"):
+        be = OracleBackend(threads=8) if name == "oracle" else _backend.HipBackend()
+        _backend._backend = be
+        try:
+            _model, store = water_store()
+            samples, lams = sampled(make_light(kind), TL.UniformWavelengthSource(lambdaRange=(350.0, 650.0) * u.nm), 16 * 1024,
+                                    store.media["water"], polarized=True)
+            out[name] = {f: np.array(samples[f]) for f in samples.fields} | {"wavelength": np.array(lams["wavelength"])}
+        finally:
+            _backend._backend = prev
+            if name == "oracle":
+                be.close()
+    a, b = out["oracle"], out["hip"]
+    assert np.array_equal(a["wavelength"], b["wavelength"])
+    for f in ("position", "startTime"):
+        assert np.allclose(a[f], b[f], rtol=1e-5, atol=1e-4), f
+    # (directions near the pole of the emission profile turn a last-bit difference of pow() into 1e-4)
+    assert np.isclose(a["direction"], b["direction"], atol=2e-4).all(-1).mean() > 0.999
+    assert np.allclose(a["contrib"], b["contrib"], rtol=1e-5)
+    assert np.allclose(a["stokes"], b["stokes"]) and np.isclose(a["polarizationRef"], b["polarizationRef"], atol=2e-4).all(-1).mean() > 0.999
+
+
+def muon_scene(batch, **kw):
+    """BASELINE config 2's detector sphere lit by a 2 TeV muon passing 6.5 m from its centre"""
+    from theia_amd import workloads as S
+
+    light = TL.MuonTrackLightSource((-6.0, -20.0, 2.5) * u.m, 0.0, (-6.0, 20.0, 2.5) * u.m, 40.0 * u.m / u.c, 2.0 * u.TeV)
+    return S.config2_sphere(batch=batch, light=light, photons=TL.UniformWavelengthSource(lambdaRange=(350.0, 550.0) * u.nm), **kw)
+
+
+@pytest.mark.gpu
+def test_scene_tracer_with_a_muon_track_hip_matches_oracle_and_overlaps():
+    """the staged scene kernel behind the sampler kernel: curves equal the oracle's; sixteen batches in flight on eight lanes (a
+    pair of sample queues per lane) equal one batch after the other"""
+    from oracle_backend import OracleBackend
+    from theia_amd import _backend
+    from theia_amd import workloads as S
+
+    n, out, prev = 50_000, {}, _backend._backend
+    for name in ("oracle", "hip"):
+        be = OracleBackend(threads=8) if name == "oracle" else _backend.HipBackend()
+        _backend._backend = be
+        try:
+            sc = muon_scene(n, stats=True)
+            out[name] = (S.run_batches(sc, 2), np.array(sc.tracer.program.read_stats()[:12]))
+        finally:
+            _backend._backend = prev
+            if name == "oracle":
+                be.close()
+    (a, sa), (b, sb) = out["oracle"], out["hip"]
+    assert sa[0] == 2 * n and a[0].sum() > 0 and not np.array_equal(a[0], a[1])
+    assert np.abs(sa.astype(float) - sb.astype(float)).max() <= 1e-3 * n  # event counts (a rounding-level difference can turn a photon)
+    for x, y in zip(a, b):
+        assert np.allclose(x, y, rtol=5e-3, atol=1e-5 * x.max())
+    prev, _backend._backend = _backend._backend, _backend.HipBackend()
+    try:
+        serial = S.run_batches(muon_scene(n), 20)
+        sc = muon_scene(n)
+        curves = []
+        sched = pl.PipelineScheduler(pl.Pipeline(sc.stages()), processFn=lambda c, i, args: curves.append(np.array(sc.response.result(c))))
+        sched.schedule([{}] * 20)
+        sched.wait()
+        assert sched.batchesInFlight == 16
+        sched.destroy()
+        for x, y in zip(serial, curves):
+            assert np.abs(x - y).max() <= 2e-6 * x.sum()
+    finally:
+        _backend._backend = prev
+
+
+# ---- theia.cascades (tests/test_cascades.py:8-33) ------------------------------------------------------------------------------
+
+@pytest.mark.parametrize("pType", list(theia.cascades.ParticleType))
+def test_params_from_particle(pType):
+    gen = np.random.default_rng(0xC0FFEE)
+    particle = theia.cascades.Particle(pType, tuple(gen.random(3) * 10.0) * u.m, tuple(gen.random(3)), (gen.random() * 100.0 + 10.0) * u.GeV,
+                                       gen.random() * 500.0 * u.ns, (gen.random() * 500.0 + 100.0) * u.m, 0.8 * u.c)
+    if pType == theia.cascades.ParticleType.UNKNOWN:
+        with pytest.raises(ValueError):
+            theia.cascades.createParamsFromParticle(particle)
+        return
+    source, params, lightYield = theia.cascades.createParamsFromParticle(particle, lightSourceName="")
+    light = source(**params)
+    assert params["startTime"] == particle.startTime
+    assert params["startPosition"] == particle.position
+    assert lightYield.effectiveLength > 0.0 and lightYield.effectiveLengthStd > 0.0
+    if isinstance(light, TL.MuonTrackLightSource):
+        reach = np.subtract(params["endPosition"], params["startPosition"])
+        assert np.isclose(np.sqrt(np.square(reach).sum()), particle.length)
+        assert np.isclose(params["endTime"], particle.startTime + particle.length / (0.8 * u.c))
+        assert lightYield.effectiveLength > particle.length
+    else:
+        assert np.isclose(np.square(params["direction"]).sum(), 1.0)
+        assert light.a_long == np.float32(params["a_long"]) and params["b_long"] > 0.3
+    named = theia.cascades.createParamsFromParticle(particle)[1]
+    assert set(named) == {"lightSource__" + k for k in params}
+    # a drawn light yield: no spread left, and the mean at the median
+    drawn = theia.cascades.createParamsFromParticle(particle, lightSourceName="", uRand=0.5)[2]
+    assert drawn.effectiveLengthStd == 0.0 and np.isclose(drawn.effectiveLength, lightYield.effectiveLength)
+
+
+def test_cascade_parameters_follow_the_fits():
+    c = theia.cascades
+    p = c.createCascadeParameters(c.EMinus, 1.0 * u.TeV)
+    assert np.isclose(p.a_long, 2.01849 + 1.45469 * 3.0) and np.isclose(p.b_long, 0.3608 / 0.63207)
+    assert np.isclose(p.effectiveLength, 5.3207078881 * (0.91 / 1.039) * 1000.0**1.00000211)
+    ice = c.createCascadeParameters(c.EMinus, 1.0 * u.TeV, c.X0_ice, c.rho_ice)
+    assert np.isclose(ice.b_long, 0.3975 / 0.63207) and np.isclose(ice.effectiveLength, 5.3207078881 * 1000.0**1.00000211)
+    assert c.getCascadeParamsFromParticleType(c.ParticleType.PI_0) is c.Gamma
+    assert c.getCascadeParamsFromParticleType(c.ParticleType.MU_MINUS) is None
+    with pytest.raises(ValueError, match="track length"):
+        c.createParamsFromParticle(c.Particle(c.ParticleType.MU_MINUS, (0.0, 0.0, 0.0), (0.0, 0.0, 1.0), 100.0))

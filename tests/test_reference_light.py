@@ -8,8 +8,8 @@ are observed through `LightSampler`; every case runs on the CPU oracle (`-m "not
 through the C ABI, on the HIP sampler kernel (`-m gpu`). The last tests feed a tracer from host
 queues.
 
-Not restated: the backward-mode cases (backward tracers are out of scope) and the Cherenkov /
-muon / cascade sources.
+Not restated: the backward-mode cases (backward tracers are out of scope). The Cherenkov / muon / cascade
+sources: tests/test_reference_cherenkov.py.
 """
 import numpy as np
 import pytest

@@ -54,10 +54,18 @@ FLAG_WAVELENGTH_FUNCTION = 1 << 19
 FLAG_TARGET_DISK = 1 << 20
 FLAG_TARGET_FLAT = 1 << 21
 FLAG_TARGET_MISS_INFINITE = 1 << 25
+FLAG_LIGHT_KIND_MASK = 7 << 26  # the Cherenkov family of light sources
+FLAG_LIGHT_CHERENKOV = 1 << 26
+FLAG_LIGHT_CHERENKOV_TRACK = 2 << 26
+FLAG_LIGHT_MUON_TRACK = 3 << 26
+FLAG_LIGHT_CASCADE = 4 << 26
+FLAG_FRANK_TAMM_PHOTONS = 1 << 29
+FLAG_FRANK_TAMM_IS = 1 << 30
 # thx_probe_unit: function -> (id, input columns, output columns)
 UNIT_PROBES = {"lookup": (0, 2, 1), "lookup_medium": (1, 1, 4), "scatter_dir": (2, 5, 3), "fresnel": (3, 3, 2), "scatter_prob": (4, 6, 1),
                "scatter_sample": (5, 5, 4), "rotate_polref": (6, 9, 5), "align_polref": (7, 9, 2), "phase_matrix": (8, 7, 4),
-               "polarizer": (9, 6, 4), "sign_bit": (10, 1, 1)}
+               "polarizer": (9, 6, 4), "sign_bit": (10, 1, 1),
+               "emission_angle": (11, 4, 1), "emission_angle_range": (12, 6, 2), "emission_pdf": (13, 4, 1), "frank_tamm": (14, 2, 3)}
 FLAG_GUIDE_DISK = 1 << 22
 FLAG_GUIDE_FLAT = 1 << 23
 FLAG_RNG_SOBOL = 1 << 24
@@ -91,9 +99,36 @@ class PhiloxParams(_Packed):
     _fields_ = [("key", c_uint32 * 2), ("offset", c_uint32 * 4)]
 
 
-class LightParams(_Packed):
+class _BasicLight(_Packed):
     _fields_ = [("position", c_float * 3), ("contribFwd", c_float), ("contribBwd", c_float), ("t_min", c_float), ("t_max", c_float),
                 ("direction", c_float * 3), ("stokes", c_float * 4), ("polRef", c_float * 3), ("cosOpeningAngle", c_float)]
+
+
+class CherenkovParams(_Packed):
+    _fields_ = [("trackStart", c_float * 3), ("startTime", c_float), ("trackEnd", c_float * 3), ("endTime", c_float),
+                ("trackDir", c_float * 3), ("trackDist", c_float)]
+
+
+class CherenkovTrackParams(_Packed):
+    _fields_ = [("track", c_uint32 * 2)]
+
+
+class MuonTrackParams(_Packed):
+    _fields_ = [("startPosition", c_float * 3), ("startTime", c_float), ("endPosition", c_float * 3), ("endTime", c_float),
+                ("energyScale", c_float), ("a_angular", c_float), ("b_angular", c_float)]
+
+
+class CascadeParams(_Packed):
+    _fields_ = [("startPosition", c_float * 3), ("startTime", c_float), ("direction", c_float * 3), ("effectiveLength", c_float),
+                ("a_angular", c_float), ("b_angular", c_float), ("a_long", c_float), ("b_long", c_float)]
+
+
+class LightParams(C.Union):
+    """thx_light_params: one block for whichever light source the tracer was created with"""
+    _pack_ = 4
+    _anonymous_ = ("basic",)
+    _fields_ = [("basic", _BasicLight), ("cherenkov", CherenkovParams), ("cherenkovTrack", CherenkovTrackParams),
+                ("muonTrack", MuonTrackParams), ("cascade", CascadeParams)]
 
 
 class WavelengthParams(_Packed):

@@ -132,6 +132,10 @@ struct thx_tracer {
     uint32_t* lamOut = nullptr;   // THX_TRACER_LIGHT_SAMPLER: wavelength output queue (light output: `hits`)
     float* lightIn[2] = {nullptr, nullptr}; // HostLightSource queue per pipeline config
     float* lamIn[2] = {nullptr, nullptr};   // HostWavelengthSource queue per pipeline config
+    // Cherenkov-family light source of a tracing kind: the sampler kernel fills these right before every launch (one pair per
+    // lane: the batches of a lane run one after the other): count word + 8 / 15 columns, count word + wavelength, contrib, dimension
+    uint32_t* preLight[THX_MAX_SLOTS] = {};
+    uint32_t* preLam[THX_MAX_SLOTS] = {};
     uint32_t trackEvents = 0;
     uint32_t lastBatch = 0;
     // ring of HIP event pairs bracketing the tracing kernel on its launch stream
@@ -550,6 +554,10 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         return fail(THX_ERR_INVALID, "host light / wavelength source flags and queue capacities do not match");
     if (sampler && (((desc->flags & THX_FLAG_LIGHT_HOST) && ((desc->flags & THX_FLAG_LIGHT_QUEUE_POLARIZED) != 0) != ((desc->flags & THX_FLAG_POLARIZED) != 0))))
         return fail(THX_ERR_INVALID, "mismatch in light queue definition (lightsource.sample.glsl:28-33)");
+    if (desc->flags & THX_FLAG_SOURCES_PRESAMPLED) return fail(THX_ERR_INVALID, "THX_FLAG_SOURCES_PRESAMPLED is set by the library, not by the caller");
+    if ((desc->flags & THX_FLAG_LIGHT_KIND_MASK) > THX_FLAG_LIGHT_CASCADE) return fail(THX_ERR_UNSUPPORTED, "unknown light source kind");
+    if ((desc->flags & THX_FLAG_LIGHT_KIND_MASK) && (desc->flags & (THX_FLAG_LIGHT_HOST | THX_FLAG_LIGHT_CONE | THX_FLAG_LIGHT_PENCIL)))
+        return fail(THX_ERR_INVALID, "a tracer has one light source: a Cherenkov-family kind excludes the host / cone / pencil flags");
     if (desc->kind == THX_TRACER_SCENE_FORWARD && !scene)
         return fail(THX_ERR_INVALID, "scene tracer needs a scene");
     const bool record = !sampler && (desc->response_kind == THX_RESPONSE_RECORD || desc->response_kind == THX_RESPONSE_STORE_TIME);
@@ -762,6 +770,10 @@ int thx_tracer_destroy(thx_tracer* t) {
         if (t->evHits[i]) (void)hipEventDestroy(t->evHits[i]);
     if (t->replayIn) (void)hipFree(t->replayIn);
     if (t->lamOut) (void)hipFree(t->lamOut);
+    for (uint32_t l = 0; l < THX_MAX_SLOTS; ++l) {
+        if (t->preLight[l]) (void)hipFree(t->preLight[l]);
+        if (t->preLam[l]) (void)hipFree(t->preLam[l]);
+    }
     for (int i = 0; i < 2; ++i) {
         if (t->lightIn[i]) (void)hipFree(t->lightIn[i]);
         if (t->lamIn[i]) (void)hipFree(t->lamIn[i]);
@@ -895,6 +907,13 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.wavelength_queue = t->lamIn[hostCfg];
     a.light_capacity = t->desc.light_queue_capacity;
     a.wavelength_capacity = t->desc.wavelength_queue_capacity;
+    const bool tracing = t->desc.kind == THX_TRACER_VOLUME_FORWARD || t->desc.kind == THX_TRACER_SCENE_FORWARD;
+    const bool presample = tracing && (t->desc.flags & THX_FLAG_LIGHT_KIND_MASK) != 0u;
+    if (presample && !t->preLight[lane]) { // first batch of this lane
+        const bool pol = (t->desc.flags & THX_FLAG_POLARIZED) != 0u;
+        THX_HIP(hipMalloc((void**)&t->preLight[lane], 4 + (pol ? 15 : 8) * 4 * (size_t)t->desc.capacity));
+        THX_HIP(hipMalloc((void**)&t->preLam[lane], 4 + 3 * 4 * (size_t)t->desc.capacity));
+    }
     if ((t->lightIn[hostCfg] && batch > t->desc.light_queue_capacity) || (t->lamIn[hostCfg] && batch > t->desc.wavelength_queue_capacity))
         return fail(THX_ERR_INVALID, "batchSize exceeds the capacity of the host light / wavelength source");
     a.track = t->track;
@@ -914,11 +933,29 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
             (t->lightIn[hostCfg] && batch + params->photon_offset > t->desc.light_queue_capacity) ||
             (t->lamIn[hostCfg] && batch + params->photon_offset > t->desc.wavelength_queue_capacity))
             return fail(THX_ERR_INVALID, "count + baseCount exceeds the capacity of the host light / wavelength source");
-        THX_HIP(launchSampler(a, (t->desc.flags & THX_FLAG_POLARIZED) != 0, t->hits, t->lamOut, t->desc.capacity, s));
+        THX_HIP(launchSampler(a, (t->desc.flags & THX_FLAG_POLARIZED) != 0, t->hits, t->lamOut, t->desc.capacity, false, s));
     } else if (t->desc.kind == THX_TRACER_HIT_REPLAY)
         THX_HIP(launchReplay(a, t->replayIn, t->desc.capacity, (t->desc.flags & THX_FLAG_POLARIZED) != 0, grid, s));
-    else
+    else {
+        if (presample) {
+            // the sources first, on the same stream: sample idx + photon_offset of wavelength and light source into item idx of the
+            // lane's queues (what a LightSampler stage does, lightsource.sample.glsl:52-75), in the photon's start medium ...
+            LaunchArgs sa = a;
+            const uint32_t* medium = t->desc.kind == THX_TRACER_SCENE_FORWARD ? params->scene.sceneMedium : params->volume.medium;
+            sa.p.volume.medium[0] = medium[0];
+            sa.p.volume.medium[1] = medium[1];
+            const bool pol = (t->desc.flags & THX_FLAG_POLARIZED) != 0u;
+            THX_HIP(launchSampler(sa, pol, t->preLight[lane], t->preLam[lane], t->desc.capacity, true, s));
+            // ... which the tracing kernel then reads like queues uploaded by the host, RNG dimension included
+            a.flags = (a.flags & ~(uint32_t)(THX_FLAG_LIGHT_KIND_MASK | THX_FLAG_FRANK_TAMM_PHOTONS | THX_FLAG_FRANK_TAMM_IS |
+                                             THX_FLAG_WAVELENGTH_UNIFORM | THX_FLAG_WAVELENGTH_FUNCTION)) |
+                      THX_FLAG_LIGHT_HOST | THX_FLAG_WAVELENGTH_HOST | THX_FLAG_SOURCES_PRESAMPLED | (pol ? THX_FLAG_LIGHT_QUEUE_POLARIZED : 0u);
+            a.light_queue = reinterpret_cast<const float*>(t->preLight[lane] + 1);
+            a.wavelength_queue = reinterpret_cast<const float*>(t->preLam[lane] + 1);
+            a.light_capacity = a.wavelength_capacity = t->desc.capacity;
+        }
         THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));
+    }
     if (t->hits1) {
         THX_HIP(hipEventRecord(t->evHits[cfg], s));
         t->lastHitCfg = cfg;
@@ -1241,7 +1278,8 @@ int thx_probe_guide(thx_ctx* ctx, const thx_philox_params* philox, uint32_t flag
 
 int thx_probe_unit(thx_ctx* ctx, uint32_t which, uint64_t addr, const float* in, uint32_t n_in, uint32_t n, float* out, uint32_t n_out) {
     if (!ctx || !in || !out) return fail(THX_ERR_INVALID, "null argument");
-    static const uint32_t cols[THX_UNIT_COUNT][2] = {{2, 1}, {1, 4}, {5, 3}, {3, 2}, {6, 1}, {5, 4}, {9, 5}, {9, 2}, {7, 4}, {6, 4}, {1, 1}};
+    static const uint32_t cols[THX_UNIT_COUNT][2] = {{2, 1}, {1, 4}, {5, 3}, {3, 2}, {6, 1}, {5, 4}, {9, 5}, {9, 2}, {7, 4}, {6, 4}, {1, 1},
+                                                     {4, 1}, {6, 2}, {4, 1}, {2, 3}};
     if (which >= THX_UNIT_COUNT) return fail(THX_ERR_INVALID, "unknown unit probe");
     if (n_in != cols[which][0] || n_out != cols[which][1]) return fail(THX_ERR_INVALID, "column counts do not match the probed function");
     if (n == 0) return THX_OK;

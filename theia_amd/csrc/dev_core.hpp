@@ -84,17 +84,20 @@ THX_DEV float thx_sin(float x) { return __sinf(x); }
 THX_DEV float thx_cos(float x) { return __cosf(x); }
 THX_DEV float thx_exp(float x) { return __expf(x); }
 THX_DEV float thx_log(float x) { return __logf(x); }
+THX_DEV float thx_pow(float x, float y) { return __powf(x, y); }
 #else
 THX_DEV float thx_sin(float x) { return sinf(x); }
 THX_DEV float thx_cos(float x) { return cosf(x); }
 THX_DEV float thx_exp(float x) { return expf(x); }
 THX_DEV float thx_log(float x) { return logf(x); }
+THX_DEV float thx_pow(float x, float y) { return powf(x, y); }
 #endif
 
 // math.glsl:8-16, material.glsl:6
 constexpr float TWO_PI = 6.283185307179586477f;
 constexpr float INV_4PI = 0.0795774715459476679f;
 constexpr float SPEED_OF_LIGHT = 0.299792458f;
+constexpr float INV_SPEED_OF_LIGHT = 3.335640951981521f; // material.glsl:7, ns / m
 
 // result.glsl:10-28
 enum : int {

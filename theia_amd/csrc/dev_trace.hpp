@@ -450,8 +450,12 @@ THX_DEV SourceRay sourceRay(f3 position, f3 direction, float startTime, float co
     return r;
 }
 
+THX_DEV float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
+
 // lightsource.host.glsl:12-19 (LOAD_SAMPLE of lightsource.queue.glsl), lightsource.cone.glsl:22-72,
-// lightsource.pencil.glsl:18-35, lightsource.spherical.glsl:16-34
+// lightsource.pencil.glsl:18-35, lightsource.spherical.glsl:16-34. (The Cherenkov family -- dev_cherenkov.hpp -- is not compiled
+// into the tracing kernels: the library samples those sources with the sampler kernel into the tracer's own queues right before the
+// launch, which then reads them through the host-queue branch below and takes the photon's RNG dimension from the queue too.)
 template <class V>
 THX_DEV SourceRay sampleLight(Lane<V>& L) {
     const THX_KERNARG thx_run_params& P = coldArgs().p; // birth happens once per photon: nothing of it needs to stay in SGPRs
@@ -525,6 +529,10 @@ THX_DEV Ray sampleRay(Lane<V>& L, uint64_t medium) {
     const WavelengthSample photon = sampleWavelength(L);
     MediumConstants constants = lookUpMedium(medium, photon.wavelength, L.cnt);
     const SourceRay s = sampleLight(L);
+    if (L.a->flags & THX_FLAG_SOURCES_PRESAMPLED) { // the draws both samples took were made by the sampler kernel: go on behind them
+        const THX_KERNARG LaunchArgs& cold = coldArgs();
+        L.dim = __float_as_uint(cold.wavelength_queue[L.local + 2u * cold.wavelength_capacity]);
+    }
     Ray r;
     r.position = s.position;
     r.direction = s.direction;
@@ -641,8 +649,6 @@ THX_DEV m3 ldm3(const float* m) { // column major
 THX_DEV m3 ldm3(const THX_KERNARG float* m) {
     return m3{f3{m[0], m[1], m[2]}, f3{m[3], m[4], m[5]}, f3{m[6], m[7], m[8]}};
 }
-THX_DEV float signf(float v) { return v > 0.0f ? 1.0f : (v < 0.0f ? -1.0f : 0.0f); }
-
 // target.disk.glsl:43-66 / target.flat.glsl:47-72
 THX_DEV TargetSample intersectTargetPlane(const thx_target_params& tp, f3 observer, f3 direction, bool disk, bool missInfinite) {
     const m3 o2w = ldm3(tp.objToWorld);

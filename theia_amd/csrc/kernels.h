@@ -72,8 +72,10 @@ hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32
                         uint32_t grid, hipStream_t stream);
 constexpr uint32_t kReplayBlock = 256;
 // lightsource.sample.glsl: dispatch.batchSize samples into the two output queues
+// (with_dim: a third column of the wavelength queue takes every sample's RNG dimension after both draws -- what a tracer that reads
+// its sources from these queues goes on with, THX_FLAG_SOURCES_PRESAMPLED)
 hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light_out, uint32_t* lam_out, uint32_t capacity,
-                         hipStream_t stream);
+                         bool with_dim, hipStream_t stream);
 // target.sample.glsl / target_guide.sample.glsl probes: out[n][25] resp. out[n][13]
 hipError_t launchProbe(bool guide, const LaunchArgs& args, const float* lo, const float* hi, uint32_t n, float* out,
                        hipStream_t stream);

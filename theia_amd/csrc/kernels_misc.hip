@@ -6,6 +6,7 @@
 
 #include "kernels.h"
 #include "dev_staged.hpp"
+#include "dev_cherenkov.hpp"
 
 namespace thx {
 
@@ -155,7 +156,7 @@ hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32
 // -> item idx of the two output queues (count + structure-of-arrays columns)
 template <bool POL>
 __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs args, uint32_t* __restrict__ light_out,
-                                                              uint32_t* __restrict__ lam_out, uint32_t capacity) {
+                                                              uint32_t* __restrict__ lam_out, uint32_t capacity, bool with_dim) {
     using V = Variant<POL, true, false, false, 0, 1>;
     const uint32_t idx = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t count = args.p.dispatch.batchSize;
@@ -168,7 +169,9 @@ __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs a
     L.local = L.idx;
     L.dim = 0;
     const WavelengthSample photon = sampleWavelength(L);
-    const SourceRay ray = sampleLight(L);
+    const uint64_t medium = (uint64_t)args.p.volume.medium[0] | ((uint64_t)args.p.volume.medium[1] << 32); // SampleParams.medium
+    const MediumConstants constants = lookUpMedium(medium, photon.wavelength, L.cnt);
+    const SourceRay ray = (args.flags & THX_FLAG_LIGHT_KIND_MASK) ? sampleCherenkovFamily(L, photon.wavelength, constants.n) : sampleLight(L);
     float* col = reinterpret_cast<float*>(light_out + 1) + idx;
     auto put = [&](float v) { *col = v; col += capacity; };
     put(ray.position.x); put(ray.position.y); put(ray.position.z);
@@ -181,6 +184,7 @@ __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs a
     float* w = reinterpret_cast<float*>(lam_out + 1) + idx;
     w[0] = photon.wavelength;
     w[capacity] = photon.contrib;
+    if (with_dim) w[2u * capacity] = __uint_as_float(L.dim); // a tracer's own queue: the RNG dimension the photon goes on with
     if (idx == 0) {
         light_out[0] = count;
         lam_out[0] = count;
@@ -188,14 +192,14 @@ __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs a
 }
 
 hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light_out, uint32_t* lam_out, uint32_t capacity,
-                         hipStream_t stream) {
+                         bool with_dim, hipStream_t stream) {
     const uint32_t count = args.p.dispatch.batchSize;
     const uint32_t grid = (count + kReplayBlock - 1) / kReplayBlock;
     if (grid == 0) return hipSuccess;
     if (polarized)
-        hipLaunchKernelGGL(samplerKernel<true>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity);
+        hipLaunchKernelGGL(samplerKernel<true>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity, with_dim);
     else
-        hipLaunchKernelGGL(samplerKernel<false>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity);
+        hipLaunchKernelGGL(samplerKernel<false>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity, with_dim);
     return hipGetLastError();
 }
 
@@ -331,6 +335,23 @@ __global__ void unitProbeKernel(uint32_t which, uint64_t addr, const float* __re
         o[0] = v.x; o[1] = v.y; o[2] = v.z; o[3] = v.w;
         break;
     }
+    case THX_UNIT_EMISSION_ANGLE: // lightsource.particles.common.glsl:69-97
+        o[0] = particleSampleEmissionAngle(x[0], x[1], x[2], x[3]);
+        break;
+    case THX_UNIT_EMISSION_ANGLE_RANGE: { // lightsource.particles.common.glsl:103-136
+        float contrib;
+        o[0] = particleSampleEmissionAngleRange(x[0], x[1], x[2], x[3], x[4], x[5], contrib);
+        o[1] = contrib;
+        break;
+    }
+    case THX_UNIT_EMISSION_PDF: // lightsource.particles.common.glsl:138-154
+        o[0] = particleEvalEmissionAngle(x[0], x[1], x[2], x[3]);
+        break;
+    case THX_UNIT_FRANK_TAMM: // lightsource.cherenkov.common.glsl:16-21 / :37-42, lightsource.particles.common.glsl:53-62
+        o[0] = frankTammCherenkov(x[0], x[1], false);
+        o[1] = frankTammCherenkov(x[0], x[1], true);
+        o[2] = frankTammParticle(x[1], x[0]);
+        break;
     default: // THX_UNIT_SIGN_BIT, math.glsl:18-20
         o[0] = signBit(x[0]);
         break;

@@ -18,12 +18,13 @@ from ._program import _Program
 from .hp.glsl import _layout, buffer_reference, vec2, vec3, vec4
 from .hp.pipeline import PipelineStage, SourceCodeMixin
 from .hp.queue import IOQueue
-from .lookup import uploadTables
+from .lookup import DeviceBlob, uploadTables
 
 __all__ = ["WavelengthSource", "WavelengthSampleItem", "HostWavelengthSource", "StreamingHostWavelengthSource",
            "ConstWavelengthSource", "UniformWavelengthSource", "FunctionWavelengthSource", "LightSource", "LightSampleItem",
            "PolarizedLightSampleItem", "LightSampler", "HostLightSource", "StreamingHostLightSource", "ConeLightSource",
-           "SphericalLightSource", "PencilLightSource"]
+           "SphericalLightSource", "PencilLightSource", "CherenkovLightSource", "ParticleTrack", "CherenkovTrackLightSource",
+           "MuonTrackLightSource", "ParticleCascadeLightSource", "frankTamm"]
 
 
 def _xyz(n: int = 3):
@@ -325,6 +326,198 @@ class ConeLightSource(_Budgeted, LightSource):
         self.setParams(_contribFwd=self.budget, _contribBwd=self.budget / cone)
 
 
+class _FrankTamm:
+    """the two compile-time switches of the Cherenkov family: the unit of the radiance (the two Cherenkov sources) and whether the
+    Frank-Tamm factor is applied at all (muon track, cascade)"""
+
+    _usePhotonCount = False
+    _applyFrankTamm = True
+    usePhotonCount = property(lambda self: self._usePhotonCount, doc="radiance in number of photons instead of eV")
+    isFrankTammApplied = property(lambda self: self._applyFrankTamm, doc="whether the Frank-Tamm equation is applied")
+
+
+class CherenkovLightSource(_FrankTamm, LightSource):
+    """
+    Cherenkov light of a particle at the speed of light on a straight track from `trackStart` (at `startTime`) to `trackEnd`
+    (at `endTime`): photons start uniformly along the track on the cone of half angle acos(1 / n), linearly polarized in the
+    plane of track and photon; their contribution is the Frank-Tamm radiance (eV, or photons with `usePhotonCount`) times the
+    track length. 2 draws. Reference: light.py:1183-1268, shader/lightsource.cherenkov.simple.glsl:20-58.
+    """
+
+    name = "Cherenkov Light Source"
+
+    class LightParams(Structure):
+        _fields_ = _layout(trackStart=vec3, startTime=c_float, trackEnd=vec3, endTime=c_float, _trackDir=vec3, _trackDist=c_float)
+
+    def __init__(self, *, trackStart=(0.0, 0.0, 0.0) * u.m, trackEnd=(100.0, 0.0, 0.0) * u.m, startTime=0.0 * u.ns,
+                 endTime=100.0 * u.m / u.c, usePhotonCount=False):
+        LightSource.__init__(self, supportForward=True, supportBackward=True, nRNGForward=2, nRNGBackward=0,
+                             params={"LightParams": self.LightParams})
+        self._usePhotonCount = bool(usePhotonCount)
+        self.setParams(trackStart=trackStart, trackEnd=trackEnd, startTime=startTime, endTime=endTime)
+
+    def _finishParams(self, i):
+        LightSource._finishParams(self, i)
+        along = np.asarray(self.trackEnd, dtype=np.float64) - np.asarray(self.trackStart, dtype=np.float64)
+        dist = float(np.sqrt(np.square(along).sum()))
+        self.setParams(_trackDir=tuple(along / dist), _trackDist=dist)
+
+
+class ParticleTrack:
+    """
+    A polyline a particle travelled along: up to `capacity` vertices (x, y, z in m, t in ns), `length` = number of segments.
+    The reference keeps it in a tensor mapped into host memory (light.py:1274-1352); here the vertices live in a numpy array
+    and every update of the light source that uses the track copies them to the device (`address`).
+    """
+
+    class Header(Structure):
+        _fields_ = [("length", c_uint32)]
+
+    class Vertex(Structure):
+        _fields_ = _layout(x=c_float, y=c_float, z=c_float, t=c_float)
+
+    def __init__(self, capacity: int) -> None:
+        if capacity < 2:
+            raise ValueError("a track needs at least two vertices")
+        self._capacity = int(capacity)
+        self._host = np.zeros(1 + 4 * self._capacity, dtype=np.uint32)
+        self._blob = DeviceBlob(self._host.nbytes)
+        self._blob.upload(self._host)
+
+    capacity = property(lambda self: self._capacity, doc="maximum number of vertices")
+    address = property(lambda self: self._blob.address, doc="device address of the track")
+
+    def __int__(self) -> int:
+        return self._blob.address
+
+    @property
+    def length(self) -> int:
+        """number of segments, i.e. number of vertices - 1"""
+        return int(self._host[0])
+
+    @length.setter
+    def length(self, value: int) -> None:
+        if not 0 <= value <= self._capacity - 1:
+            raise ValueError("length must be between 0 and (capacity - 1)")
+        self._host[0] = value
+
+    def numpy(self, flat: bool = False) -> np.ndarray:
+        """the vertices: a structured array (x, y, z, t), or with `flat` a float array of shape (capacity, 4)"""
+        v = self._host[1:].view(np.float32).reshape(self._capacity, 4)
+        return v if flat else v.view(np.dtype([(c, np.float32) for c in "xyzt"])).reshape(-1)
+
+    def setVertices(self, data) -> None:
+        """copies vertices of shape (n, 4) -- x, y, z, t -- into the track and sets its length to n - 1 segments"""
+        data = np.asarray(data, dtype=np.float32)
+        if data.ndim != 2 or data.shape[1] != 4 or not 2 <= len(data) <= self._capacity:
+            raise ValueError("expected between 2 and `capacity` vertices (x, y, z, t)")
+        self.numpy(True)[: len(data)] = data
+        self.length = len(data) - 1
+
+    def flush(self) -> None:
+        """host -> device"""
+        self._blob.upload(self._host)
+
+
+class CherenkovTrackLightSource(_FrankTamm, LightSource):
+    """
+    Cherenkov light of a particle at the speed of light along a `ParticleTrack`: a segment is picked uniformly, the photon starts
+    uniformly on it, cone and polarization as for `CherenkovLightSource`. 2 draws. `track` may be `None` until the source is used.
+    Reference: light.py:1355-1410, shader/lightsource.cherenkov.track.glsl:23-78.
+    """
+
+    name = "Cherenkov Track Light Source"
+
+    class TrackParams(Structure):
+        _fields_ = _layout(_track=buffer_reference)
+
+    def __init__(self, track=None, *, usePhotonCount=False):
+        LightSource.__init__(self, supportForward=True, supportBackward=False, nRNGForward=2,
+                             params={"TrackParams": self.TrackParams}, extra={"track"})
+        self._usePhotonCount = bool(usePhotonCount)
+        self.track = track
+
+    def _set_track(self, track) -> None:
+        if track is not None and not isinstance(track, ParticleTrack):
+            raise TypeError("track must be a ParticleTrack or None")
+        self._trackObj = track
+
+    track = property(lambda self: self._trackObj, _set_track, doc="the track the light is sampled from")
+
+    def _finishParams(self, i):
+        LightSource._finishParams(self, i)
+        if self._trackObj is None or self._trackObj.length < 1:
+            raise RuntimeError("CherenkovTrackLightSource needs a ParticleTrack of at least one segment before it is sampled")
+        self._trackObj.flush()
+        self.setParams(_track=self._trackObj.address)
+
+
+class MuonTrackLightSource(_FrankTamm, LightSource):
+    """
+    Cherenkov light of a high-energy muon and its secondaries below 500 MeV on a straight track (Raedel 2012): photons start
+    uniformly between `startPosition` (at `startTime`) and `endPosition` (at `endTime`); their angle to the track follows the
+    profile exp(-b x^a) x^(a-1), x = |cos(theta) - 1 / n|, with a, b and the light yield scale set by `muonEnergy`. 3 draws.
+    With `applyFrankTamm=False` the Frank-Tamm factor is left to the wavelength source. Unpolarized.
+    Reference: light.py:1413-1519, shader/lightsource.particles.muon.glsl:29-60.
+    """
+
+    name = "Muon Track Light Source"
+
+    class TrackParameters(Structure):
+        _fields_ = _layout(startPosition=vec3, startTime=c_float, endPosition=vec3, endTime=c_float, _energyScale=c_float,
+                           _a_angular=c_float, _b_angular=c_float)
+
+    def __init__(self, startPosition=(0.0, 0.0, 0.0), startTime=0.0, endPosition=(0.0, 0.0, 0.0), endTime=0.0,
+                 muonEnergy=1.0 * u.GeV, applyFrankTamm=True):
+        LightSource.__init__(self, supportForward=True, nRNGForward=3, supportBackward=True, nRNGBackward=1,
+                             params={"MuonTrackParams": self.TrackParameters}, extra={"muonEnergy"})
+        self.setParams(startPosition=startPosition, startTime=startTime, endPosition=endPosition, endTime=endTime)
+        self.muonEnergy = muonEnergy
+        self._applyFrankTamm = bool(applyFrankTamm)
+
+    def _set_energy(self, energy) -> None:
+        self._muonEnergy = energy
+        # light yield of the secondaries and the angular profile as functions of the muon's energy (light.py:1505-1513)
+        self.setParam("_energyScale", 1.1880 + 0.0206 * np.log(energy))
+        self.setParam("_a_angular", 0.86634 - 7.5624e-3 * np.log10(energy))
+        self.setParam("_b_angular", 2.5030 + 3.0533e-2 * np.log10(energy))
+
+    muonEnergy = property(lambda self: self._muonEnergy, _set_energy, doc="energy of the muon producing the secondary particles")
+
+
+class ParticleCascadeLightSource(_FrankTamm, LightSource):
+    """
+    Cherenkov light of an electromagnetic or hadronic cascade (Raedel 2012): photons start on the axis `startPosition` +
+    z `direction`, z gamma distributed with shape `a_long` and scale `b_long` (m), at the time the primary passes; angular profile
+    as for the muon track with `a_angular`, `b_angular`; contribution `effectiveLength` (times Frank-Tamm unless
+    `applyFrankTamm=False`). The number of draws varies (rejection sampling of the gamma distribution); 12 are reserved.
+    Unpolarized. Reference: light.py:1522-1653, shader/lightsource.particles.cascade.glsl:41-69, random.gamma.glsl.
+    """
+
+    name = "Particle Cascade Light Source"
+
+    class CascadeParameters(Structure):
+        _fields_ = _layout(startPosition=vec3, startTime=c_float, direction=vec3, effectiveLength=c_float, a_angular=c_float,
+                           b_angular=c_float, a_long=c_float, b_long=c_float)
+
+    def __init__(self, startPosition=(0.0, 0.0, 0.0), startTime=0.0 * u.ns, direction=(0.0, 0.0, 1.0), effectiveLength=1.0,
+                 a_angular=0.0, b_angular=0.0, a_long=0.0, b_long=0.0, applyFrankTamm=True):
+        LightSource.__init__(self, supportForward=True, supportBackward=True, nRNGForward=12, nRNGBackward=10,
+                             params={"CascadeParams": self.CascadeParameters})
+        self.setParams(startPosition=startPosition, startTime=startTime, direction=direction, effectiveLength=effectiveLength,
+                       a_angular=a_angular, b_angular=b_angular, a_long=a_long, b_long=b_long)
+        self._applyFrankTamm = bool(applyFrankTamm)
+
+
+def frankTamm(wavelength, refractiveIndex, beta: float = 1.0) -> np.ndarray:
+    """Frank-Tamm equation: photons per metre of track and nanometre of wavelength, 2 pi alpha / lambda^2 (1 - 1 / (beta n)^2)
+    (light.py:1656-1677)"""
+    lam = np.asarray(wavelength, dtype=np.float64) / u.nm
+    n = beta * np.asarray(refractiveIndex, dtype=np.float64)
+    alpha = 7.2973525693e-3  # fine-structure constant (CODATA 2018)
+    return 2.0 * np.pi * alpha / lam**2 * (1.0 - 1.0 / n**2) * 1e9  # (one of the two nm^-1 becomes m^-1)
+
+
 class HostLightSource(_Fed, LightSource):
     """
     Light source passing samples from the host to the device (light.py:692-772,
@@ -360,7 +553,9 @@ class StreamingHostLightSource(_StreamMixin, HostLightSource):
 
 # ---- what the HIP backend needs to know about a (light source, wavelength source) pair --------
 
-_LIGHTS = (SphericalLightSource, PencilLightSource, ConeLightSource, HostLightSource)
+_CHERENKOV_FAMILY = {CherenkovLightSource: capi.FLAG_LIGHT_CHERENKOV, CherenkovTrackLightSource: capi.FLAG_LIGHT_CHERENKOV_TRACK,
+                     MuonTrackLightSource: capi.FLAG_LIGHT_MUON_TRACK, ParticleCascadeLightSource: capi.FLAG_LIGHT_CASCADE}
+_LIGHTS = (SphericalLightSource, PencilLightSource, ConeLightSource, HostLightSource) + tuple(_CHERENKOV_FAMILY)
 _WAVELENGTHS = (ConstWavelengthSource, UniformWavelengthSource, FunctionWavelengthSource, HostWavelengthSource)
 
 
@@ -374,6 +569,10 @@ def sourceSpec(source: LightSource, wavelength: WavelengthSource) -> tuple[int, 
         flags |= capi.FLAG_LIGHT_CONE | (capi.FLAG_LIGHT_POLARIZED if source.polarized else 0)
     elif isinstance(source, PencilLightSource):
         flags |= capi.FLAG_LIGHT_PENCIL
+    elif type(source) in _CHERENKOV_FAMILY:
+        flags |= _CHERENKOV_FAMILY[type(source)]
+        flags |= capi.FLAG_FRANK_TAMM_PHOTONS if source.usePhotonCount else 0
+        flags |= 0 if source.isFrankTammApplied else capi.FLAG_FRANK_TAMM_IS
     if isinstance(wavelength, HostWavelengthSource):
         flags |= capi.FLAG_WAVELENGTH_HOST
         lamCap = wavelength.capacity
@@ -386,7 +585,9 @@ def sourceSpec(source: LightSource, wavelength: WavelengthSource) -> tuple[int, 
 
 def fillSourceParams(P: capi.RunParams, i: int, source: LightSource, wavelength: WavelengthSource) -> None:
     """copies the sources' parameter blocks of config `i` into the C-ABI run parameters"""
-    if not isinstance(source, HostLightSource):
+    if type(source) in _CHERENKOV_FAMILY:
+        _fillCherenkovFamily(P.light, i, source)
+    elif not isinstance(source, HostLightSource):
         l = source._getParamsBlock("LightParams", i)
         for k, c in enumerate("xyz"):
             P.light.position[k] = getattr(l.position, c)
@@ -414,6 +615,31 @@ def fillSourceParams(P: capi.RunParams, i: int, source: LightSource, wavelength:
         P.wavelength.table[0], P.wavelength.table[1] = w._table & 0xFFFFFFFF, (w._table >> 32) & 0xFFFFFFFF
     else:
         P.wavelength.p0 = w.wavelength
+
+
+def _fillCherenkovFamily(L: capi.LightParams, i: int, source: LightSource) -> None:
+    """the parameter block of a Cherenkov-family source is the reference's uniform block, field by field"""
+    def vec(dst, src):
+        for k, c in enumerate("xyz"):
+            dst[k] = getattr(src, c)
+
+    if isinstance(source, CherenkovLightSource):
+        b, d = source._getParamsBlock("LightParams", i), L.cherenkov
+        vec(d.trackStart, b.trackStart), vec(d.trackEnd, b.trackEnd), vec(d.trackDir, b._trackDir)
+        d.startTime, d.endTime, d.trackDist = b.startTime, b.endTime, b._trackDist
+    elif isinstance(source, CherenkovTrackLightSource):
+        b = source._getParamsBlock("TrackParams", i)
+        L.cherenkovTrack.track[0], L.cherenkovTrack.track[1] = b._track.lo, b._track.hi
+    elif isinstance(source, MuonTrackLightSource):
+        b, d = source._getParamsBlock("MuonTrackParams", i), L.muonTrack
+        vec(d.startPosition, b.startPosition), vec(d.endPosition, b.endPosition)
+        d.startTime, d.endTime = b.startTime, b.endTime
+        d.energyScale, d.a_angular, d.b_angular = b._energyScale, b._a_angular, b._b_angular
+    else:
+        b, d = source._getParamsBlock("CascadeParams", i), L.cascade
+        vec(d.startPosition, b.startPosition), vec(d.direction, b.direction)
+        d.startTime, d.effectiveLength = b.startTime, b.effectiveLength
+        d.a_angular, d.b_angular, d.a_long, d.b_long = b.a_angular, b.b_angular, b.a_long, b.b_long
 
 
 def uploadSourceQueues(program, i: int, source: LightSource, wavelength: WavelengthSource) -> None:

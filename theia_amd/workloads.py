@@ -113,7 +113,8 @@ def config1_volume(batch: int = 100_000, *, polarized: bool = False, stats: bool
 
 def config2_sphere(batch: int = 1 << 20, *, polarized: bool = False, stats: bool = False, track: bool = False,
                    guide: bool = True, mu_a: float = 0.05, mu_s: float = 0.005, g: float = 0.5,
-                   maxPathLength: int = 10, key: int = 0xC0FFEE, subdivide: int = 0, custom_guide=None, rng=None, response=None) -> Scenario:
+                   maxPathLength: int = 10, key: int = 0xC0FFEE, subdivide: int = 0, custom_guide=None, rng=None, response=None,
+                   light=None, photons=None) -> Scenario:
     """BASELINE config 2 = sphere-in-medium (reference tests/test_trace_energy.py:187-337,
     Crosscheck geometry): detector sphere r=5 m at the origin, light 6 m away."""
     model = EnergyTestModel(mu_a, mu_s, g)
@@ -126,8 +127,10 @@ def config2_sphere(batch: int = 1 << 20, *, polarized: bool = False, stats: bool
     target = meshes.createInstance("sphere", "det", trafo, detectorId=0)
     scene = Scene([target], store.material, medium=store.media["homogenous"])
     lam = 400.0 * u.nm
-    photons = UniformWavelengthSource(lambdaRange=(lam, lam))
-    light = SphericalLightSource(position=(-6.0, 0.0, 0.0) * u.m, timeRange=(30.0, 30.0) * u.ns, budget=1e9)
+    if photons is None:
+        photons = UniformWavelengthSource(lambdaRange=(lam, lam))
+    if light is None:
+        light = SphericalLightSource(position=(-6.0, 0.0, 0.0) * u.m, timeRange=(30.0, 30.0) * u.ns, budget=1e9)
     if response is None:
         response = HistogramHitResponse(UniformValueResponse(), nBins=30, binSize=20.0, t0=0.0, normalization=1 / batch)
     rng = PhiloxRNG(key=key) if rng is None else rng
