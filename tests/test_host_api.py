@@ -328,3 +328,37 @@ def test_example03_shared_stages_between_pipelines(backend):
     assert sphereSignal[1] > 0
     # different sources, different curves: the shared response returned each pipeline's own result
     assert pencilSignal.sum() > sphereSignal.sum() and not np.allclose(pencilSignal, sphereSignal, rtol=0.1)
+
+
+def test_addresses_keep_their_memory_alive(backend):
+    """theia hands device addresses around as integers; a tracer built inside a function from the addresses of a material store that
+    dies with the function must not read freed memory (a GPU memory fault on HIP): the addresses hold on to the allocation"""
+    import gc
+    import weakref
+
+    import theia.light
+    import theia.material
+    import theia.random
+    import theia.response
+    import theia.target
+    import theia.trace
+    from theia.testing import WaterTestModel
+
+    def build():
+        store = theia.material.MaterialStore([], media=[WaterTestModel().createMedium()])
+        address = store.media["water"]
+        assert isinstance(address, int) and address + 0 == int(address) and type(address + 0) is int
+        rng = theia.random.PhiloxRNG(key=5)
+        response = theia.response.HistogramHitResponse(theia.response.UniformValueResponse(), nBins=20, binSize=10.0 * u.ns)
+        tracer = theia.trace.VolumeForwardTracer(4096, theia.light.SphericalLightSource(budget=1.0e3), theia.target.SphereTarget(position=(3.0, 0.0, 0.0), radius=1.0),
+                                                 theia.light.ConstWavelengthSource(), response, rng, medium=address, nScattering=5)
+        return tracer, response, weakref.ref(store._blob)
+
+    tracer, response, blob = build()
+    gc.collect()
+    assert blob() is not None  # the store is gone, its memory is not
+    pl.runPipeline(tracer.collectStages())
+    assert response.result(0).sum() > 0
+    del tracer
+    gc.collect()
+    assert blob() is None

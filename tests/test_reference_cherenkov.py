@@ -509,6 +509,26 @@ def test_scene_tracer_with_a_muon_track_hip_matches_oracle_and_overlaps():
         _backend._backend = prev
 
 
+def test_an_event_of_particles_through_two_pipelines(backend):
+    """examples/neutrino_event.py in small: a muon and its cascades, each particle one task of a scheduler over two pipelines whose
+    light sources take their parameters from `createParamsFromParticle` (the flow of the reference's example 03)"""
+    import importlib.util
+    import os
+
+    spec = importlib.util.spec_from_file_location("neutrino_event", os.path.join(os.path.dirname(os.path.dirname(__file__)), "examples", "neutrino_event.py"))
+    ev = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ev)
+    pipelines, response, _owners = ev.build(8192)
+    tasks = ev.event(5)
+    assert [name for name, _ in tasks] == ["track"] + ["cascade"] * 5
+    total, curves = ev.trace(pipelines, response, tasks)
+    assert len(curves) == 6 and total.sum() > 0 and curves[0].sum() > 0
+    assert sum(c.sum() > 0 for c in curves[1:]) >= 3  # (a low-energy cascade far from the module may leave nothing in 8192 photons)
+    # the same event again: same parameters, other random numbers (the generator moved on)
+    again, _ = ev.trace(pipelines, response, tasks)
+    assert not np.array_equal(total, again) and abs(again.sum() / total.sum() - 1.0) < 0.5
+
+
 # ---- theia.cascades (tests/test_cascades.py:8-33) ------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("pType", list(theia.cascades.ParticleType))

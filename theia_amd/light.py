@@ -683,6 +683,7 @@ class LightSampler(PipelineStage):
         if medium is None and scene is not None:
             medium = scene.medium
         medium = medium or 0
+        self._mediumOwner = medium  # (a `DeviceAddress` keeps the material store's memory alive as long as this sampler)
         self._batchSize, self._capacity, self._scene, self._source = batchSize, capacity, scene, source
         self._retrieve, self._polarized, self._rng, self._wavelengthSource = retrieve, polarized, rng, wavelengthSource
         self._code = b"" if code is None else code

@@ -68,6 +68,21 @@ class DeviceBlob:
             pass
 
 
+class DeviceAddress(int):
+    """A device address that keeps the allocation it points into alive. theia hands addresses around as plain integers
+    (`store.media["water"]`, `scene.medium`); here the integer also holds a reference to its `DeviceBlob`, so that a function which
+    builds a material store, makes a tracer from its addresses and returns only the tracer does not leave the tracer reading freed
+    memory. Arithmetic gives plain integers."""
+
+    def __new__(cls, address: int, owner) -> "DeviceAddress":
+        self = super().__new__(cls, int(address))
+        self.owner = owner
+        return self
+
+    def __reduce__(self):
+        return (int, (int(self),))
+
+
 def uploadTables(data: list) -> tuple[DeviceBlob, list[int]]:
     """Uploads the given arrays as consecutive tables; returns the allocation and
     the device address of every table (src/theia/lookup.py:101-131)."""

@@ -351,7 +351,7 @@ class Scene:
         self._backend = _backend.get()
         self._handle = self._backend.scene_create(meshes, descs)
         self._instances = instances
-        self._keepalive = materials  # the proxy keeps the MaterialStore blob alive
+        self._keepalive = materials  # (its values are `DeviceAddress`es: they keep the MaterialStore's blob alive)
         #: device address of the medium surrounding the instances (0 = vacuum); plain attribute
         self.medium = medium
         #: rays leaving this box are lost; default: a cube of 2 km around the origin

@@ -368,6 +368,7 @@ class VolumeForwardTracer(Tracer):
                         capacity=capacity, nRNGSamples=draws, maxHitsPerThread=hits, polarized=polarized)
         self._source, self._wavelengthSource, self._rng, self._target, self._callback = source, wavelengthSource, rng, target, callback
         self._switches = {"nScattering": nScattering, "direct": direct, "mis": mis}
+        self._mediumOwner = medium  # (a `DeviceAddress` keeps the material store's memory alive as long as this tracer)
         self.setParams(medium=medium, objectId=objectId, maxTime=maxTime, scatterCoefficient=scatterCoefficient)
         self._setBox(traceBBox)
         srcFlags, lightCap, lamCap = sourceSpec(source, wavelengthSource)
@@ -459,6 +460,7 @@ class SceneForwardTracer(Tracer):
                           "noTransmission": bool(disableTransmission), "noBorder": bool(disableVolumeBorder),
                           "refractedDir": bool(useRefractedHitDir)}
         box = scene.bbox
+        self._mediumOwner = (scene.medium, sourceMedium)
         self.setParams(sourceMedium=scene.medium if sourceMedium is None else sourceMedium, targetId=targetId, maxTime=maxTime,
                        scatterCoefficient=scatterCoefficient, _maxDist=box.diagonal, _lowerBBoxCorner=box.lowerCorner,
                        _upperBBoxCorner=box.upperCorner)
