@@ -55,24 +55,42 @@ THX_DEV float particleEvalEmissionAngle(float n, float a, float b, float cos_the
     return thx_exp(-b * thx_pow(x, a)) * thx_pow(x, a - 1.0f) * norm;
 }
 // random.gamma.glsl:8-31: Cheng's GA rejection sampler; alpha < 1 through alpha + 1
+// (in two halves -- what is fixed by alpha, and one proposal -- so that the balanced sampler kernel of kernels_misc.hip can run the same
+// arithmetic with another photon in every lane and iteration)
+struct GammaGA {
+    float alpha, a, b, c; // alpha: of the distribution the proposals are made for (the given one, or + 1 below 1)
+    bool lifted;          // the given alpha was below 1: a sample is scaled with u^(1 / alpha) of one more draw, made first
+    float invAlpha;       // 1 / the given alpha
+};
+THX_DEV GammaGA gammaSetup(float alpha) {
+    GammaGA g;
+    g.lifted = alpha < 1.0f;
+    g.invAlpha = 1.0f / alpha;
+    if (g.lifted) alpha += 1.0f;
+    g.alpha = alpha;
+    g.a = sqrtf(2.0f * alpha - 1.0f);
+    g.b = alpha - thx_log(4.0f);
+    g.c = alpha + 1.0f / alpha;
+    return g;
+}
+template <class V>
+THX_DEV float gammaScale(Lane<V>& L, const GammaGA& g) { return g.lifted ? thx_pow(draw(L), g.invAlpha) : 1.0f; }
+// one proposal: true = accepted, x is the sample (before the scale)
+template <class V>
+THX_DEV bool gammaPropose(Lane<V>& L, const GammaGA& g, float& x) {
+    float u0, u1;
+    draw2(L, u0, u1);
+    const float v = g.a * thx_log(u0 / (1.0f - u0));
+    x = g.alpha * thx_exp(v);
+    return g.b + g.c * v - x >= thx_log(u0 * u0 * u1) || !(u0 == u0); // (a NaN draw cannot happen; no endless loop if it ever did)
+}
 template <class V>
 THX_DEV float sampleGamma(Lane<V>& L, float alpha) {
-    float scale = 1.0f;
-    if (alpha < 1.0f) {
-        scale = thx_pow(draw(L), 1.0f / alpha);
-        alpha += 1.0f;
-    }
-    const float a = sqrtf(2.0f * alpha - 1.0f);
-    const float b = alpha - thx_log(4.0f);
-    const float c = alpha + 1.0f / alpha;
-    while (true) {
-        float u0, u1;
-        draw2(L, u0, u1);
-        const float v = a * thx_log(u0 / (1.0f - u0));
-        const float x = alpha * thx_exp(v);
-        if (b + c * v - x >= thx_log(u0 * u0 * u1)) return scale * x;
-        if (!(u0 == u0)) return scale * x; // (a NaN draw cannot happen; every lane must leave the loop if it ever did)
-    }
+    const GammaGA g = gammaSetup(alpha);
+    const float scale = gammaScale(L, g);
+    float x;
+    while (!gammaPropose(L, g, x)) {}
+    return scale * x;
 }
 // a Cherenkov photon: on the cone of half angle acos(1 / n) around the particle's direction, linearly polarized in the plane of
 // the two directions (lightsource.cherenkov.simple.glsl:37-57, lightsource.cherenkov.track.glsl:48-77)
@@ -93,6 +111,24 @@ THX_DEV SourceRay cherenkovRay(f3 pos, f3 particleDir, float n, float phiDraw, f
     return r;
 }
 THX_DEV f3 mix3(f3 a, f3 b, float t) { return f3{mixf(a.x, b.x, t), mixf(a.y, b.y, t), mixf(a.z, b.z, t)}; }
+
+// lightsource.particles.cascade.glsl:46-68: the photon of a cascade whose depth sample (gamma distributed, in units of b_long) is given
+template <class V>
+THX_DEV SourceRay cascadeRay(Lane<V>& L, float wavelength, float n, float gammaSample) {
+    const THX_KERNARG thx_cascade_params& cascade = coldArgs().p.light.cascade;
+    const f3 dir = ld3(cascade.direction);
+    const float z = gammaSample * cascade.b_long;
+    const f3 rayPos = ld3(cascade.startPosition) + dir * z;
+    const float time = cascade.startTime + z * INV_SPEED_OF_LIGHT;
+    float u0, u1;
+    draw2(L, u0, u1);
+    const float phi = TWO_PI * u0;
+    const float cos_theta = particleSampleEmissionAngle(n, cascade.a_angular, cascade.b_angular, u1);
+    const f3 rayDir = mul(createLocalCOSY(dir), sphericalToCartessian(phi, cos_theta));
+    float contrib = cascade.effectiveLength;
+    if ((L.a->flags & THX_FLAG_FRANK_TAMM_IS) == 0u) contrib *= frankTammParticle(wavelength, n);
+    return sourceRay<V>(rayPos, rayDir, time, contrib);
+}
 
 // forward sampleLight of lightsource.cherenkov.simple.glsl:20-58, lightsource.cherenkov.track.glsl:23-78,
 // lightsource.particles.muon.glsl:29-60, lightsource.particles.cascade.glsl:41-69
@@ -145,20 +181,8 @@ THX_DEV SourceRay sampleCherenkovFamily(Lane<V>& L, float wavelength, float n) {
         if (applyFrankTamm) contrib *= frankTammParticle(wavelength, n);
         return sourceRay<V>(position, rayDir, startTime, contrib);
     }
-    default: { // THX_FLAG_LIGHT_CASCADE
-        const f3 dir = ld3(light.cascade.direction);
-        const float z = sampleGamma(L, light.cascade.a_long) * light.cascade.b_long;
-        const f3 rayPos = ld3(light.cascade.startPosition) + dir * z;
-        const float time = light.cascade.startTime + z * INV_SPEED_OF_LIGHT;
-        float u0, u1;
-        draw2(L, u0, u1);
-        const float phi = TWO_PI * u0;
-        const float cos_theta = particleSampleEmissionAngle(n, light.cascade.a_angular, light.cascade.b_angular, u1);
-        const f3 rayDir = mul(createLocalCOSY(dir), sphericalToCartessian(phi, cos_theta));
-        float contrib = light.cascade.effectiveLength;
-        if (applyFrankTamm) contrib *= frankTammParticle(wavelength, n);
-        return sourceRay<V>(rayPos, rayDir, time, contrib);
-    }
+    default: // THX_FLAG_LIGHT_CASCADE
+        return cascadeRay<V>(L, wavelength, n, sampleGamma(L, light.cascade.a_long));
     }
 }
 

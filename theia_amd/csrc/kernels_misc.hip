@@ -155,6 +155,24 @@ hipError_t launchReplay(const LaunchArgs& args, const uint32_t* in_queue, uint32
 // LightSampler (lightsource.sample.glsl:52-75): sample idx + base of the wavelength and light source
 // -> item idx of the two output queues (count + structure-of-arrays columns)
 template <bool POL>
+THX_DEV void putSample(uint32_t idx, const SourceRay& ray, const WavelengthSample& photon, uint32_t dim, uint32_t* __restrict__ light_out,
+                       uint32_t* __restrict__ lam_out, uint32_t capacity, bool with_dim) {
+    float* col = reinterpret_cast<float*>(light_out + 1) + idx;
+    auto put = [&](float v) { *col = v; col += capacity; };
+    put(ray.position.x); put(ray.position.y); put(ray.position.z);
+    put(ray.direction.x); put(ray.direction.y); put(ray.direction.z);
+    if constexpr (POL) {
+        put(ray.stokes.x); put(ray.stokes.y); put(ray.stokes.z); put(ray.stokes.w);
+        put(ray.polRef.x); put(ray.polRef.y); put(ray.polRef.z);
+    }
+    put(ray.startTime); put(ray.contrib);
+    float* w = reinterpret_cast<float*>(lam_out + 1) + idx;
+    w[0] = photon.wavelength;
+    w[capacity] = photon.contrib;
+    if (with_dim) w[2u * capacity] = __uint_as_float(dim); // a tracer's own queue: the RNG dimension the photon goes on with
+}
+
+template <bool POL>
 __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs args, uint32_t* __restrict__ light_out,
                                                               uint32_t* __restrict__ lam_out, uint32_t capacity, bool with_dim) {
     using V = Variant<POL, true, false, false, 0, 1>;
@@ -172,20 +190,80 @@ __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs a
     const uint64_t medium = (uint64_t)args.p.volume.medium[0] | ((uint64_t)args.p.volume.medium[1] << 32); // SampleParams.medium
     const MediumConstants constants = lookUpMedium(medium, photon.wavelength, L.cnt);
     const SourceRay ray = (args.flags & THX_FLAG_LIGHT_KIND_MASK) ? sampleCherenkovFamily(L, photon.wavelength, constants.n) : sampleLight(L);
-    float* col = reinterpret_cast<float*>(light_out + 1) + idx;
-    auto put = [&](float v) { *col = v; col += capacity; };
-    put(ray.position.x); put(ray.position.y); put(ray.position.z);
-    put(ray.direction.x); put(ray.direction.y); put(ray.direction.z);
-    if constexpr (POL) {
-        put(ray.stokes.x); put(ray.stokes.y); put(ray.stokes.z); put(ray.stokes.w);
-        put(ray.polRef.x); put(ray.polRef.y); put(ray.polRef.z);
-    }
-    put(ray.startTime); put(ray.contrib);
-    float* w = reinterpret_cast<float*>(lam_out + 1) + idx;
-    w[0] = photon.wavelength;
-    w[capacity] = photon.contrib;
-    if (with_dim) w[2u * capacity] = __uint_as_float(L.dim); // a tracer's own queue: the RNG dimension the photon goes on with
+    putSample<POL>(idx, ray, photon, L.dim, light_out, lam_out, capacity, with_dim);
     if (idx == 0) {
+        light_out[0] = count;
+        lam_out[0] = count;
+    }
+}
+
+// The same for a ParticleCascadeLightSource, whose depth sample comes out of a rejection loop (random.gamma.glsl) that the shader's
+// constants make long -- five proposals per sample on average at alpha = 6, the slowest of 64 lanes three times that: with one
+// photon per lane a wavefront runs the loop at a third of its lanes. Here a wavefront works through kCascadePerWave photons: in the
+// loop a lane whose proposal was accepted takes the next photon of the wave's range at once (ballot + prefix count: no atomics, and
+// which lane draws which photon changes nothing -- a photon's random numbers are addressed by its index), the accepted samples and
+// the RNG dimensions behind them wait in LDS, and the rest of the sampling runs afterwards, photon by photon, with all lanes.
+// Same arithmetic per photon as samplerKernel (tests/test_reference_cherenkov.py holds both against the oracle item by item).
+constexpr uint32_t kCascadePerWave = 1024;
+template <bool POL>
+__global__ void __launch_bounds__(kReplayBlock) cascadeSamplerKernel(const LaunchArgs args, uint32_t* __restrict__ light_out,
+                                                                     uint32_t* __restrict__ lam_out, uint32_t capacity, bool with_dim) {
+    using V = Variant<POL, true, false, false, 0, 1>;
+    __shared__ float depth[kReplayBlock / 64][kCascadePerWave];
+    __shared__ uint32_t dimAfter[kReplayBlock / 64][kCascadePerWave];
+    const uint32_t count = args.p.dispatch.batchSize;
+    const uint32_t lane = threadIdx.x & 63u, waveInBlock = threadIdx.x >> 6;
+    const uint32_t first = (blockIdx.x * (kReplayBlock / 64) + waveInBlock) * kCascadePerWave;
+    if (first >= count) return; // (the whole wavefront)
+    const uint32_t last = min(first + kCascadePerWave, count);
+    float* const zs = depth[waveInBlock];
+    uint32_t* const ds = dimAfter[waveInBlock];
+    Lane<V> L;
+    L.a = &args;
+    L.stackBase = 0;
+    L.cnt.clear();
+    const GammaGA g = gammaSetup(args.p.light.cascade.a_long);
+    // the depth samples
+    uint32_t next = first; // (the same in every lane)
+    uint32_t mine = 0;
+    bool have = false;
+    float scale = 1.0f;
+    while (true) {
+        const unsigned long long idle = __ballot(!have);
+        if (!have) {
+            const uint32_t cand = next + (uint32_t)__popcll(idle & ((1ull << lane) - 1ull));
+            if (cand < last) {
+                mine = cand;
+                have = true;
+                L.idx = mine + args.p.photon_offset;
+                L.local = L.idx;
+                L.dim = 0;
+                (void)sampleWavelength(L); // (its draws come first)
+                scale = gammaScale(L, g);
+            }
+        }
+        next += (uint32_t)__popcll(idle);
+        if (__ballot(have) == 0ull) break;
+        float x;
+        if (have && gammaPropose(L, g, x)) {
+            zs[mine - first] = scale * x;
+            ds[mine - first] = L.dim;
+            have = false;
+        }
+    }
+    // everything else, one photon per lane and pass
+    const uint64_t medium = (uint64_t)args.p.volume.medium[0] | ((uint64_t)args.p.volume.medium[1] << 32);
+    for (uint32_t idx = first + lane; idx < last; idx += 64u) {
+        L.idx = idx + args.p.photon_offset;
+        L.local = L.idx;
+        L.dim = 0;
+        const WavelengthSample photon = sampleWavelength(L);
+        const MediumConstants constants = lookUpMedium(medium, photon.wavelength, L.cnt);
+        L.dim = ds[idx - first];
+        const SourceRay ray = cascadeRay<V>(L, photon.wavelength, constants.n, zs[idx - first]);
+        putSample<POL>(idx, ray, photon, L.dim, light_out, lam_out, capacity, with_dim);
+    }
+    if (first == 0u && lane == 0u) {
         light_out[0] = count;
         lam_out[0] = count;
     }
@@ -194,8 +272,17 @@ __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs a
 hipError_t launchSampler(const LaunchArgs& args, bool polarized, uint32_t* light_out, uint32_t* lam_out, uint32_t capacity,
                          bool with_dim, hipStream_t stream) {
     const uint32_t count = args.p.dispatch.batchSize;
+    if (count == 0) return hipSuccess;
+    if ((args.flags & THX_FLAG_LIGHT_KIND_MASK) == THX_FLAG_LIGHT_CASCADE) {
+        const uint32_t perBlock = (kReplayBlock / 64) * kCascadePerWave;
+        const uint32_t grid = (count + perBlock - 1) / perBlock;
+        if (polarized)
+            hipLaunchKernelGGL(cascadeSamplerKernel<true>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity, with_dim);
+        else
+            hipLaunchKernelGGL(cascadeSamplerKernel<false>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity, with_dim);
+        return hipGetLastError();
+    }
     const uint32_t grid = (count + kReplayBlock - 1) / kReplayBlock;
-    if (grid == 0) return hipSuccess;
     if (polarized)
         hipLaunchKernelGGL(samplerKernel<true>, dim3(grid), dim3(kReplayBlock), 0, stream, args, light_out, lam_out, capacity, with_dim);
     else
