@@ -909,10 +909,13 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
     a.wavelength_capacity = t->desc.wavelength_queue_capacity;
     const bool tracing = t->desc.kind == THX_TRACER_VOLUME_FORWARD || t->desc.kind == THX_TRACER_SCENE_FORWARD;
     const bool presample = tracing && (t->desc.flags & THX_FLAG_LIGHT_KIND_MASK) != 0u;
-    if (presample && !t->preLight[lane]) { // first batch of this lane
+    // (one pair of queues per lane: a lane's batches run one after the other on its stream. A caller that brings its own stream
+    // orders the batches itself: a pair per slot then)
+    const uint32_t pq = stream ? cfg : lane;
+    if (presample && !t->preLight[pq]) { // first batch of this lane
         const bool pol = (t->desc.flags & THX_FLAG_POLARIZED) != 0u;
-        THX_HIP(hipMalloc((void**)&t->preLight[lane], 4 + (pol ? 15 : 8) * 4 * (size_t)t->desc.capacity));
-        THX_HIP(hipMalloc((void**)&t->preLam[lane], 4 + 3 * 4 * (size_t)t->desc.capacity));
+        THX_HIP(hipMalloc((void**)&t->preLight[pq], 4 + (pol ? 15 : 8) * 4 * (size_t)t->desc.capacity));
+        THX_HIP(hipMalloc((void**)&t->preLam[pq], 4 + 3 * 4 * (size_t)t->desc.capacity));
     }
     if ((t->lightIn[hostCfg] && batch > t->desc.light_queue_capacity) || (t->lamIn[hostCfg] && batch > t->desc.wavelength_queue_capacity))
         return fail(THX_ERR_INVALID, "batchSize exceeds the capacity of the host light / wavelength source");
@@ -945,13 +948,13 @@ int thx_tracer_run(thx_tracer* t, uint32_t cfg, const thx_run_params* params, vo
             sa.p.volume.medium[0] = medium[0];
             sa.p.volume.medium[1] = medium[1];
             const bool pol = (t->desc.flags & THX_FLAG_POLARIZED) != 0u;
-            THX_HIP(launchSampler(sa, pol, t->preLight[lane], t->preLam[lane], t->desc.capacity, true, s));
+            THX_HIP(launchSampler(sa, pol, t->preLight[pq], t->preLam[pq], t->desc.capacity, true, s));
             // ... which the tracing kernel then reads like queues uploaded by the host, RNG dimension included
             a.flags = (a.flags & ~(uint32_t)(THX_FLAG_LIGHT_KIND_MASK | THX_FLAG_FRANK_TAMM_PHOTONS | THX_FLAG_FRANK_TAMM_IS |
                                              THX_FLAG_WAVELENGTH_UNIFORM | THX_FLAG_WAVELENGTH_FUNCTION)) |
                       THX_FLAG_LIGHT_HOST | THX_FLAG_WAVELENGTH_HOST | THX_FLAG_SOURCES_PRESAMPLED | (pol ? THX_FLAG_LIGHT_QUEUE_POLARIZED : 0u);
-            a.light_queue = reinterpret_cast<const float*>(t->preLight[lane] + 1);
-            a.wavelength_queue = reinterpret_cast<const float*>(t->preLam[lane] + 1);
+            a.light_queue = reinterpret_cast<const float*>(t->preLight[pq] + 1);
+            a.wavelength_queue = reinterpret_cast<const float*>(t->preLam[pq] + 1);
             a.light_capacity = a.wavelength_capacity = t->desc.capacity;
         }
         THX_HIP(t->variant.launch(t->mode, a, grid, t->block, t->lds, s));

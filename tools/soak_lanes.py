@@ -19,8 +19,30 @@ from theia_amd.hp import pipeline as pl  # noqa: E402
 
 seconds = float(sys.argv[1]) if len(sys.argv) > 1 else 120.0
 gen = np.random.default_rng(int(sys.argv[2]) if len(sys.argv) > 2 else 1)
+import theia_amd.light as TL  # noqa: E402
+import theia_amd.units as u  # noqa: E402
+
+
+def cherenkov(batch, **kw):
+    """config 2's detector lit by one of the Cherenkov-family sources (sampled by the sampler kernel in front of the tracing kernel:
+    a pair of sample queues per lane)"""
+    kind = kw.pop("family")
+    if kind == 0:
+        light = TL.MuonTrackLightSource((-6.0, -20.0, 2.5), 0.0, (-6.0, 20.0, 2.5), 133.4, 2.0 * u.TeV)
+    elif kind == 1:
+        light = TL.ParticleCascadeLightSource(startPosition=(-6.0, -3.0, 2.5), direction=(0.0, 1.0, 0.0), effectiveLength=500.0, a_angular=0.54,
+                                              b_angular=3.3, a_long=4.2, b_long=0.57)
+    elif kind == 2:
+        light = TL.CherenkovLightSource(trackStart=(-6.0, -20.0, 2.5), trackEnd=(-6.0, 20.0, 2.5), startTime=0.0, endTime=133.4)
+    else:
+        track = TL.ParticleTrack(4)
+        track.setVertices([[-6.0, -20.0, 2.5, 0.0], [-6.0, 0.0, 2.5, 66.7], [-6.5, 20.0, 2.5, 133.4]])
+        light = TL.CherenkovTrackLightSource(track)
+    return S.config2_sphere(batch=batch, light=light, photons=TL.UniformWavelengthSource(lambdaRange=(350.0, 550.0) * u.nm), **kw)
+
+
 makers = [("config2", S.config2_sphere, 600_000), ("config3", S.config3_cube_torus, 150_000), ("config5", S.config5_suzanne_grid, 40_000),
-          ("config1", S.config1_volume, 400_000)]
+          ("config1", S.config1_volume, 400_000), ("cherenkov", cherenkov, 400_000)]
 t0, lists, batches, photons, compared = time.time(), 0, 0, 0, 0
 while time.time() - t0 < seconds:
     name, make, top = makers[gen.integers(len(makers))]
@@ -28,7 +50,9 @@ while time.time() - t0 < seconds:
     stats = bool(gen.integers(2))
     kw = {"stats": stats, "key": int(gen.integers(1 << 40))}
     if name != "config1":
-        kw["polarized"] = bool(gen.integers(2)) if name == "config2" else True
+        kw["polarized"] = bool(gen.integers(2)) if name in ("config2", "cherenkov") else True
+    if name == "cherenkov":
+        kw["family"] = int(gen.integers(4))
     lanes = int(gen.integers(1, 17))
     div = int(gen.integers(1, lanes + 1))
     depth = int(gen.integers(1, 17))
