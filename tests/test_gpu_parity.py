@@ -529,7 +529,17 @@ def test_production_kernel_equals_instrumented(hip_backend, scene):
         assert np.abs(got - want).max() <= 2e-6 * want.sum(), (launch, np.abs(got - want).max() / want.sum())
 
 
-@pytest.mark.parametrize("config", ["config2", "config3", "config5"])
+def _config2_with_cascade(batch, key=0xC0FFEE):
+    """config 2's detector lit by a particle cascade: the sources a tracer samples with its sampler kernel first (api.cpp: thx_tracer_run)"""
+    import theia_amd.light as TL
+    from theia_amd import units as u
+
+    light = TL.ParticleCascadeLightSource(startPosition=(-6.0, -3.0, 2.5), direction=(0.0, 1.0, 0.0), effectiveLength=500.0, a_angular=0.54,
+                                          b_angular=3.3, a_long=4.2, b_long=0.57)
+    return S.config2_sphere(batch=batch, key=key, light=light, photons=TL.UniformWavelengthSource(lambdaRange=(350.0, 550.0) * u.nm))
+
+
+@pytest.mark.parametrize("config", ["config2", "config3", "config5", "config2-cascade"])
 def test_full_size_properties(hip_backend, config):
     """BASELINE.json's scene configurations at their full 10^7 photons per launch, where the oracle cannot follow: properties
     that do not depend on the size. (1) a launch repeated gives the same light curve (sums of the same hits in another
@@ -537,7 +547,7 @@ def test_full_size_properties(hip_backend, config):
     the full batch, add up to it -- the multi-GPU contract; (3) it agrees with a 50 times smaller launch of other photons
     within that launch's statistical error; (4) no launch trips the device error word."""
     n = 10_000_000
-    make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid}[config]
+    make = {"config2": S.config2_sphere, "config3": S.config3_cube_torus, "config5": S.config5_suzanne_grid, "config2-cascade": _config2_with_cascade}[config]
     full = make(batch=n)
     full.rng.autoAdvance = 0  # consecutive batches use the same photons then: the Philox offset stays where it is
     first, again = [h.astype(np.float64) for h in S.run_batches(full, 2)]
