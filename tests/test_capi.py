@@ -139,13 +139,15 @@ def test_no_kernel_spills_vector_registers(tmp_path):
             name = re.search(r"\.name:\s+(\S+)", block).group(1)
             kernels[name] = {k: get(k) for k in ("vgpr_count", "vgpr_spill_count", "sgpr_spill_count", "private_segment_fixed_size")}
     staged = {k: v for k, v in kernels.items() if "sceneStagedKernel" in k}
-    assert len(staged) >= 40, len(staged)  # 4 physics variants x 5 walk forms x {production, instrumented}
+    assert len(staged) >= 48, len(staged)  # 4 physics variants x 6 walk forms x {production, instrumented}
     spilling = {k: v for k, v in kernels.items() if v["vgpr_spill_count"] != 0}
     assert not spilling, spilling
     for k, v in staged.items():
         instrumented = "Lb1ELb1ELi" in k
-        # production variants fit 16 wavefronts per workgroup (128 registers), instrumented ones 12 (168)
-        assert v["vgpr_count"] <= (168 if instrumented else 128), (k, v)
+        # production variants fit 16 wavefronts per workgroup (128 registers), instrumented ones 12 (168); the polarized instrumented
+        # variants of the 4-wide walk (walk form 5) run 8 wavefronts (256): with 168 they were ten registers short
+        wide_pol = instrumented and "VariantILb1E" in k and "Li5E" in k
+        assert v["vgpr_count"] <= (256 if wide_pol else 168 if instrumented else 128), (k, v)
         # SGPR spills live in VGPR lanes: a production kernel touches no scratch memory at all; the instrumented ones keep one
         # small run-time-indexed array of their own there (the per-stage counters), nothing the register allocator put there
         assert v["private_segment_fixed_size"] == (0 if not instrumented else v["private_segment_fixed_size"]) and v["private_segment_fixed_size"] <= 64, (k, v)

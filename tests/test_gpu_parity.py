@@ -90,6 +90,70 @@ def test_ray_query_matches_brute_force(hip, mesh, scale):
     hip.scene_destroy(hs)
 
 
+@pytest.mark.parametrize("mesh,scale", [("sphere", 5.0), ("torus", 1.0), ("suzanne", 1.0), ("cube", 0.5)])
+def test_ray_query_of_4_wide_records_matches_brute_force(hip, mesh, scale, monkeypatch):
+    """large scenes are built with 4-wide records (bvh_build.cpp: emitTree; here forced onto small ones with THX_WIDE=1): the same
+    closest hits as testing every triangle, in two instances of different orientation"""
+    from theia_amd.scene import Transform
+
+    monkeypatch.setenv("THX_WIDE", "1")
+    m = S.bundled_mesh(mesh)
+    meshes = [(m.vertices, m.indices)]
+    inst = [(0, Transform.TRS(scale=scale, rotate=(0.3, 1.0, 0.2, 33.0), translate=(0.5, -0.25, 1.0)).numpy(), 3, 0),
+            (0, Transform.TRS(scale=0.7 * scale, rotate=(1.0, 0.0, 0.2, 71.0), translate=(0.5 + 2.5 * scale, 0.3, 1.0)).numpy(), 4, 0)]
+    hs = hip.scene_create(meshes, inst)
+    ob = OracleBackend(brute_force=True)
+    os_ = ob.scene_create(meshes, inst)
+    o, d = _random_rays(6000, 9, 2.5 * scale)
+    o += np.array([0.5 + 1.2 * scale, -0.25, 1.0], np.float32)
+    got = hip.scene_query(hs, o, d, 1e4)
+    want = ob.scene_query(os_, o, d, 1e4)
+    assert np.array_equal(got[:, 0], want[:, 0])
+    hit = want[:, 0] > 0
+    assert hit.sum() > 300 and len(np.unique(want[hit, 1])) == 2  # both instances
+    assert np.array_equal(got[hit, 1:3], want[hit, 1:3])  # instance, primitive
+    assert np.array_equal(got[hit, 3:].view(np.uint32), want[hit, 3:].view(np.uint32))
+    hip.scene_destroy(hs)
+
+
+@pytest.mark.parametrize("scene", ["config2", "config3", "suzanne-grid"])
+def test_4_wide_walk_traces_the_same_photons(hip_backend, scene, monkeypatch):
+    """The walk of 4-wide records (Walker::visitStraight4 / visitBranchy4; what scenes of 4 096 pair records and more are built with)
+    visits other nodes in another order than the walk of pair records, and finds the same closest hits: every photon's events are
+    the same bit for bit -- with the next three stack slots in LDS (the straight-line visit), with none (every visit through push /
+    pop) and with a mix of both."""
+    make = {"config2": lambda: S.config2_sphere(batch=20000, stats=True, track=True),
+            "config3": lambda: S.config3_cube_torus(batch=20000, polarized=True, stats=True, track=True),
+            "suzanne-grid": lambda: S.config5_suzanne_grid(batch=20000, n_side=4, polarized=True, stats=True, track=True)}[scene]
+    runs = {}
+    for name, env in (("pair records", {"THX_WIDE": "0"}), ("4-wide", {"THX_WIDE": "1"}), ("4-wide, 2 stack entries in LDS", {"THX_WIDE": "1", "THX_STACK_LDS": "2"}),
+                      ("4-wide, 5 stack entries in LDS", {"THX_WIDE": "1", "THX_STACK_LDS": "5"}),
+                      ("4-wide, walks set aside after every round", {"THX_WIDE": "1", "THX_PARK_BELOW": "65", "THX_PARK_ROUNDS": "1"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            sys.__stderr__.write(f"[walk form] {scene}: {name}\n")
+            sys.__stderr__.flush()
+            sc = make()
+            hist = S.run_batches(sc, 1)[0]
+            runs[name] = (hist, sc.tracer.program.read_stats(), sc.tracer.program.read_track(sc.tracer.batchSize))
+    h0, s0, t0 = runs["pair records"]
+    assert h0.sum() > 0 and s0[0] == 20000
+    for name, (h, s, t) in runs.items():
+        assert np.array_equal(t0.view(np.uint32), t.view(np.uint32)), name
+        assert np.array_equal(s0[:13], s[:13]) and s0[16] == s[16], name  # events, queries, hits (nodes / triangles / instance visits differ)
+        assert np.abs(h - h0).max() <= 1e-5 * h0.sum(), name
+    assert 0.8 * s0[13] < runs["4-wide"][1][13] < 1.3 * s0[13]  # about as many box tests (up to four per visit, about half the visits)
+    production = {}
+    for name, env in (("pair records", {"THX_WIDE": "0"}), ("4-wide", {"THX_WIDE": "1"})):
+        with monkeypatch.context() as m:
+            for k, v in env.items():
+                m.setenv(k, v)
+            production[name] = S.run_batches({"config2": lambda: S.config2_sphere(batch=200000), "config3": lambda: S.config3_cube_torus(batch=100000),
+                                              "suzanne-grid": lambda: S.config5_suzanne_grid(batch=50000, n_side=4)}[scene](), 1)[0].astype(np.float64)
+    assert np.abs(production["4-wide"] - production["pair records"]).max() <= 2e-6 * production["pair records"].sum()
+
+
 @pytest.mark.parametrize("mesh,scale", [("sphere", 5.0), ("cube", 0.5), ("torus", 1.0)])
 def test_ray_query_axis_parallel_rays(hip, mesh, scale):
     """rays with exactly zero direction components (1/d = inf) and rays through the centre of the

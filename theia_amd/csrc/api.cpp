@@ -76,6 +76,7 @@ struct thx_scene {
     SceneView view{};
     thx_scene_info info{};
     uint32_t nPairs = 0; // pair records the walk reads (inner nodes of all trees)
+    bool wide = false;   // ... as 4-wide records of two slots each (bvh_build.cpp)
     float lastQueryMs = 0.0f;
     std::vector<void*> allocs;
 };
@@ -464,6 +465,8 @@ int thx_scene_create(thx_ctx* ctx, const thx_mesh_desc* meshes, uint32_t n_meshe
     s->view.geometries = reinterpret_cast<const GeometryGLSL*>(p);
     s->view.tlas = built.frames[0];
     s->view.nInstances = n_instances;
+    s->view.wide = built.wide ? 1u : 0u;
+    s->wide = built.wide;
 
     s->info.n_nodes = (uint32_t)built.nodes.size();
     s->info.n_triangles = (uint32_t)nTriangles;
@@ -585,9 +588,10 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         t->stackDepth = std::min<uint32_t>(kStackDepth, scene->info.max_depth + 2);
         // 16-bit stack entries are read sign-extended (0xFFFE / 0xFFFF = leave the instance / done): every ref = index << 3 | count
         // of the scene has to stay below 0x8000
-        t->stack16 = scene->nPairs < 4096 * kRecordSlots && scene->info.n_triangles < 4096 && scene->info.n_instances < 4096;
+        const uint32_t recordSlots = scene->wide ? 2u : kRecordSlots;
+        t->stack16 = !scene->wide && scene->nPairs < 4096 * recordSlots && scene->info.n_triangles < 4096 && scene->info.n_instances < 4096;
         // (what the bound stands for, checked on the value itself: the largest ref any stack entry of this scene can hold)
-        const uint32_t maxIndex = std::max(std::max(scene->nPairs / kRecordSlots, scene->info.n_triangles), scene->info.n_instances);
+        const uint32_t maxIndex = std::max(std::max(scene->nPairs / recordSlots, scene->info.n_triangles), scene->info.n_instances);
         if (t->stack16 && ((maxIndex << 3) | 7u) >= 0x8000u) { delete t; return fail(THX_ERR_INVALID, "internal: 16-bit stack entries picked for a scene with refs >= 0x8000"); }
         if (const char* env = std::getenv("THX_STACK32")) t->stack16 = t->stack16 && std::atoi(env) == 0;
         // test hook: a stack shallower than the scene needs (the walk then flags ERROR_CODE_TRACE_ABORT)
@@ -601,7 +605,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
     }
     t->mode = (t->debug ? 1u : 0u) | (t->staged ? 2u : 0u);
     if (t->staged) {
-        const uint32_t fullBlock = t->debug ? kStagedBlockDebug : kStagedBlock;
+        const uint32_t fullBlock = t->debug ? (scene->wide && pol ? kStagedBlockDebugWidePol : kStagedBlockDebug) : kStagedBlock;
         t->block = fullBlock;
         if (const char* env = std::getenv("THX_THREADS")) t->block = (uint32_t)std::min<int>((int)fullBlock, std::max(64, std::atoi(env) / 64 * 64));
         size_t budget = (size_t)ctx->prop.maxSharedMemoryPerMultiProcessor - 2048; // whole CU, one workgroup
@@ -613,7 +617,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         // one more slot per lane below entry 0 (dev_walk.hpp: Walker<V, FAST>)
         // (the variants compiled for a stack that is all in LDS do not check for a full stack: only where it cannot fill up)
         const bool stackAllLds = t->stack16 && t->stackLds == t->stackDepth && t->stackDepth >= scene->info.max_depth + 2;
-        t->stackSlots = t->stackLds + 1u;
+        t->stackSlots = t->stackLds + 1u + (scene->wide ? 1u : 0u); // (4-wide walks: one more slot, beyond the LDS part, for the writes of visitStraight4 that nobody reads)
         const uint32_t stackBytes = t->stackSlots * (t->stack16 ? 2u : 4u);
         // The pool comes first: measured on MI355X, 768 -> 1024 photons per CU is worth 14 %.
         // Deep scenes (large per-thread stacks) leave a pool much smaller than the workgroup:
@@ -641,11 +645,12 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
                 t->pool = stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, 0, xr);
             }
         t->pool = std::min(t->pool, kPoolBest);
+        if (scene->wide) t->mode |= 32u; // the variant that walks 4-wide records (32-bit entries)
         if (t->stack16) t->mode |= 4u; // the kernel variant with 16-bit stack entries compiled in ...
         if (stackAllLds) t->mode |= 8u; // ... and with the whole stack in LDS
         // Small scenes: the walk reads its pair records from a copy in LDS if that leaves a pool of kLdsNodeMinPool photons
         // (THX_LDS_NODES=0 / 1: never / whenever it fits at all)
-        if ((t->mode & 4u) && t->block == fullBlock) { // (16-bit stack entries: the variants that exist with the copy)
+        if ((t->mode & 4u) && t->block == fullBlock && !scene->wide) { // (16-bit stack entries: the variants that exist with the copy)
             const size_t nodeBytes = (size_t)scene->nPairs * sizeof(NodePair);
             const uint32_t poolN = std::min(stagedPoolFor(pol, desc->n_bins, stackBytes, budget, t->block, nodeBytes, xr), kPoolBest);
             bool use = nodeBytes <= kLdsNodeMaxBytes && poolN >= kLdsNodeMinPool;

@@ -219,6 +219,63 @@ uint32_t emitTree(BuiltScene& out, uint32_t root, TreeFrame& frame, bool tlas) {
         while (q < 65534 && dequant((uint32_t)q, frame.step[k], frame.origin[k]) < v) ++q;
         return (uint32_t)std::min<int64_t>(q + 1, 65535);
     };
+    if (out.wide) {
+        // 4-wide records (two NodePair slots = one 64-B line each): an inner node's children, the larger inner ones of them replaced
+        // by their own children until there are four. An empty slot is a box no ray can hit (lo > hi). Returns what a walk of this
+        // tree needs of the stack: a visit pushes up to (children - 1) entries before it descends.
+        auto area = [&](uint32_t node) {
+            const BvhNode& n = out.nodes[node];
+            const float dx = n.hi[0] - n.lo[0], dy = n.hi[1] - n.lo[1], dz = n.hi[2] - n.lo[2];
+            return dx * dy + dy * dz + dz * dx;
+        };
+        auto refOf4 = [&](uint32_t node, uint32_t& need, auto&& self) -> uint32_t {
+            const BvhNode& n = out.nodes[node];
+            need = 0;
+            if (n.count != 0) return ((tlas ? out.tlasInstance[n.leftFirst] : n.leftFirst) << 3) | n.count;
+            uint32_t ch[4] = {n.leftFirst, n.leftFirst + 1, 0, 0};
+            int k = 2;
+            while (k < 4) {
+                int open = -1;
+                float best = -1.0f;
+                for (int c = 0; c < k; ++c)
+                    if (out.nodes[ch[c]].count == 0 && area(ch[c]) > best) { best = area(ch[c]); open = c; }
+                if (open < 0) break;
+                const uint32_t left = out.nodes[ch[open]].leftFirst;
+                for (int c = k; c > open + 1; --c) ch[c] = ch[c - 1];
+                ch[open] = left;
+                ch[open + 1] = left + 1;
+                ++k;
+            }
+            const uint32_t index = (uint32_t)out.pairs.size() / 2;
+            out.pairs.emplace_back();
+            out.pairs.emplace_back();
+            uint32_t w[16];
+            for (int c = 0; c < 4; ++c) {
+                if (c >= k) {
+                    w[4 * c + 0] = w[4 * c + 1] = w[4 * c + 2] = 0x0000FFFFu; // lo = 65535, hi = 0
+                    w[4 * c + 3] = 0xFFFFFFFFu;
+                    continue;
+                }
+                const BvhNode& cn = out.nodes[ch[c]];
+                uint32_t l[3], h[3];
+                for (int a = 0; a < 3; ++a) { l[a] = qlo(cn.lo[a], a); h[a] = qhi(cn.hi[a], a); }
+                for (int a = 0; a < 3; ++a) w[4 * c + a] = l[a] | (h[a] << 16);
+            }
+            uint32_t deepest = 0;
+            for (int c = 0; c < k; ++c) {
+                uint32_t sub = 0;
+                w[4 * c + 3] = self(ch[c], sub, self);
+                deepest = std::max(deepest, sub);
+            }
+            std::memcpy(out.pairs[2 * (size_t)index].w, w, 32);
+            std::memcpy(out.pairs[2 * (size_t)index + 1].w, w + 8, 32);
+            need = (uint32_t)(k - 1) + deepest;
+            return index << 3;
+        };
+        uint32_t need = 0;
+        frame.rootRef = refOf4(root, need, refOf4);
+        return need;
+    }
     // inner nodes of this tree get consecutive pair indices in depth-first order
     auto refOf = [&](uint32_t node, auto&& self) -> uint32_t {
         const BvhNode& n = out.nodes[node];
@@ -258,7 +315,7 @@ void emitPairs(BuiltScene& out) {
         w.rootRef = f.rootRef;
         w.pad = 0;
     }
-    (void)top;
+    if (out.wide) out.maxDepth = top + 1 + deepest;
 }
 } // namespace
 
@@ -376,6 +433,19 @@ BuiltScene buildScene(const thx_mesh_desc* meshes, uint32_t n_meshes,
         throw std::runtime_error("scene hierarchy deeper than the traversal stack");
     for (uint32_t k = 0; k < n_instances; ++k) out.instances[k].frame = 1 + instances[k].mesh;
     emitPairs(out);
+    // Large scenes get 4-wide records (bvh_build.h: kWideFromPairs; THX_WIDE=0 / 1: never / always -- the walk's forms are tested on small scenes)
+    bool wantWide = out.pairs.size() >= kWideFromPairs;
+    if (const char* e = std::getenv("THX_WIDE")) wantWide = std::atoi(e) != 0;
+    if (wantWide) {
+        const uint32_t binaryDepth = out.maxDepth;
+        out.wide = true;
+        emitPairs(out);
+        if (out.maxDepth + 1 > max_stack_depth) { // (three entries per 4-wide level: deeper than the stack bound -> stay binary)
+            out.wide = false;
+            out.maxDepth = binaryDepth;
+            emitPairs(out);
+        }
+    }
     return out;
 }
 

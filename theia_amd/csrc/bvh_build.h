@@ -11,6 +11,10 @@
 
 namespace thx {
 
+// scenes with at least this many pair records are built with 4-wide records: they need 32-bit stack entries anyway (api.cpp: stack16),
+// their hierarchies are far larger than any cache, and a 4-wide record is one 64-B line where a pair record uses half of one
+constexpr size_t kWideFromPairs = 4096;
+
 struct BuiltScene {
     std::vector<BvhNode> nodes;         // [TLAS | BLAS 0 | BLAS 1 | ...] (host only: the source of `pairs`)
     std::vector<NodePair> pairs;        // what the device walks: one record per inner node
@@ -20,6 +24,7 @@ struct BuiltScene {
     std::vector<InstanceRecord> instances;
     std::vector<uint32_t> tlasInstance; // TLAS leaf slot -> instance id (host only: the leaf refs of `pairs` hold the ids)
     std::vector<WalkInstance> walkInstances; // by instance id
+    bool wide = false;                  // `pairs` holds 4-wide records (two slots each) instead of pair records (emitTree)
     uint32_t tlasRoot = 0;
     uint32_t maxDepth = 0;              // TLAS depth + 1 + deepest BLAS (stack bound)
     std::vector<uint32_t> blasRoot;     // per mesh

@@ -30,9 +30,12 @@ struct Variant {
     // wavefronts gathering) when it hits and the L2's 500+ when it does not (profiles/r03_mem_latency.txt).
     // 4: as 1 (16-bit entries, deep part of the stack in global memory) with the pair records in LDS: deep scenes whose
     // records still fit.
-    static constexpr bool S16 = STACK_ != 0;
+    // 5: as 0 (32-bit entries) for scenes built with 4-wide records (SceneView::wide: large meshes), which the staged kernel walks with
+    // Walker::visitStraight4.
+    static constexpr bool S16 = STACK_ != 0 && STACK_ != 5;
     static constexpr bool SPILL = STACK_ != 2 && STACK_ != 3;
     static constexpr bool LDSN = STACK_ == 3 || STACK_ == 4;
+    static constexpr bool WIDE = STACK_ == 5;
 };
 
 // ray.glsl:22-36 (+163-170 polarized part)

@@ -274,6 +274,7 @@ struct Walker {
     const char* tris; // TriRecord array, as bytes
     uint32_t depth, ldsN;
     bool s16;
+    bool wide; // the scene has 4-wide records (SceneView::wide; the same for every lane of every wavefront of a launch)
     THX_GLOBAL uint32_t* spill; // this wavefront's deep entries (beyond ldsN): entry e of lane l at e * 64 + l (wave-uniform: lives in SGPRs)
     uint32_t* stack32;
     uint16_t* stack16;
@@ -295,6 +296,8 @@ struct Walker {
         tris = reinterpret_cast<const char*>(L.a->scene.tris);
         depth = L.a->stack_depth;
         ldsN = L.a->stack_lds;
+        // (the staged kernel has variants of its own for 4-wide scenes; the one-variant kernels around it -- probes, lane kernel -- look)
+        wide = FAST ? V::WIDE : L.a->scene.wide != 0u;
         // Deep entries: the host sizes the LDS part for what rays typically use and lets the rest of the worst case
         // live in global memory (L2), so the depth of a scene's hierarchy does not come out of the photon pool.
         spill = (THX_GLOBAL uint32_t*)(L.a->spill) + (size_t)((blockIdx.x * (blockDim.x >> 6) + (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6))) * (depth - ldsN)) * 64u;
@@ -528,6 +531,69 @@ struct Walker {
         cur = none ? below : nearRef;
     }
 
+    // ---- 4-wide records (SceneView::wide): four children per visit, the hit ones nearest first ----
+    // Order of two children: by entry distance, equal distances (and misses, all at +inf) by their position in the record.
+    // rank = how many of the others come first; the nearest hit child is visited next, the other hit ones go on the stack with
+    // rank 1 on top. Both forms below make the same visits in the same order.
+    struct Quad {
+        float t[4];
+        uint32_t r[4], rank[4], nhit;
+    };
+    THX_DEV Quad quadOrder(uint32_t r0, uint32_t r1, uint32_t r2, uint32_t r3, float t0, float t1, float t2, float t3) {
+        Quad q;
+        q.t[0] = t0; q.t[1] = t1; q.t[2] = t2; q.t[3] = t3;
+        q.r[0] = r0; q.r[1] = r1; q.r[2] = r2; q.r[3] = r3;
+        const uint32_t b10 = t1 < t0, b20 = t2 < t0, b30 = t3 < t0, b21 = t2 < t1, b31 = t3 < t1, b32 = t3 < t2;
+        q.rank[0] = b10 + b20 + b30;
+        q.rank[1] = (1u - b10) + b21 + b31;
+        q.rank[2] = (1u - b20) + (1u - b21) + b32;
+        q.rank[3] = (1u - b30) + (1u - b31) + (1u - b32);
+        q.nhit = (uint32_t)(t0 < INFINITY) + (uint32_t)(t1 < INFINITY) + (uint32_t)(t2 < INFINITY) + (uint32_t)(t3 < INFINITY);
+        return q;
+    }
+    // through push() / pop(): every walk outside the staged kernel, and lanes of it whose next three stack slots are not all in LDS
+    THX_DEV void visitBranchy4() {
+        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + ((size_t)cur << 3));
+        const float4 c0 = rec[0], c1 = rec[1];
+        const float t0 = slabChildFar(c0, sr, h.t), t1 = slabChildFar(c1, sr, h.t);
+        asm volatile("" ::: "memory"); // (half a record at a time: sixteen registers of boxes at once are more than the instrumented variants have left)
+        const float4 c2 = rec[2], c3 = rec[3];
+        const Quad q = quadOrder(__float_as_uint(c0.w), __float_as_uint(c1.w), __float_as_uint(c2.w), __float_as_uint(c3.w), t0, t1,
+                                 slabChildFar(c2, sr, h.t), slabChildFar(c3, sr, h.t));
+        L.cnt.add(ST_NODES, 2u + (q.r[2] != WALK_DONE ? 1u : 0u) + (q.r[3] != WALK_DONE ? 1u : 0u));
+        if (q.nhit == 0u) { cur = pop(); return; }
+        for (uint32_t want = q.nhit - 1u; want >= 1u; --want) // the farthest first: rank 1 ends up on top
+            for (int i = 0; i < 4; ++i)
+                if (q.rank[i] == want) push(q.r[i]);
+        for (int i = 0; i < 4; ++i)
+            if (q.rank[i] == 0u) cur = q.r[i];
+    }
+    // straight-line form (staged kernel, the next three stack slots in LDS): every child's ref is written -- a hit child of rank k >= 1 to
+    // its slot above the stack top, everything else to a slot nobody reads (the first one beyond the LDS part: the host adds it) --
+    // and what a pop would return is read together with the record, as in visitStraight()
+    THX_DEV void visitStraight4() {
+        const float4* rec = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(nodes) + ((size_t)cur << 3));
+        const uint32_t below = V::S16 ? (uint32_t)(int32_t)(int16_t)stack16[(int32_t)(sp << 6) - 64] : stack32[(int32_t)(sp << 6) - 64];
+        const float4 c0 = rec[0], c1 = rec[1];
+        const float4 c2 = rec[2], c3 = rec[3];
+        const float t0 = slabChildInf(c0, sr, h.t, infReg), t1 = slabChildInf(c1, sr, h.t, infReg);
+        const Quad q = quadOrder(__float_as_uint(c0.w), __float_as_uint(c1.w), __float_as_uint(c2.w), __float_as_uint(c3.w), t0, t1,
+                                 slabChildInf(c2, sr, h.t, infReg), slabChildInf(c3, sr, h.t, infReg));
+        L.cnt.add(ST_NODES, 2u + (q.r[2] != WALK_DONE ? 1u : 0u) + (q.r[3] != WALK_DONE ? 1u : 0u));
+        uint32_t nearRef = q.r[3];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+            const bool keep = q.t[i] < INFINITY && q.rank[i] != 0u;
+            const uint32_t slot = keep ? sp + q.nhit - 1u - q.rank[i] : ldsN;
+            if (V::S16) stack16[slot << 6] = (uint16_t)q.r[i];
+            else stack32[slot << 6] = q.r[i];
+        }
+#pragma unroll
+        for (int i = 2; i >= 0; --i) nearRef = q.rank[i] == 0u ? q.r[i] : nearRef;
+        cur = q.nhit != 0u ? nearRef : below;
+        sp = q.nhit != 0u ? sp + q.nhit - 1u : sp - 1u;
+    }
+
     // one round: inner nodes down to a leaf, then that leaf. No-op for a finished lane.
     THX_DEV void advance() {
 #ifdef THX_STAGE_PROFILE
@@ -562,8 +628,13 @@ struct Walker {
                 }
 #endif
 #endif
-                if (!V::SPILL || sp < ldsN) visitStraight();
-                else visitBranchy();
+                if constexpr (V::WIDE) {
+                    if (sp + 3u <= ldsN) visitStraight4();
+                    else visitBranchy4();
+                } else {
+                    if (!V::SPILL || sp < ldsN) visitStraight();
+                    else visitBranchy();
+                }
                 const bool atInner = (cur & 7u) == 0u;
                 const unsigned long long goMask = __builtin_amdgcn_ballot_w64(atInner); // (the comparison's own mask)
                 go = atInner && (THX_INNER_KEEP == 0 || (uint32_t)__popcll(goMask) >= innerKeep);
@@ -583,7 +654,8 @@ struct Walker {
                 }
             }
 #endif
-            visitBranchy();
+            if (wide) visitBranchy4();
+            else visitBranchy();
             if (THX_INNER_KEEP > 0 && (uint32_t)__popcll(__ballot((cur & 7u) == 0u)) < innerKeep) break;
         }
     innerDone:

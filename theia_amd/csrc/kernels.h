@@ -39,6 +39,7 @@ constexpr uint32_t kStagedBlock = 1024;
 #define THX_DEBUG_THREADS 768
 #endif
 constexpr uint32_t kStagedBlockDebug = THX_DEBUG_THREADS; // instrumented variants: 12 wavefronts, 168 registers per lane (dev_staged.hpp: kSchedThreadsDebug)
+constexpr uint32_t kStagedBlockDebugWidePol = 512;        // ... the polarized ones of the 4-wide walk: 8 wavefronts, 256 registers (168 left them 10 short)
 // staged kernel: the pair records of a scene go into LDS when they are at most kLdsNodeMaxBytes and still leave a pool of
 // kLdsNodeMinPool photons (measured: profiles/r03_lds_nodes.txt)
 constexpr size_t kLdsNodeMaxBytes = 48 * 1024;

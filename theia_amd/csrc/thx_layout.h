@@ -116,6 +116,7 @@ struct SceneView {
     const TreeFrame* frames;
     TreeFrame tlas; // frame 0 by value: every query starts with it
     uint32_t nInstances;
+    uint32_t wide; // `nodes` holds 4-wide records of 64 B (bvh_build.cpp: emitTree) instead of pair records
 };
 
 } // namespace thx

@@ -110,18 +110,22 @@ using PlainN = Variant<THX_POL != 0, THX_MIS != 0, false, false, 3>; // ... and 
 using DebugN = Variant<THX_POL != 0, THX_MIS != 0, true, true, 3>;
 using PlainM = Variant<THX_POL != 0, THX_MIS != 0, false, false, 4>; // 16-bit entries, deep part in global memory, pair records in LDS
 using DebugM = Variant<THX_POL != 0, THX_MIS != 0, true, true, 4>;
+using PlainW = Variant<THX_POL != 0, THX_MIS != 0, false, false, 5>; // 32-bit entries, 4-wide records (large meshes)
+using DebugW = Variant<THX_POL != 0, THX_MIS != 0, true, true, 5>;
 
 #if THX_KIND == 1
 // staged (regrouped-in-LDS) form of the scene tracer, see dev_staged.hpp
 template <class V>
-__global__ void __launch_bounds__(V::STATS ? kSchedThreadsDebug : kSchedThreads) sceneStagedKernel(const LaunchArgs args) {
+__global__ void __launch_bounds__(V::STATS ? (V::WIDE && V::POL ? kStagedBlockDebugWidePol : kSchedThreadsDebug) : kSchedThreads) sceneStagedKernel(const LaunchArgs args) {
     sceneStagedBody<V>(args);
 }
 #endif
 
 // staged kernel variants: 0/1 nothing known about the stack, 2/3 16-bit entries, 4/5 ... all in LDS, 6/7 ... and the
-// pair records too, 8/9 16-bit entries with the deep part in global memory and the pair records in LDS; odd = instrumented
+// pair records too, 8/9 16-bit entries with the deep part in global memory and the pair records in LDS, 10/11 32-bit entries and
+// 4-wide records; odd = instrumented
 static inline uint32_t stagedVariantIndex(uint32_t mode) {
+    if (mode & 32u) return 10u + (mode & 1u); // 4-wide records
     return ((mode & 1u) ? 1u : 0u) | ((mode & 4u) ? ((mode & 8u) ? ((mode & 16u) ? 6u : 4u) : ((mode & 16u) ? 8u : 2u)) : 0u);
 }
 
@@ -130,7 +134,7 @@ static inline uint32_t stagedVariantIndex(uint32_t mode) {
 #define THX_FN(prefix) THX_CAT(prefix, THX_KIND, THX_POL, THX_MIS)
 
 // mode: bit 0 = instrumented (statistics + track), bit 1 = staged kernel (scene only),
-// bit 2 = 16-bit traversal stack entries, bit 3 = the whole stack in LDS, bit 4 = the pair records in LDS
+// bit 2 = 16-bit traversal stack entries, bit 3 = the whole stack in LDS, bit 4 = the pair records in LDS, bit 5 = 4-wide records
 // (staged kernel only: variants of their own)
 hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t grid, uint32_t block,
                                 size_t lds, hipStream_t stream) {
@@ -138,12 +142,13 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
 #if THX_KIND == 1
     if (mode & 2u) {
         // > 64 KB of dynamic LDS needs an explicit opt-in (once per kernel)
-        const void* fn[10] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
+        const void* fn[12] = {reinterpret_cast<const void*>(sceneStagedKernel<Plain>), reinterpret_cast<const void*>(sceneStagedKernel<Debug>),
                              reinterpret_cast<const void*>(sceneStagedKernel<PlainS>), reinterpret_cast<const void*>(sceneStagedKernel<DebugS>),
                              reinterpret_cast<const void*>(sceneStagedKernel<PlainT>), reinterpret_cast<const void*>(sceneStagedKernel<DebugT>),
                              reinterpret_cast<const void*>(sceneStagedKernel<PlainN>), reinterpret_cast<const void*>(sceneStagedKernel<DebugN>),
-                             reinterpret_cast<const void*>(sceneStagedKernel<PlainM>), reinterpret_cast<const void*>(sceneStagedKernel<DebugM>)};
-        static bool optedIn[10] = {false, false, false, false, false, false, false, false, false, false};
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainM>), reinterpret_cast<const void*>(sceneStagedKernel<DebugM>),
+                             reinterpret_cast<const void*>(sceneStagedKernel<PlainW>), reinterpret_cast<const void*>(sceneStagedKernel<DebugW>)};
+        static bool optedIn[12] = {false, false, false, false, false, false, false, false, false, false, false, false};
         const uint32_t k = stagedVariantIndex(mode);
         if (!optedIn[k]) {
             hipError_t e = hipFuncSetAttribute(fn[k], hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
@@ -160,7 +165,9 @@ hipError_t THX_FN(traceLaunch_)(uint32_t mode, const LaunchArgs& args, uint32_t 
         case 6: hipLaunchKernelGGL((sceneStagedKernel<PlainN>), dim3(grid), dim3(block), lds, stream, args); break;
         case 7: hipLaunchKernelGGL((sceneStagedKernel<DebugN>), dim3(grid), dim3(block), lds, stream, args); break;
         case 8: hipLaunchKernelGGL((sceneStagedKernel<PlainM>), dim3(grid), dim3(block), lds, stream, args); break;
-        default: hipLaunchKernelGGL((sceneStagedKernel<DebugM>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 9: hipLaunchKernelGGL((sceneStagedKernel<DebugM>), dim3(grid), dim3(block), lds, stream, args); break;
+        case 10: hipLaunchKernelGGL((sceneStagedKernel<PlainW>), dim3(grid), dim3(block), lds, stream, args); break;
+        default: hipLaunchKernelGGL((sceneStagedKernel<DebugW>), dim3(grid), dim3(block), lds, stream, args); break;
         }
         return hipGetLastError();
     }
@@ -189,7 +196,9 @@ int THX_FN(traceOccupancy_)(uint32_t mode, uint32_t block, size_t lds) {
         case 6: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainN>, (int)block, lds); break;
         case 7: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugN>, (int)block, lds); break;
         case 8: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainM>, (int)block, lds); break;
-        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugM>, (int)block, lds); break;
+        case 9: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugM>, (int)block, lds); break;
+        case 10: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<PlainW>, (int)block, lds); break;
+        default: e = hipOccupancyMaxActiveBlocksPerMultiprocessor(&n, sceneStagedKernel<DebugW>, (int)block, lds); break;
         }
         return e == hipSuccess ? n : -1;
     }
