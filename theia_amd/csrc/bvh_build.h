@@ -11,9 +11,10 @@
 
 namespace thx {
 
-// scenes with at least this many pair records are built with 4-wide records: they need 32-bit stack entries anyway (api.cpp: stack16),
-// their hierarchies are far larger than any cache, and a 4-wide record is one 64-B line where a pair record uses half of one
-constexpr size_t kWideFromPairs = 4096;
+// scenes with at least this many pair records (1 MB of them) are built with 4-wide records: their hierarchies are larger than the caches
+// near the CUs, and a 4-wide record is one 64-B line where a pair record uses half of one. Measured on config 2 with the detector
+// sphere subdivided (profiles/r04_wide_records.txt): 20 480 triangles +2.4 %, 81 920 +-0, 327 680 -3 %, 1.3 M -4.5 %, 5.2 M -6 %.
+constexpr size_t kWideFromPairs = 32768;
 
 struct BuiltScene {
     std::vector<BvhNode> nodes;         // [TLAS | BLAS 0 | BLAS 1 | ...] (host only: the source of `pairs`)
