@@ -29,7 +29,9 @@ while time.time() - t0 < seconds:
         knobs["THX_LDS_NODES"] = str(int(gen.integers(2)))
     if gen.integers(4) == 0:
         knobs["THX_STACK32"] = "1"
-    for k in ("THX_PARK_BELOW", "THX_PARK_ROUNDS", "THX_STACK_LDS", "THX_LDS_NODES", "THX_STACK32"):
+    if gen.integers(3) == 0:  # ... 4-wide records (what large scenes get), forced onto these small ones
+        knobs["THX_WIDE"] = "1"
+    for k in ("THX_PARK_BELOW", "THX_PARK_ROUNDS", "THX_STACK_LDS", "THX_LDS_NODES", "THX_STACK32", "THX_WIDE"):
         os.environ.pop(k, None)
     os.environ.update(knobs)
     sc = make(batch=n, stats=True, key=int(gen.integers(1 << 40)), **kw)
