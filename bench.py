@@ -451,13 +451,13 @@ def main() -> None:
                 "launch": s.info,
             }
             tr = (profile_json("traffic.json", name) or {}).get("hbm_bytes_per_launch")
-            if name == "bigmesh":  # 355 MB of BVH: the walk's gathers come out of HBM
+            if name == "bigmesh":  # ~0.4 GB of BVH: the walk's gathers come out of HBM
                 entry["scene"] = s.scene_info
                 entry["roofline"] = {"bound": "hbm", "unit": "GB/s", "peak": HBM_PEAK_GBS, "traffic": tr,
                                      "achieved": tr / (r["kernel_ms"] * 1e-3) / 1e9 if tr else None,
                                      "frac": tr / (r["kernel_ms"] * 1e-3) / 1e9 / HBM_PEAK_GBS if tr else None,
                                      "note": "achieved = HBM bytes per launch from the PMC counters (2 x FETCH_SIZE + WRITE_SIZE, separate passes: "
-                                             "profiles/traffic.json) / live kernel time; 16-B gathers of quantised pair records, 355 MB of BVH"}
+                                             "profiles/traffic.json) / live kernel time; 16-B gathers of 4-wide quantised records (one 64-B line per visit), ~0.4 GB of BVH"}
             else:
                 entry["roofline"] = dict(issue_roofline(profile_json("issue.json", name), r["kernel_ms"]), traffic=tr)
             secondary.append(entry)
