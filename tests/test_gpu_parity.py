@@ -765,3 +765,50 @@ def test_mesh_with_a_million_triangles(hip_backend):
     n = 4000
     res = _both(S.config2_sphere, batch=n, stats=True, track=True, subdivide=5)
     _compare(res, n, code_agree=0.998)
+
+
+def test_hit_queues_per_config_and_page_locked_buffers_through_the_c_abi(hip_backend):
+    """thx_tracer_read_hits_cfg (one device hit queue per pipeline config; waits for that config's launch only), thx_host_register /
+    _unregister (page-locked readback buffers): argument checks, two batches in flight, the same hits as the blocking read"""
+    import ctypes as C
+
+    import theia.response
+    from theia_amd import _capi as capi
+    from theia_amd._capi import ThxError
+
+    lib, ctx = hip_backend._lib, hip_backend._ctx
+    with pytest.raises(ThxError):
+        capi.check(lib.thx_host_register(ctx, None, 16))
+    with pytest.raises(ThxError):
+        capi.check(lib.thx_host_register(None, C.c_void_p(16), 16))
+    rec = theia.response.HitRecorder()
+    sc = S.config2_sphere(batch=50_000, response=rec)
+    from theia_amd.hp.pipeline import Pipeline
+
+    pipe = Pipeline(sc.stages())
+    tr, h = sc.tracer, sc.tracer.program.handle
+    nbytes = rec.queue.nbytes
+    bufs = [rec.queue.buffer(k) for k in range(2)]
+    for b in bufs:  # (twice: registering what is registered is no error)
+        hip_backend.host_register(b)
+        hip_backend.host_register(b)
+    with pytest.raises(ThxError, match="config index"):
+        hip_backend.tracer_read_hits(h, bufs[0], True, cfg=2)
+    for k in range(2):  # both configs launched before either queue is read
+        pipe.update(k)
+        hip_backend.tracer_run(h, k, tr._assemble(k))
+    counts = []
+    for k in (1, 0):  # (read in the other order: each read waits for its own launch)
+        hip_backend.tracer_read_hits(h, bufs[k], True, cfg=k)
+        counts.append(int(bufs[k][:4].view(np.uint32)[0]))
+    assert min(counts) > 1000 and counts[0] != counts[1]  # other photons (the generator advanced between the configs)
+    again = np.zeros(nbytes, np.uint8)
+    hip_backend.tracer_read_hits(h, again, False, cfg=0)
+    assert int(again[:4].view(np.uint32)[0]) == 0  # the read above cleared the queue's counter
+    for b in bufs:
+        hip_backend.host_unregister(b)
+        hip_backend.host_unregister(b)  # (and unregistering what is not registered neither)
+    # a histogram tracer has no hit queue at all
+    plain = S.config2_sphere(batch=1000)
+    with pytest.raises(ThxError, match="hit queue"):
+        hip_backend.tracer_read_hits(plain.tracer.program.handle, again, True, cfg=0)
