@@ -529,6 +529,46 @@ def test_an_event_of_particles_through_two_pipelines(backend):
     assert not np.array_equal(total, again) and abs(again.sum() / total.sum() - 1.0) < 0.5
 
 
+@pytest.mark.gpu
+@pytest.mark.parametrize("kind", ["muon", "cascade"])
+def test_photon_tracer_with_cherenkov_sources_hip_matches_oracle(kind):
+    """VolumePhotonTracer (absorption roulette, RNG dimension restarted per run) behind a pre-sampled source, with a recorder (two hit
+    queues, batches of both configs): the hits of oracle and HIP pair up by time"""
+    from oracle_backend import OracleBackend
+    from theia_amd import _backend
+
+    n, out, prev = 40_000, {}, _backend._backend
+    for name in ("oracle", "hip"):
+        be = OracleBackend(threads=8) if name == "oracle" else _backend.HipBackend()
+        _backend._backend = be
+        try:
+            water = WaterTestModel().createMedium()
+            store = theia.material.MaterialStore([], media=[water])
+            rec = theia.response.HitRecorder()
+            rng = PhiloxRNG(key=0xBADC0DE)
+            tracer = theia.trace.VolumePhotonTracer(n, make_light(kind), SphereTarget(position=(5.0, 2.0, -8.0) * u.m, radius=4.0 * u.m),
+                                                    TL.UniformWavelengthSource(lambdaRange=(400.0, 600.0) * u.nm), rec, rng,
+                                                    medium=store.media["water"], nRuns=2, nScatteringPerRun=4)
+            rng.autoAdvance = tracer.nRNGSamples
+            pipe = pl.Pipeline(tracer.collectStages())
+            times = []
+            for k in range(2):
+                pipe.run(k)
+                q = rec.queue.view(k)
+                times.append(np.sort(np.array(q["time"][: q.count])))
+            out[name] = times
+        finally:
+            _backend._backend = prev
+            if name == "oracle":
+                be.close()
+    for a, b in zip(out["oracle"], out["hip"]):
+        assert len(a) > 300 and abs(len(a) - len(b)) <= max(2, len(a) // 200)
+        idx = np.clip(np.searchsorted(b, a), 1, len(b) - 1)
+        idx = np.where(np.abs(b[idx - 1] - a) < np.abs(b[idx] - a), idx - 1, idx)
+        assert (np.abs(b[idx] - a) < 1e-3).mean() > 0.99
+    assert not np.array_equal(out["hip"][0], out["hip"][1])
+
+
 # ---- theia.cascades (tests/test_cascades.py:8-33) ------------------------------------------------------------------------------
 
 @pytest.mark.parametrize("pType", list(theia.cascades.ParticleType))
