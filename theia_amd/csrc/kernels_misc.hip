@@ -198,7 +198,7 @@ __global__ void __launch_bounds__(kReplayBlock) samplerKernel(const LaunchArgs a
 }
 
 // The same for a ParticleCascadeLightSource, whose depth sample comes out of a rejection loop (random.gamma.glsl) that the shader's
-// constants make long -- five proposals per sample on average at alpha = 6, the slowest of 64 lanes three times that: with one
+// constants make long -- 13.5 proposals per sample on average at alpha = 6.4 (8.5 at 4.2), the slowest of 64 lanes a multiple of that: with one
 // photon per lane a wavefront runs the loop at a third of its lanes. Here a wavefront works through kCascadePerWave photons: in the
 // loop a lane whose proposal was accepted takes the next photon of the wave's range at once (ballot + prefix count: no atomics, and
 // which lane draws which photon changes nothing -- a photon's random numbers are addressed by its index), the accepted samples and
