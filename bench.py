@@ -42,6 +42,7 @@ import os
 import sys
 import time
 
+os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")  # (RCCL between the ranks of one node: this pool's driver supports dmabuf IPC only)
 os.environ.setdefault("GPU_MAX_HW_QUEUES", "16")  # before torch / HIP initialise: the scheduler-flow lines keep 8 launches side by side (theia_amd/__init__.py)
 ROOT = os.path.dirname(os.path.abspath(__file__))
 for _p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "oracle")):
