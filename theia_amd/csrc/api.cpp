@@ -612,7 +612,7 @@ int thx_tracer_create(thx_ctx* ctx, const thx_tracer_desc* desc, thx_scene* scen
         if (const char* env = std::getenv("THX_POOL_LDS_KB")) budget = (size_t)std::max(16, std::atoi(env)) * 1024;
         // Deep hierarchies: rays use the worst-case depth rarely, so only the first kStackLds entries (THX_STACK_LDS)
         // come out of LDS and the rest lives in global memory (dev_walk.hpp: Walker::push)
-        t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : kStackLds32);
+        t->stackLds = std::min(t->stackDepth, t->stack16 ? kStackLds16 : (scene->wide ? kStackLds32Wide : kStackLds32));
         if (const char* env = std::getenv("THX_STACK_LDS")) t->stackLds = (uint32_t)std::min<int>((int)t->stackDepth, std::max(1, std::atoi(env)));
         // one more slot per lane below entry 0 (dev_walk.hpp: Walker<V, FAST>)
         // (the variants compiled for a stack that is all in LDS do not check for a full stack: only where it cannot fill up)

@@ -48,6 +48,7 @@ constexpr uint32_t kLdsNodeMinPool = 1056;
 // workgroup can turn over: 1264 at the end of round 2, 1344 with 64 B per photon, and with the kernels of the end of round 3
 // config 2 read through the vector cache (THX_LDS_NODES=0) runs 2.58 / 2.48 / 2.48 ms at 1344 / 1472 / 1600; config 5 and the
 // large meshes are flat from 1344 on (gpurun_out/r03/sweep20-22.txt)
+constexpr uint32_t kStackLds32Wide = 14; // 4-wide records (up to three pushes per visit): 1.3 M / 5.2 M triangles -1.3 / -1.4 % against 12, 16 is slower again (profiles/r04_wide_records.txt)
 constexpr uint32_t kPoolBest = 1472;
 constexpr uint32_t kPoolMax = 2048; // == THX_POOL_MAX of dev_staged.hpp: the largest pool any sizing (or THX_POOL) can pick
 
