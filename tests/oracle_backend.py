@@ -69,11 +69,21 @@ class OracleBackend:
     def free(self, addr: int) -> None:
         self._blobs.pop(addr, None)
 
+    def _inside(self, addr: int, nbytes: int):
+        """(blob, offset) of an address range inside one of the allocations -- the stand-in for device pointer arithmetic"""
+        for base, blob in self._blobs.items():
+            if base <= addr and addr + nbytes <= base + blob.buf.nbytes:
+                return blob, addr - base
+        raise KeyError(f"address range {addr:#x} + {nbytes} lies in no allocation")
+
     def upload(self, addr: int, data) -> None:
-        self._blobs[addr].upload(bytes(data))
+        raw = np.frombuffer(bytes(data), dtype=np.uint8)
+        blob, off = self._inside(addr, raw.nbytes)
+        blob.buf[off:off + raw.nbytes] = raw
 
     def download(self, addr: int, nbytes: int) -> bytes:
-        return self._blobs[addr].buf[:nbytes].tobytes()
+        blob, off = self._inside(addr, nbytes)
+        return blob.buf[off:off + nbytes].tobytes()
 
     # scene
     def scene_create(self, meshes, instances) -> int:

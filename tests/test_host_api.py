@@ -362,3 +362,50 @@ def test_addresses_keep_their_memory_alive(backend):
     del tracer
     gc.collect()
     assert blob() is None
+
+
+def test_buffers_tensors_and_copy_commands(backend):
+    """the hephaistos memory surface user code stages its own data with (theia_amd/hp/memory.py): typed buffers and tensors, update /
+    retrieve / clear with offsets, execute and beginSequence, addresses that fit buffer_reference parameters"""
+    import ctypes
+
+    import hephaistos as hp
+
+    src = hp.FloatBuffer(np.arange(12, dtype=np.float32).reshape(3, 4))
+    assert src.size_bytes == 48 and src.numpy().shape == (3, 4)
+    t = hp.FloatTensor(12)
+    out = hp.FloatBuffer(12)
+    hp.execute(hp.updateTensor(src, t), hp.retrieveTensor(t, out))
+    assert np.array_equal(out.numpy(), np.arange(12))
+    # a range in the middle, then cleared words
+    part = hp.FloatBuffer([100.0, 101.0])
+    seq = hp.beginSequence().And(hp.updateTensor(part, t, tensorOffset=16)).Then(hp.clearTensor(t, offset=40, size=8, data=0x3F800000)).Then(hp.retrieveTensor(t, out))
+    assert np.array_equal(out.numpy(), np.arange(12))  # (nothing ran yet)
+    seq.Submit().wait()
+    assert np.array_equal(out.numpy(), [0, 1, 2, 3, 100, 101, 6, 7, 8, 9, 1, 1])
+    with pytest.raises(ValueError):
+        hp.updateTensor(part, t, tensorOffset=44, size=8)
+    with pytest.raises(ValueError):
+        hp.clearTensor(t, offset=2, size=4)
+    # tensors made from data; addresses are integers that keep the allocation alive
+    u = hp.UnsignedIntTensor(np.array([7, 8, 9], dtype=np.uint32))
+    back = hp.UnsignedIntBuffer(3)
+    hp.execute([hp.retrieveTensor(u, back)], hp.flushMemory())
+    assert list(back.numpy()) == [7, 8, 9] and isinstance(u.address, int) and int(u) == u.address and u.address.owner is u._blob
+
+    class Item(ctypes.Structure):
+        _fields_ = [("a", ctypes.c_float), ("b", ctypes.c_uint32)]
+
+    items = hp.ArrayBuffer(Item, 4)
+    items.numpy()["b"] = [1, 2, 3, 4]
+    dev = hp.ArrayTensor(Item, 4)
+    again = hp.ArrayBuffer(Item, 4)
+    hp.execute(hp.updateTensor(items, dev), hp.retrieveTensor(dev, again))
+    assert list(again.numpy()["b"]) == [1, 2, 3, 4]
+    one = hp.StructureBuffer(Item)
+    one.a, one.b = 2.5, 9
+    assert one.numpy().view(np.float32)[0] == 2.5 and one.b == 9
+    with pytest.raises(NotImplementedError):
+        hp.Tensor(16, mapped=True)
+    with pytest.raises(NotImplementedError):
+        hp.Program(b"")

@@ -1,21 +1,25 @@
 """
 The slice of the `hephaistos` API that theia's forward tracers, examples and
 tests touch, implemented on the HIP backend: device queries,
-`Mesh`, and the `pipeline` / `glsl` submodules. Vulkan-specific entry points
-(programs, compilers, command sequences) have no counterpart here and are not
-provided -- component GLSL injection is replaced by compiled kernel variants.
+`Mesh`, buffers / tensors and the commands that copy between them (`memory`),
+and the `pipeline` / `glsl` / `queue` submodules. Programs and compilers (GLSL
+at run time) have no counterpart here -- component GLSL injection is replaced
+by compiled kernel variants -- and say so when constructed.
 """
 from __future__ import annotations
 
 import numpy as np
 
 from .. import _backend
-from . import glsl, pipeline, queue  # noqa: F401
+from . import glsl, memory, pipeline, queue  # noqa: F401
+from .memory import *  # noqa: F401,F403
+from .pipeline import Command  # noqa: F401
 
 __all__ = [
     "Mesh", "getCurrentDevice", "isRaytracingSupported", "isRaytracingEnabled", "enableRaytracing",
-    "suitableDeviceAvailable", "destroyResources", "selectDevice", "enumerateDevices", "glsl", "pipeline", "queue",
-]
+    "suitableDeviceAvailable", "destroyResources", "selectDevice", "enumerateDevices", "enableAtomics", "Command", "glsl", "pipeline", "queue",
+    "memory",
+] + memory.__all__
 
 
 class Device:
