@@ -152,3 +152,60 @@ def test_store_update_rules(oracle_backend):
         store.updateMedium(M.Medium("other", 200.0, 800.0))
     with pytest.raises(ValueError):
         M.MaterialStore([M.Material("m", "missing", None)])
+
+
+@pytest.mark.parametrize("where", ["zip", "directory"])
+def test_materials_on_disk(tmp_path, where):
+    """saveMaterials / loadMaterials (the reference's tests/test_material.py:360-442, restated): media with tables of different
+    lengths, materials that hold or name their media, an extra medium; to a zip file and to a directory"""
+    import json
+
+    import theia_amd.material as M
+
+    gen = np.random.default_rng(0xC0FFEE)
+    f32 = lambda n, scale=1.0: (gen.random(n, dtype=np.float32) * scale)
+    med1 = M.Medium("med1", 400.0, 800.0, refractive_index=f32(256, 2.0), group_velocity=f32(128), absorption_coef=f32(64, 5.0),
+                    scattering_coef=f32(97, 5.0), log_phase_function=f32(156), phase_sampling=f32(648, 3.14), phase_m12=f32(354),
+                    phase_m22=f32(416), phase_m33=f32(422), phase_m34=f32(235))
+    med2 = M.Medium("med2", 500.0, 700.0, refractive_index=f32(199, 4.5), group_velocity=f32(256, 0.8), absorption_coef=f32(145, 25.0),
+                    scattering_coef=f32(263, 25.0), log_phase_function=f32(105), phase_sampling=f32(156))
+    extra = M.Medium("extra", 450.0, 650.0, refractive_index=f32(199), group_velocity=f32(156, 0.8))
+    mat1 = M.Material("mat1", "med1", med2, flags=("R", "Tfb"))
+    mat2 = M.Material("mat2", med1, None, flags=("B", "RbTf"))
+    path = tmp_path / ("materials.zip" if where == "zip" else "materials")
+    if where == "directory":
+        path.mkdir()
+    M.saveMaterials(path, [mat1, mat2], media=[extra])
+    mat, med = M.loadMaterials(path)
+    assert med.keys() == {"med1", "med2", "extra"} and mat.keys() == {"mat1", "mat2"}
+    for got, want in ((med["med1"], med1), (med["med2"], med2), (med["extra"], extra)):
+        assert (got.lambda_min, got.lambda_max) == (want.lambda_min, want.lambda_max)
+        assert got.tables().keys() == want.tables().keys()
+        for key, table in want.tables().items():
+            assert np.array_equal(got.tables()[key], table), key
+    assert mat["mat1"].inside is med["med1"] and mat["mat1"].outside is med["med2"]
+    assert mat["mat2"].inside is med["med1"] and mat["mat2"].outside is None
+    for name, want in (("mat1", mat1), ("mat2", mat2)):
+        assert mat[name].flagsInward == want.flagsInward and mat[name].flagsOutward == want.flagsOutward
+    # what a broken tree says
+    with pytest.raises(ValueError, match="unknown medium"):
+        M.saveMaterials(tmp_path / "other.zip", [M.Material("m", "nowhere", None)])
+    if where == "directory":
+        listing = json.loads((path / "material.json").read_text())
+        (path / "material.json").write_text(json.dumps(listing + [dict(listing[0])]))
+        with pytest.raises(ValueError, match="Duplicate"):
+            M.loadMaterials(path)
+        (path / "material.json").write_text(json.dumps([{"name": "m", "inside": "gone", "outside": None, "flagsInward": 0, "flagsOutward": 0}]))
+        with pytest.raises(ValueError, match="unknown medium"):
+            M.loadMaterials(path)
+        (path / "material.json").write_text(json.dumps([{"name": "m", "inside": None, "outside": None, "flagsInward": -1, "flagsOutward": 0}]))
+        with pytest.raises(ValueError, match="negative"):
+            M.loadMaterials(path)
+        (path / "material.json").write_text("{")
+        with pytest.raises(ValueError, match="Invalid material description"):
+            M.loadMaterials(path)
+        (path / "material.json").unlink()
+        with pytest.raises(ValueError, match="Missing file"):
+            M.loadMaterials(path)
+    with pytest.raises(ValueError):
+        M.loadMaterials(tmp_path / "nothing-here")
