@@ -409,3 +409,24 @@ def test_buffers_tensors_and_copy_commands(backend):
         hp.Tensor(16, mapped=True)
     with pytest.raises(NotImplementedError):
         hp.Program(b"")
+
+
+def test_util_helpers():
+    """theia.util: integers in and out of uvec fields, the structure-of-arrays view, the macro text; the shader loaders say what they are"""
+    import ctypes
+
+    import theia.util as tu
+
+    big = 0x0123456789ABCDEF_FEDCBA9876543210
+    assert tu.uvec4ToInt(tu.intToUvec4(big)) == big and tu.intToUvec4(big).w == 0x01234567
+    assert tu.unpackUint64(tu.packUint64(0xDEADBEEF_00C0FFEE)) == 0xDEADBEEF_00C0FFEE and tu.packUint64(5).y == 0
+    assert tu.createPreamble(N=4, POLARIZATION=True, OFF=False, NAME="x") == "#define N 4\n#define POLARIZATION\n#define NAME x\n"
+
+    class Item(ctypes.Structure):
+        _fields_ = [("value", ctypes.c_float), ("id", ctypes.c_uint32)]
+
+    raw = np.concatenate([np.arange(5, dtype=np.float32).view(np.uint32), np.arange(10, 15, dtype=np.uint32)])
+    view = tu.viewSoA(raw.ctypes.data, Item, 5)
+    assert list(view["value"]) == [0, 1, 2, 3, 4] and list(view["id"]) == [10, 11, 12, 13, 14]
+    with pytest.raises(NotImplementedError):
+        tu.compileShader("tracer.scene.forward.glsl")
