@@ -209,3 +209,22 @@ def test_materials_on_disk(tmp_path, where):
             M.loadMaterials(path)
     with pytest.raises(ValueError):
         M.loadMaterials(tmp_path / "nothing-here")
+
+
+def test_sample_table_2d():
+    """lookup.sampleTable2D: scattered samples of a plane come back as the plane on the regular grid (linear and cubic), rows = y"""
+    from theia_amd.lookup import sampleTable2D
+
+    gen = np.random.default_rng(3)
+    pts = gen.random((4000, 2)) * [2.0, 3.0]
+    data = np.column_stack([pts, 1.0 + 2.0 * pts[:, 0] - pts[:, 1]])
+    x, y = np.linspace(0.2, 1.8, 16), np.linspace(0.3, 2.7, 8)
+    want = 1.0 + 2.0 * x[None, :] - y[:, None]
+    for mode in ("linear", "cubic"):
+        table = sampleTable2D(data, 16, 8, boundaries=((0.2, 1.8), (0.3, 2.7)), mode=mode)
+        assert np.asarray(table.data).shape == (8, 16) and np.allclose(table.data, want, atol=1e-5)
+    assert np.asarray(sampleTable2D(data, 4, 5).data).shape == (5, 4)
+    with pytest.raises(RuntimeError):
+        sampleTable2D(data, 4, 4, mode="nearest")
+    with pytest.raises(RuntimeError):
+        sampleTable2D(data, 4, 4, boundaries=(0.0, 1.0, 2.0))

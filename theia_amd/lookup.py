@@ -14,7 +14,7 @@ import numpy as np
 
 from . import _backend
 
-__all__ = ["Table", "getTableSize", "uploadTables", "sampleTable1D", "evalTable"]
+__all__ = ["Table", "getTableSize", "uploadTables", "sampleTable1D", "sampleTable2D", "evalTable"]
 
 
 class Table:
@@ -109,6 +109,26 @@ def sampleTable1D(data, nx: int = 1024, *, boundary=None, mode: Literal["linear"
 
         return Table(CubicSpline(data[:, 0], data[:, 1])(x))
     raise RuntimeError("Unknown interpolation mode!")
+
+
+def sampleTable2D(data, nx: int = 1024, ny: int = 1024, *, boundaries=None, mode: Literal["linear", "cubic"] = "linear") -> Table:
+    """Resamples scattered (x, y, f(x, y)) rows onto a regular `ny` x `nx` grid (rows: y) by triangulation -- piecewise linear, or
+    Clough-Tocher cubic; `boundaries`: ((x_min, x_max), (y_min, y_max)), either may be None = the data's own range. No kernel of this
+    backend reads 2-D tables (neither does a shader of the reference); the table is there for user code (lookup.py:181-238)."""
+    from scipy.interpolate import CloughTocher2DInterpolator, LinearNDInterpolator
+
+    data = np.asarray(data, dtype=np.float64)
+    if boundaries is not None and not (isinstance(boundaries, tuple) and len(boundaries) == 2):
+        raise RuntimeError("Cant parse given boundaries!")
+    axes = []
+    for column, count, bounds in ((0, nx, None if boundaries is None else boundaries[0]), (1, ny, None if boundaries is None else boundaries[1])):
+        lo, hi = (data[:, column].min(), data[:, column].max()) if bounds is None else bounds
+        axes.append(np.linspace(lo, hi, count))
+    if mode not in ("linear", "cubic"):
+        raise RuntimeError("Unknown interpolation mode!")
+    model = LinearNDInterpolator if mode == "linear" else CloughTocher2DInterpolator
+    gx, gy = np.meshgrid(*axes)
+    return Table(model(data[:, :2], data[:, 2])(gx, gy))
 
 
 def evalTable(f, *axes) -> Table:
