@@ -430,3 +430,16 @@ def test_util_helpers():
     assert list(view["value"]) == [0, 1, 2, 3, 4] and list(view["id"]) == [10, 11, 12, 13, 14]
     with pytest.raises(NotImplementedError):
         tu.compileShader("tracer.scene.forward.glsl")
+
+
+def test_what_is_not_there_says_so():
+    """names of the reference this backend does not provide fail with a reason, not with an AttributeError deep inside user code"""
+    import theia.camera
+    import theia.trace
+
+    with pytest.raises(NotImplementedError, match="backward"):
+        theia.camera.PencilCamera
+    with pytest.raises(AttributeError):
+        theia.camera.nonsense
+    with pytest.raises(NotImplementedError, match="forward tracing path"):
+        theia.trace.BidirectionalPathTracer

@@ -10,7 +10,7 @@ import sys as _sys
 
 import hephaistos as _hp  # noqa: F401  (mirrors the reference: device comes up with the package)
 
-_NAMES = ("units", "lookup", "material", "random", "light", "target", "response", "scene", "trace", "testing", "task", "cascades", "util")
+_NAMES = ("units", "lookup", "material", "random", "light", "target", "response", "scene", "trace", "testing", "task", "cascades", "util", "camera")
 for _n in _NAMES:
     _m = _importlib.import_module(f"theia_amd.{_n}")
     _sys.modules[f"{__name__}.{_n}"] = _m

@@ -590,3 +590,13 @@ class VolumePhotonTracer(VolumeForwardTracer):
         P.photon_steps_per_run = self._nScatteringPerRun
         P.photon_rng_per_run = self._nRNGPerRun
         return P
+
+
+_BACKWARD = ("VolumeBackwardTracer", "SceneBackwardTracer", "SceneBackwardTargetTracer", "DirectLightTracer", "BidirectionalPathTracer")
+
+
+def __getattr__(name: str):
+    if name in _BACKWARD:
+        raise NotImplementedError(f"theia.trace.{name}: backward, direct and bidirectional tracers are not provided by the HIP backend "
+                                  "(SURVEY.md 8: the forward tracing path -- VolumeForwardTracer, SceneForwardTracer and the photon tracers)")
+    raise AttributeError(f"module {__name__!r} has no attribute {name!r}")
